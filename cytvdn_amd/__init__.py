@@ -1,0 +1,22 @@
+"""cytvdn_amd -- MI355X-native anisotropic TV denoising behind the cyTVDN API.
+
+`import cytvdn_amd as tv` gives the names `import cyTVDN as tv` gives (reference
+cyTVDN/__init__.py:1): denoise4D, denoise3D, check_memory and the kernel-level
+accumulator_update_* / datacube_update_* / sum_square_error_* functions.  All arithmetic runs in
+hand-written HIP kernels for gfx950 (libtvdn_hip.so, C ABI in include/tvdn.h); there is no CPU
+fallback: compute calls raise when the library or the GPU is missing.
+"""
+from .driver import check_memory, denoise3D, denoise4D
+from .kernels import (accumulator_update_3D, accumulator_update_3D_FISTA, accumulator_update_4D,
+                      accumulator_update_4D_FISTA, datacube_update_3D, datacube_update_4D,
+                      iso_accumulator_update_4D, iso_accumulator_update_4D_FISTA, sum_square_error_3D,
+                      sum_square_error_4D)
+
+__version__ = "0.1.0"
+
+__all__ = [
+    "denoise4D", "denoise3D", "check_memory",
+    "accumulator_update_4D", "accumulator_update_4D_FISTA", "accumulator_update_3D", "accumulator_update_3D_FISTA",
+    "datacube_update_4D", "datacube_update_3D", "sum_square_error_4D", "sum_square_error_3D",
+    "iso_accumulator_update_4D", "iso_accumulator_update_4D_FISTA",
+]

@@ -1,0 +1,135 @@
+"""ctypes binding of libtvdn_hip.so (C ABI: include/tvdn.h).
+
+There is no CPU fallback anywhere in this package: if the shared library is missing, or no
+MI355X is visible when a compute call is made, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+# torch is imported BEFORE the library on purpose: it ships its own HIP runtime with soname
+# libamdhip64.so.7, and loading it first makes libtvdn_hip.so bind to that same runtime, so
+# pointers and streams handed over from torch tensors are valid in our launches.
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtvdn_hip.so")
+
+TVDN_F32, TVDN_F64 = 0, 1
+EDGE_BC, EDGE_HALO, EDGE_ZERO = 0, 1, 2
+
+EXPORTS = (
+    "tvdn_abi_version", "tvdn_last_error", "tvdn_device_count", "tvdn_ctx_create", "tvdn_ctx_destroy",
+    "tvdn_ctx_timing_enable", "tvdn_ctx_timing_read",
+    "tvdn_accumulator_update", "tvdn_datacube_update", "tvdn_sum_square_error", "tvdn_iterate_fused",
+    "tvdn_synth_fill",
+)
+
+
+class TvdnError(RuntimeError):
+    pass
+
+
+class IterArgs(C.Structure):
+    """struct tvdn_iter_args (include/tvdn.h)."""
+    _fields_ = [
+        ("dtype", C.c_int32), ("ndim", C.c_int32), ("shape", C.c_int64 * 4),
+        ("row_lo", C.c_int64), ("row_hi", C.c_int64),
+        ("lo_mode", C.c_int32), ("hi_mode", C.c_int32), ("bc_mode", C.c_int32), ("fista", C.c_int32),
+        ("tk", C.c_double), ("clip", C.c_double * 4), ("lambda_mu", C.c_double * 4),
+        ("orig", C.c_void_p), ("recon_in", C.c_void_p), ("recon_out", C.c_void_p),
+        ("b_in", C.c_void_p * 4), ("b_out", C.c_void_p * 4), ("d_in", C.c_void_p * 4), ("d_out", C.c_void_p * 4),
+    ]
+
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libtvdn_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc")]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises TvdnError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TvdnError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C cytvdn_amd/csrc`.  cytvdn_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.tvdn_abi_version.restype = C.c_int
+    L.tvdn_last_error.restype = C.c_char_p
+    L.tvdn_device_count.restype = C.c_int
+    L.tvdn_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.tvdn_ctx_destroy.argtypes = [C.c_void_p]
+    L.tvdn_ctx_timing_enable.argtypes = [C.c_void_p, C.c_int]
+    L.tvdn_ctx_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    i64p = C.POINTER(C.c_int64)
+    L.tvdn_accumulator_update.argtypes = [C.c_void_p, C.c_int, C.c_int, i64p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_double, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+    L.tvdn_datacube_update.argtypes = [C.c_void_p, C.c_int, C.c_int, i64p, C.c_void_p, C.c_void_p,
+                                       C.POINTER(C.c_void_p), C.POINTER(C.c_double), C.c_int, C.c_void_p, C.c_void_p]
+    L.tvdn_sum_square_error.argtypes = [C.c_void_p, C.c_int, C.c_int, i64p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]
+    L.tvdn_iterate_fused.argtypes = [C.c_void_p, C.POINTER(IterArgs), C.c_void_p, C.c_void_p]
+    L.tvdn_synth_fill.argtypes = [C.c_int, C.c_int, i64p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    for name in EXPORTS:
+        getattr(L, name)  # AttributeError here = header and library out of step
+    if L.tvdn_abi_version() != 1:
+        raise TvdnError("libtvdn_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib().tvdn_last_error().decode("utf-8", "replace")
+        if rc == -2:
+            raise NotImplementedError(msg)
+        if rc == -1:
+            raise ValueError(msg)
+        raise TvdnError(f"libtvdn_hip status {rc}: {msg}")
+
+
+def dtype_code(dt) -> int:
+    dt = np.dtype(dt)
+    if dt == np.float32:
+        return TVDN_F32
+    if dt == np.float64:
+        return TVDN_F64
+    raise TypeError("No matching signature found")
+
+
+def shape_arr(shape):
+    return (C.c_int64 * len(shape))(*[int(s) for s in shape])
+
+
+_ctxs: dict[int, C.c_void_p] = {}
+
+
+def ctx(device: int) -> C.c_void_p:
+    """Per-device reduction scratch (created lazily; raises when no GPU is visible)."""
+    h = _ctxs.get(device)
+    if h is None:
+        if not torch.cuda.is_available():
+            raise TvdnError("no MI355X visible (torch.cuda.is_available() is False): cytvdn_amd has no CPU fallback")
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            check(lib().tvdn_ctx_create(C.byref(h), int(device)))
+        _ctxs[device] = h
+    return h
+
+
+def current_stream(device: int) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,288 @@
+"""denoise4D / denoise3D / check_memory with the reference's signatures, on the MI355X engine.
+
+Reference: cyTVDN/cyTVDN.py:19-247 (denoise4D), :250-435 (denoise3D), :438-467 (check_memory).
+Same arguments, same defaults, same assertions, same return tuple; the iteration loop
+(cyTVDN.py:147-242, :368-430) runs device-resident: the datacube is copied to HBM once, every
+iteration is one fused HIP sweep (csrc/tvdn_fused.hip), the convergence scalars are reduced on
+the device into per-iteration slots and read back once at the end (or per iteration only when
+`stopping_relative_change` asks for it), and the result is copied back once.
+
+Differences, all deliberate:
+  * BC_mode=1 raises NotImplementedError: upstream's mirror reconstruction update indexes out of
+    bounds (utils.pyx:117-120) and the 3-D variant returns NaN (utils.pyx:192-197).
+  * isotropic_R / isotropic_Q raise NotImplementedError: the semi-isotropic scheme "appears to have
+    an error, and should not be used" (README.md:9).
+  * b_norm / delta_recon / MSE are reduced in f64 by a fixed tree and then cast to the data dtype;
+    upstream's dtype-width OpenMP sums drift with the thread count (1e-2 at 1e7 f32 voxels).
+  * Memory notes are about HBM, not host RAM.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import HipBackend, SlabLayout, SlabRunner, hbm_plan
+
+try:  # tqdm is what upstream shows (cyTVDN.py:148-152); it is optional here
+    from tqdm import tqdm as _tqdm
+except Exception:  # pragma: no cover
+    _tqdm = None
+
+
+def _fmt_bytes(n: float) -> str:
+    for unit in ("B", "KiB", "MiB", "GiB", "TiB"):
+        if n < 1024 or unit == "TiB":
+            return f"{n:.1f} {unit}" if unit != "B" else f"{int(n)} B"
+        n /= 1024.0
+    return f"{n:.1f} TiB"
+
+
+def _hbm_free(device: int):
+    if not torch.cuda.is_available():
+        return None
+    free, total = torch.cuda.mem_get_info(device)
+    return free, total
+
+
+def _split_iterations(iterations, FISTA):
+    # reference cyTVDN.py:99-108 / :322-331
+    unaccelerated = not FISTA
+    if type(iterations) in (list, tuple):
+        FISTA = True
+        unaccelerated = True
+        n_fista, n_plain = int(iterations[0]), int(iterations[1])
+    else:
+        n_fista, n_plain = int(iterations * FISTA), int(iterations * (not FISTA))
+    return bool(FISTA), bool(unaccelerated), n_fista, n_plain
+
+
+def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, reference_data, BC_mode, quiet,
+         device):
+    dtype = datacube.dtype
+    lambdaInv = 1.0 / lam                      # cyTVDN.py:77 / :303
+    lam_mu = (lam / mu).astype(dtype)          # cyTVDN.py:78 / :304
+    FISTA, unaccelerated, n_fista, n_plain = _split_iterations(iterations, FISTA)
+    n_total = n_fista + n_plain
+
+    if BC_mode == 1:
+        raise NotImplementedError("BC_mode=1 (mirror): the reference's reconstruction update reads out of bounds "
+                                  "(utils.pyx:117-120); not reproduced")
+    if BC_mode not in (0, 2):
+        raise ValueError(f"BC_mode must be 0 or 2, got {BC_mode}")
+
+    if not quiet:
+        plan = hbm_plan(datacube.shape, dtype, FISTA)
+        kind = "FISTA Accelerated" if FISTA else "Unaccelerated"
+        print(f"{kind} TV denoising will keep {plan['arrays']} arrays = {_fmt_bytes(plan['bytes'])} in HBM...", flush=True)
+
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    layout = SlabLayout(tuple(datacube.shape), 0, 1, int(BC_mode))
+    be = HipBackend(layout, dtype, FISTA, device=device, max_iters=n_total)   # raises without a GPU
+    be.set_params(lambdaInv, lam_mu)
+    be.set_input(datacube)
+    runner = SlabRunner(be)
+
+    calculate_MSE = reference_data is not None
+    mse_dev = ref_dev = None
+    if calculate_MSE:
+        ref_dev = torch.from_numpy(np.ascontiguousarray(reference_data)).to(be.orig.device)
+        mse_dev = torch.zeros(n_total + 1, dtype=torch.float64, device=be.orig.device)
+        be.sse(ref_dev, mse_dev[0:1])          # MSE[0] = input vs reference (cyTVDN.py:124-125)
+
+    bars = []
+
+    def on_iter(slot):
+        if calculate_MSE:
+            be.sse(ref_dev, mse_dev[slot + 1:slot + 2])
+        if bars:
+            bars[-1].update(1)
+        if stopping_relative_change is not None:
+            s = be.sums[slot].cpu().numpy()   # one small read-back per iteration, only in this mode
+            with np.errstate(divide="ignore", invalid="ignore"):
+                delta = dtype.type(dtype.type(s[1]) / dtype.type(s[2]))
+            if delta < stopping_relative_change:
+                return True
+        return False
+
+    def phase(n, tk_phase, desc):
+        if n <= 0:
+            return
+        if _tqdm is not None:
+            bars.append(_tqdm(total=n, desc=desc, leave=not quiet))
+        try:
+            runner.run(n if tk_phase else 0, 0 if tk_phase else n, on_iter)
+        finally:
+            if bars:
+                bars.pop().close()
+
+    # the plain phase always starts at slot n_fista, also when the FISTA phase broke early (cyTVDN.py:201)
+    if FISTA:
+        phase(n_fista, True, "FISTA Accelerated TV Denoising")
+        runner.iter = n_fista
+    if unaccelerated:
+        phase(n_plain, False, "Unaccelerated TV Denoising")
+
+    sums = be.sums.cpu().numpy()[:n_total] if n_total else np.zeros((0, 3))
+    ran = np.zeros(n_total, dtype=bool)
+    ran[runner.ran] = True
+    # slots of iterations that never ran keep the reference's zero tail (cyTVDN.py:127-128)
+    b_norm = np.where(ran, sums[:, 0], 0.0).astype(dtype)
+    num, den = sums[:, 1].astype(dtype), sums[:, 2].astype(dtype)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        delta_recon = np.where(ran, num / den, dtype.type(0)).astype(dtype)   # divided in the data dtype (utils.pyx:125)
+    recon = be.recon_tensor().cpu().numpy()
+
+    if stopping_relative_change is not None and not quiet and unaccelerated and n_plain and not ran[-1]:
+        print(f"Stopping condition reached after {int(np.nonzero(ran)[0][-1])} iterations, stopping.")
+
+    if calculate_MSE:
+        return recon, b_norm, delta_recon, mse_dev.cpu().numpy().astype(dtype)
+    return recon, b_norm, delta_recon
+
+
+def denoise4D(
+    datacube: np.ndarray,
+    mu: np.ndarray,
+    iterations: int = 10,
+    FISTA: bool = True,
+    stopping_relative_change: Optional[float] = None,
+    isotropic_R: bool = False,
+    isotropic_Q: bool = False,
+    reference_data: Optional[np.ndarray] = None,
+    BC_mode: int = 2,
+    lam: Optional[np.ndarray] = None,
+    quiet: bool = False,
+    device: Optional[int] = None,
+) -> Tuple[np.ndarray, np.ndarray, np.ndarray, Optional[np.ndarray]]:
+    """Proximal anisotropic TV denoising of a 4-D datacube on one MI355X.
+
+    Arguments, defaults and return value are those of the reference's denoise4D
+    (cyTVDN/cyTVDN.py:19-60); `device` (keyword only in practice) selects the GPU.
+
+    datacube  C-contiguous 4-D float32/float64 array (never modified)
+    mu        4-element array, TV weight per axis, same dtype
+    iterations  int, or [n_FISTA, n_unaccelerated] for the hybrid schedule
+    FISTA     use FISTA acceleration (about twice the state in HBM)
+    stopping_relative_change  stop a phase when delta_recon drops below this
+    reference_data  noise-free cube; adds the per-iteration sum of squared errors (MSE) to the result
+    BC_mode   0 periodic, 2 Jia-Zhao (default); 1 (mirror) is not supported (see module docstring)
+    lam       4-element array, default mu/32
+    Returns (recon, b_norm, delta_recon[, MSE]).
+    """
+    assert isinstance(datacube, np.ndarray) and datacube.dtype in (
+        np.float32,
+        np.float64,
+    ), "datacube must be floating point datatype."
+    if datacube.ndim != 4:
+        raise TypeError("No matching signature found")
+    mu = np.asarray(mu)
+    if lam is None:
+        lam = mu * 1.0 / 32.0
+    lam = np.asarray(lam)
+    assert lam.dtype == datacube.dtype, "Lambda must have same dtype as datacube."
+    assert mu.dtype == datacube.dtype, "Mu must have same dtype as datacube."
+    assert datacube.flags["C_CONTIGUOUS"], \
+        "datacube must be C-contiguous. Try np.ascontiguousarray(datacube) on the array."
+    if isotropic_R or isotropic_Q:
+        raise NotImplementedError("the semi-isotropic scheme 'appears to have an error, and should not be used' "
+                                  "(reference README.md:9); use the anisotropic scheme")
+    if mu.shape != (4,) or lam.shape != (4,):
+        raise ValueError("mu and lam must have 4 entries")
+    if reference_data is not None and (reference_data.shape != datacube.shape or reference_data.dtype != datacube.dtype):
+        raise ValueError("reference_data must match the datacube's shape and dtype")
+
+    lam_mu = (lam / mu).astype(datacube.dtype)
+    if not quiet:
+        try:
+            print(f"λ/μ ≈ [1/{mu[0]/lam[0]:.0f}, 1/{mu[1]/lam[1]:.0f}, 1/{mu[2]/lam[2]:.0f}, 1/{mu[3]/lam[3]:.0f}]")
+        except Exception:
+            print("lambda/mu ~ [" + ", ".join(f"1/{m/l:.0f}" for m, l in zip(mu, lam)) + "]")
+    if (np.any(lam_mu > (1.0 / 32.0)) or np.any(lam_mu <= 0)) and not quiet:
+        print("WARNING: Parameters must satisfy 0 < λ/μ <= 1/32 or result may diverge!")
+    if not quiet:
+        fr = _hbm_free(0 if device is None else device)
+        if fr:
+            print(f"Available HBM: {_fmt_bytes(fr[0])} of {_fmt_bytes(fr[1])}", flush=True)
+
+    return _run(4, datacube, mu, lam, iterations, FISTA, stopping_relative_change, reference_data, BC_mode, quiet,
+                device)
+
+
+def denoise3D(
+    datacube: np.ndarray,
+    mu: np.ndarray,
+    iterations: int = 7_500,
+    stopping_relative_change: Optional[float] = None,
+    BC_mode: int = 2,
+    FISTA: bool = False,
+    reference_data: Optional[np.ndarray] = None,
+    lam: Optional[np.ndarray] = None,
+    quiet: bool = False,
+    device: Optional[int] = None,
+) -> Tuple[np.ndarray, np.ndarray, np.ndarray, Optional[np.ndarray]]:
+    """Proximal anisotropic TV denoising of a 3-D datacube on one MI355X.
+
+    Arguments, defaults (note: FISTA=False, 7500 iterations, lam = mu/16) and return value are
+    those of the reference's denoise3D (cyTVDN/cyTVDN.py:250-290).
+    """
+    assert isinstance(datacube, np.ndarray) and datacube.dtype in (
+        np.float32,
+        np.float64,
+    ), "datacube must be floating point datatype."
+    if datacube.ndim != 3:
+        raise TypeError("No matching signature found")
+    mu = np.asarray(mu)
+    if lam is None:
+        lam = mu / 16.0
+    lam = np.asarray(lam)
+    assert lam.dtype == datacube.dtype, "Lambda must have same dtype as datacube."
+    assert datacube.flags["C_CONTIGUOUS"], \
+        "datacube must be C-contiguous. Try np.ascontiguousarray(datacube) on the array"
+    if mu.shape != (3,) or lam.shape != (3,):
+        raise ValueError("mu and lam must have 3 entries")
+    if reference_data is not None and (reference_data.shape != datacube.shape or reference_data.dtype != datacube.dtype):
+        raise ValueError("reference_data must match the datacube's shape and dtype")
+
+    lam_mu = (lam / mu).astype(datacube.dtype)
+    # upstream's message says 1/8 while testing 1/16 (cyTVDN.py:306-308); the test is what counts
+    assert np.all(lam_mu <= (1.0 / 16.0)) & np.all(lam_mu > 0), "Parameters must satisfy 0 < λ/μ <= 1/16"
+    if not quiet:
+        print("λ/μ ≈ [" + ", ".join(f"1/{m/l:.0f}" for m, l in zip(mu, lam)) + "]")
+        fr = _hbm_free(0 if device is None else device)
+        if fr:
+            print(f"Available HBM: {_fmt_bytes(fr[0])} of {_fmt_bytes(fr[1])}", flush=True)
+
+    return _run(3, datacube, mu, lam, iterations, FISTA, stopping_relative_change, reference_data, BC_mode, quiet,
+                device)
+
+
+def check_memory(datacube, device: int = 0):
+    """Print whether each algorithm's state fits in this GPU's HBM (reference check_memory,
+    cyTVDN.py:438-467, which does the same sum for host RAM)."""
+    shape, dtype = tuple(datacube.shape), datacube.dtype
+    if len(shape) not in (3, 4):
+        raise TypeError("No matching signature found")
+    fr = _hbm_free(device)
+    avail = fr[0] if fr else None
+    rows = []
+    for name, fista in (("Anisotropic Unaccelerated", False), ("Anisotropic FISTA", True)):
+        p = hbm_plan(shape, dtype, fista)
+        ok = "?" if avail is None else ("✅" if p["bytes"] < avail else "❌")
+        rows.append([name, _fmt_bytes(p["bytes"]), f"{p['arrays']} arrays", ok])
+    print(f"Datacube size is {_fmt_bytes(datacube.nbytes)} with dtype {dtype}")
+    if avail is not None:
+        print(f"Free HBM on device {device}: {_fmt_bytes(avail)}")
+    try:
+        from tabulate import tabulate
+        print(tabulate(rows, ["Algorithm", "HBM Needed", "State", "OK?"]))
+    except Exception:  # pragma: no cover
+        for r in rows:
+            print("  ".join(r))
+    return rows
+
+
+__all__ = ["denoise4D", "denoise3D", "check_memory"]

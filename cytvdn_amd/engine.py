@@ -1,0 +1,289 @@
+"""Device-resident iteration engine: one slab of the datacube per GPU.
+
+The reference's only multi-process path tiles real space in 2-D over MPI ranks and patches 1-row
+halos with mpi4py messages (reference cyTVDN/mpi.py:131-210, :314-434).  Here the same idea is
+expressed MI355X-first: axis 0 is cut into contiguous slabs, one per GPU, so that a halo row is a
+single contiguous block that RCCL sends straight out of / into the recon buffer (no packing), and
+only recon is ever exchanged (accumulators of the halo row are recomputed locally).
+
+Pieces
+------
+SlabLayout   pure bookkeeping: which global rows a rank owns, which halo rows it keeps, how its two
+             edges are treated by the fused sweep (tvdn.h TVDN_EDGE_*), who its neighbours are.
+HipBackend   the product backend: state in HBM (torch tensors are only the allocator), one
+             `tvdn_iterate_fused` launch per iteration (double-buffered state, see csrc/tvdn_fused.hip).
+SlabRunner   drives a backend: FISTA schedule (float64 on the host as upstream, cyTVDN.py:153-156),
+             per-iteration halo exchange over torch.distributed (RCCL on GPUs; any backend object with
+             the same five methods can be driven, which is how tests rehearse the protocol with gloo).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def fista_ratios(n: int) -> np.ndarray:
+    """(tk-1)/tk_new for iterations 0..n-1, float64 on the host (reference cyTVDN.py:153-156)."""
+    out = np.empty(int(n), np.float64)
+    tk = 1.0
+    for i in range(int(n)):
+        tk_new = (1 + np.sqrt(1 + 4 * tk ** 2)) / 2
+        out[i] = (tk - 1.0) / tk_new
+        tk = tk_new
+    return out
+
+
+@dataclass(frozen=True)
+class SlabLayout:
+    """Rows of axis 0 owned by `rank` out of `world`, plus halo bookkeeping."""
+    shape: tuple          # GLOBAL shape
+    rank: int
+    world: int
+    bc_mode: int
+
+    def __post_init__(self):
+        if self.world < 1 or not (0 <= self.rank < self.world):
+            raise ValueError("bad rank/world")
+        if self.shape[0] < self.world:
+            raise ValueError(f"axis 0 ({self.shape[0]} rows) cannot be cut into {self.world} slabs")
+        if self.bc_mode not in (0, 2):
+            raise NotImplementedError("slab engine supports BC_mode 0 (periodic) and 2 (Jia-Zhao)")
+
+    # global rows [g0, g1) owned by this rank (balanced split)
+    @property
+    def g0(self) -> int:
+        return (self.rank * self.shape[0]) // self.world
+
+    @property
+    def g1(self) -> int:
+        return ((self.rank + 1) * self.shape[0]) // self.world
+
+    @property
+    def ring(self) -> bool:
+        return self.world > 1 and self.bc_mode == 0
+
+    @property
+    def halo_lo(self) -> int:
+        return 1 if self.world > 1 and (self.rank > 0 or self.ring) else 0
+
+    @property
+    def halo_hi(self) -> int:
+        return 1 if self.world > 1 and (self.rank < self.world - 1 or self.ring) else 0
+
+    @property
+    def own_rows(self) -> int:
+        return self.g1 - self.g0
+
+    @property
+    def local_shape(self) -> tuple:
+        return (self.halo_lo + self.own_rows + self.halo_hi,) + tuple(self.shape[1:])
+
+    @property
+    def row_lo(self) -> int:
+        return self.halo_lo
+
+    @property
+    def row_hi(self) -> int:
+        return self.halo_lo + self.own_rows
+
+    @property
+    def lo_mode(self) -> int:
+        return _lib.EDGE_HALO if self.halo_lo else _lib.EDGE_BC
+
+    @property
+    def hi_mode(self) -> int:
+        if self.halo_hi:
+            return _lib.EDGE_HALO
+        return _lib.EDGE_BC if self.world == 1 else _lib.EDGE_ZERO
+
+    @property
+    def left(self):
+        """Rank that owns the row below g0 (None at a non-periodic global edge)."""
+        if not self.halo_lo:
+            return None
+        return (self.rank - 1) % self.world
+
+    @property
+    def right(self):
+        if not self.halo_hi:
+            return None
+        return (self.rank + 1) % self.world
+
+    def local_rows_global(self) -> np.ndarray:
+        """Global row index held by each local row (halo rows included, periodic wrap applied)."""
+        rows = np.arange(self.g0 - self.halo_lo, self.g1 + self.halo_hi)
+        return rows % self.shape[0]
+
+
+class HipBackend:
+    """State of one slab in HBM + the fused sweep.  torch is the allocator, nothing more."""
+
+    def __init__(self, layout: SlabLayout, dtype, fista: bool, device: int = 0, max_iters: int = 1):
+        self.layout = layout
+        self.dtype = np.dtype(dtype)
+        self.code = _lib.dtype_code(self.dtype)
+        self.fista = bool(fista)
+        self.device = int(device)
+        self.nd = len(layout.shape)
+        if self.nd not in (3, 4):
+            raise TypeError("No matching signature found")
+        self.ctx = _lib.ctx(self.device)  # raises without a GPU: no CPU fallback
+        tdt = torch.float32 if self.dtype == np.float32 else torch.float64
+        dev = torch.device("cuda", self.device)
+        ls = layout.local_shape
+        self.orig = torch.zeros(ls, dtype=tdt, device=dev)
+        self.recon = [torch.zeros(ls, dtype=tdt, device=dev) for _ in range(2)]
+        self.b = [[torch.zeros(ls, dtype=tdt, device=dev) for _ in range(2)] for _ in range(self.nd)]
+        self.d = [[torch.zeros(ls, dtype=tdt, device=dev) for _ in range(2)] for _ in range(self.nd)] if fista else None
+        self.sums = torch.zeros((max(int(max_iters), 1), 3), dtype=torch.float64, device=dev)
+        self.cur = 0
+        self._args = _lib.IterArgs()
+        a = self._args
+        a.dtype, a.ndim = self.code, self.nd
+        for i, s in enumerate(ls):
+            a.shape[i] = int(s)
+        a.row_lo, a.row_hi = layout.row_lo, layout.row_hi
+        a.lo_mode, a.hi_mode, a.bc_mode = layout.lo_mode, layout.hi_mode, layout.bc_mode
+        a.orig = self.orig.data_ptr()
+
+    # -- the five methods SlabRunner needs ------------------------------------------------------
+    def set_params(self, clip, lam_mu):
+        for q in range(self.nd):
+            self._args.clip[q] = float(clip[q])
+            self._args.lambda_mu[q] = float(lam_mu[q])
+
+    def set_input(self, local_block):
+        """local_block: torch tensor or NumPy array of layout.local_shape (halo rows included)."""
+        t = local_block if isinstance(local_block, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local_block))
+        self.orig.copy_(t, non_blocking=False)
+        self.recon[self.cur].copy_(self.orig)
+
+    def step(self, tk_ratio, slot: int):
+        a = self._args
+        i, o = self.cur, self.cur ^ 1
+        use_fista = tk_ratio is not None
+        if use_fista and not self.fista:
+            raise ValueError("backend was allocated without FISTA state")
+        a.fista = 1 if use_fista else 0
+        a.tk = float(tk_ratio) if use_fista else 0.0
+        a.recon_in, a.recon_out = self.recon[i].data_ptr(), self.recon[o].data_ptr()
+        for q in range(self.nd):
+            a.b_in[q], a.b_out[q] = self.b[q][i].data_ptr(), self.b[q][o].data_ptr()
+            if use_fista:
+                a.d_in[q], a.d_out[q] = self.d[q][i].data_ptr(), self.d[q][o].data_ptr()
+            else:
+                a.d_in[q], a.d_out[q] = None, None
+        _lib.check(_lib.lib().tvdn_iterate_fused(self.ctx, C.byref(a), C.c_void_p(self.sums[slot].data_ptr()),
+                                                 _lib.current_stream(self.device)))
+        self.cur = o
+
+    def recon_tensor(self) -> torch.Tensor:
+        return self.recon[self.cur]
+
+    def sums_tensor(self) -> torch.Tensor:
+        return self.sums
+
+    # -- extras ------------------------------------------------------------------------------------
+    def sse(self, ref: torch.Tensor, out: torch.Tensor):
+        """out (device double, 1 element) <- sum((ref - recon)^2) over the slab's own rows."""
+        lay = self.layout
+        own = self.recon_tensor()[lay.row_lo:lay.row_hi]
+        refo = ref[lay.row_lo:lay.row_hi]
+        _lib.check(_lib.lib().tvdn_sum_square_error(self.ctx, self.code, self.nd, _lib.shape_arr(own.shape),
+                                                    refo.data_ptr(), own.data_ptr(), out.data_ptr(),
+                                                    _lib.current_stream(self.device)))
+
+    def state_bytes(self) -> int:
+        n = 1 + 2 + 2 * self.nd * (2 if self.fista else 1)
+        return n * int(np.prod(self.layout.local_shape)) * self.dtype.itemsize
+
+
+class SlabRunner:
+    """Runs iterations on one slab and keeps its halo rows current."""
+
+    def __init__(self, backend, group=None):
+        self.be = backend
+        self.layout: SlabLayout = backend.layout
+        self.group = group
+        self.iter = 0
+        self.ran = []  # slots of the iterations that actually ran
+        if self.layout.world > 1:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                raise RuntimeError("world > 1 needs an initialised torch.distributed process group")
+            self.dist = dist
+
+    def exchange_halos(self):
+        """Send my first/last own recon rows to the neighbours, receive theirs into my halo rows.
+
+        One row = one contiguous block; with RCCL each message rides one
+        xGMI link between the two neighbouring GPUs."""
+        lay = self.layout
+        if lay.world == 1:
+            return
+        dist = self.dist
+        r = self.be.recon_tensor()
+        # Order matters where RCCL matches messages per peer in issue order and one peer is both
+        # neighbours (periodic ring of two): sends go (first row -> left, last row -> right), so the
+        # receives are posted (from right, from left).
+        ops = []
+        if lay.left is not None:
+            ops.append(dist.P2POp(dist.isend, r[lay.row_lo], self._peer(lay.left), self.group, tag=1))
+        if lay.right is not None:
+            ops.append(dist.P2POp(dist.isend, r[lay.row_hi - 1], self._peer(lay.right), self.group, tag=2))
+            ops.append(dist.P2POp(dist.irecv, r[lay.row_hi], self._peer(lay.right), self.group, tag=1))
+        if lay.left is not None:
+            ops.append(dist.P2POp(dist.irecv, r[lay.row_lo - 1], self._peer(lay.left), self.group, tag=2))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def _peer(self, rank_in_group: int) -> int:
+        if self.group is None:
+            return rank_in_group
+        return self.dist.get_global_rank(self.group, rank_in_group)
+
+    def run(self, n_fista: int, n_plain: int, on_iter=None):
+        """n_fista FISTA iterations then n_plain unaccelerated ones (hybrid mode of the reference,
+        cyTVDN.py:99-108).  `on_iter(slot)` may return True to stop the current phase early."""
+        slot = self.iter
+        ratios = fista_ratios(n_fista)
+        for i in range(n_fista):
+            self.be.step(float(ratios[i]), slot)
+            self.exchange_halos()
+            self.ran.append(slot)
+            slot += 1
+            if on_iter is not None and on_iter(slot - 1):
+                break
+        slot = self.iter + n_fista  # the plain phase starts at its own slot even after an early break
+        for _ in range(n_plain):
+            self.be.step(None, slot)
+            self.exchange_halos()
+            self.ran.append(slot)
+            slot += 1
+            if on_iter is not None and on_iter(slot - 1):
+                break
+        self.iter += n_fista + n_plain
+
+    def global_sums(self) -> torch.Tensor:
+        """[iters,3] f64 sums over ALL slabs (b_norm, sum|delta|, sum|old|)."""
+        s = self.be.sums_tensor().clone()
+        if self.layout.world > 1:
+            self.dist.all_reduce(s, group=self.group)
+        return s
+
+
+def hbm_plan(shape, dtype, fista: bool, world: int = 1) -> dict:
+    """Bytes of HBM one slab needs in the fused (double-buffered) engine (cf. check_memory)."""
+    n = int(np.prod(shape)) // max(world, 1)
+    item = np.dtype(dtype).itemsize
+    nd = len(shape)
+    arrays = 1 + 2 + 2 * nd * (2 if fista else 1)
+    return dict(arrays=arrays, bytes=arrays * n * item, per_array=n * item)
+
+
+__all__ = ["SlabLayout", "HipBackend", "SlabRunner", "fista_ratios", "hbm_plan"]

@@ -33,12 +33,20 @@ _M2 = np.uint64(0x94D049BB133111EB)
 
 def _hash24(seed: int, lin: np.ndarray) -> np.ndarray:
     """Top 24 bits of splitmix64(seed + (lin+1)*golden)."""
-    with np.errstate(over="ignore"):
-        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + (lin.astype(np.uint64) + np.uint64(1)) * _GOLD
-        z = (z ^ (z >> np.uint64(30))) * _M1
-        z = (z ^ (z >> np.uint64(27))) * _M2
-        z = z ^ (z >> np.uint64(31))
-    return (z >> np.uint64(40)).astype(np.uint32)
+    z = lin.astype(np.uint64) + np.uint64(1)
+    return _hash24_inplace(seed, z, np.empty_like(z)).astype(np.uint32)
+
+
+def _hash24_inplace(seed: int, z: np.ndarray, tmp: np.ndarray) -> np.ndarray:
+    """z holds lin+1 (uint64) on entry and the 24-bit hash on exit; no temporaries are allocated
+    (fresh multi-megabyte temporaries cost more than the arithmetic)."""
+    z *= _GOLD
+    z += np.uint64(seed & 0xFFFFFFFFFFFFFFFF)
+    np.right_shift(z, np.uint64(30), out=tmp); z ^= tmp; z *= _M1
+    np.right_shift(z, np.uint64(27), out=tmp); z ^= tmp; z *= _M2
+    np.right_shift(z, np.uint64(31), out=tmp); z ^= tmp
+    np.right_shift(z, np.uint64(40), out=z)
+    return z
 
 
 def level_4d(x, y, qx, qy, shape):
@@ -80,13 +88,44 @@ def level_3d(x, y, e, shape):
     return (lvl + 4).astype(np.int32)
 
 
+_KEYS = (np.arange(_TAB.shape[0], dtype=np.int64)[:, None] * (1 << 24) + _TAB.astype(np.int64)).ravel()
+
+
 def _draw(lvl: np.ndarray, u: np.ndarray) -> np.ndarray:
-    """Poisson count = number of the level's thresholds that u reaches (u >= t)."""
-    out = np.zeros(u.shape, dtype=np.int32)
-    for L in np.unique(lvl):
-        m = lvl == L
-        out[m] = np.searchsorted(_TAB[L], u[m], side="right")
-    return out
+    """Poisson count = number of the level's thresholds that u reaches (u >= t).
+
+    One search over the concatenated tables: key = level * 2^24 + u; every threshold of a lower
+    level is below the key, so the rank minus level * NT is the count within the level."""
+    key = lvl.astype(np.int64) * (1 << 24) + u.astype(np.int64)
+    return (np.searchsorted(_KEYS, key.ravel(), side="right").reshape(u.shape) - lvl.astype(np.int64) * NT).astype(np.int32)
+
+
+def _patterns(shape):
+    """The level functions factor into a class of the two leading (spatial) indices and a pattern over
+    the remaining (spectral / diffraction) indices: return (pattern if class, pattern if not class),
+    both flattened, evaluated with level_4d / level_3d themselves."""
+    if len(shape) == 4:
+        NX, NY, NQX, NQY = shape
+        qx, qy = np.meshgrid(np.arange(NQX), np.arange(NQY), indexing="ij")
+        zero = np.zeros_like(qx)
+        pat_t = level_4d(zero, zero + NY, qx, qy, shape)   # x = 0, y = NY  -> grain A
+        pat_f = level_4d(zero + NX, zero, qx, qy, shape)   # x = NX, y = 0  -> grain B
+    else:
+        NX, NY, NE = shape
+        e = np.arange(NE)
+        pat_t = level_3d(np.zeros_like(e), np.zeros_like(e), e, shape)            # x = y = 0: phase B
+        pat_f = level_3d(np.zeros_like(e) + NX, np.zeros_like(e) + NY, e, shape)  # far corner: phase A
+    return pat_t.ravel().astype(np.int32), pat_f.ravel().astype(np.int32)
+
+
+def _classes(shape, o0, o1):
+    """Class (grain A / phase B) of the spatial positions with flat index x*NY + y in [o0, o1)."""
+    NX, NY = int(shape[0]), int(shape[1])
+    o = np.arange(o0, o1, dtype=np.int64)
+    x, y = o // NY, o % NY
+    if len(shape) == 4:
+        return 4 * x * NY < 2 * NX * NY + (2 * y - NY) * NX
+    return 4 * (x * x + y * y) < NX * NX + NY * NY
 
 
 def _gen(shape, seed, dtype, row0, rows, kind, ndim):
@@ -95,21 +134,25 @@ def _gen(shape, seed, dtype, row0, rows, kind, ndim):
     rows = shape[0] - row0 if rows is None else rows
     assert 0 <= row0 and row0 + rows <= shape[0]
     out = np.empty((rows,) + shape[1:], dtype=dtype)
-    plane = int(np.prod(shape[1:]))
-    chunk = max(1, (1 << 22) // max(plane, 1))
-    for r in range(0, rows, chunk):
-        n = min(chunk, rows - r)
-        idx = np.indices((n,) + shape[1:], dtype=np.int64)
-        idx[0] += row0 + r
-        if ndim == 4:
-            lvl = level_4d(idx[0], idx[1], idx[2], idx[3], shape)
-        else:
-            lvl = level_3d(idx[0], idx[1], idx[2], shape)
+    NY = shape[1]
+    inner = int(np.prod(shape[2:]))
+    flat = out.reshape(rows * NY, inner)
+    pat_t, pat_f = _patterns(shape)
+    step = max(1, (1 << 21) // inner)          # spatial positions per chunk (~2M voxels)
+    z = np.empty(step * inner, np.uint64)
+    tmp = np.empty_like(z)
+    for o in range(0, rows * NY, step):
+        n = min(step, rows * NY - o)
+        cls = _classes(shape, row0 * NY + o, row0 * NY + o + n)
+        lvl = np.where(cls[:, None], pat_t[None, :], pat_f[None, :])
         if kind == "mean":
-            out[r:r + n] = _MEANS[lvl].astype(dtype)
+            flat[o:o + n] = _MEANS[lvl].astype(dtype)
         else:
-            lin = np.ravel_multi_index(tuple(idx), shape).astype(np.uint64)
-            out[r:r + n] = _draw(lvl, _hash24(seed, lin)).astype(dtype)
+            zz, tt = z[:n * inner], tmp[:n * inner]
+            zz[:] = np.arange(1, n * inner + 1, dtype=np.uint64)
+            zz += np.uint64((row0 * NY + o) * inner)
+            u = _hash24_inplace(seed, zz, tt).reshape(n, inner)
+            flat[o:o + n] = _draw(lvl, u).astype(dtype)
     return out
 
 

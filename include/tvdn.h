@@ -1,0 +1,154 @@
+/*
+ * tvdn.h -- C ABI of the MI355X-native anisotropic TV denoising hot path (libtvdn_hip.so).
+ *
+ * The reference (cyTVDN) has no FFI header: its boundary is "Python callables taking NumPy
+ * arrays" (cyTVDN/__init__.py:1).  Each entry point below names the reference callable whose
+ * arithmetic it replaces; cytvdn_amd/ binds them with ctypes and presents the reference's
+ * Python names and signatures on top (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *  - All array arguments are DEVICE pointers to C-contiguous blocks of `dtype`
+ *    (TVDN_F32 / TVDN_F64); `shape` is a HOST array of `ndim` (3 or 4) extents in the
+ *    reference's axis order.  Scalars that the reference converts to the array dtype
+ *    (clip, tk, lambda_mu) are passed as double and rounded to `dtype` inside, which is
+ *    what the Cython fused-type call does.
+ *  - Reductions (the Python floats the reference kernels return) are written to DEVICE
+ *    double slots, accumulated in f64 by a fixed tree (deterministic run to run).
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are
+ *    asynchronous with respect to the host; nothing here synchronises.
+ *  - Every function returns TVDN_OK (0) or a negative tvdn_status; tvdn_last_error()
+ *    describes the last failure of the calling thread.  Nothing falls back to the CPU.
+ */
+#ifndef TVDN_H
+#define TVDN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TVDN_ABI_VERSION 1
+
+typedef enum tvdn_dtype { TVDN_F32 = 0, TVDN_F64 = 1 } tvdn_dtype;
+
+typedef enum tvdn_status {
+    TVDN_OK = 0,
+    TVDN_ERR_INVALID = -1,     /* bad argument (ndim, ax, bc_mode, shape, NULL pointer, ...)   */
+    TVDN_ERR_UNSUPPORTED = -2, /* defined upstream as undefined behaviour (mirror-BC recon)     */
+    TVDN_ERR_HIP = -3,         /* a HIP runtime call failed; see tvdn_last_error()               */
+    TVDN_ERR_NO_DEVICE = -4    /* no gfx950 device visible                                       */
+} tvdn_status;
+
+/* Boundary-condition modes, as the reference numbers them (anisotropic.pyx:20-23). */
+#define TVDN_BC_PERIODIC 0
+#define TVDN_BC_MIRROR 1
+#define TVDN_BC_JIA_ZHAO 2
+
+int tvdn_abi_version(void);
+const char *tvdn_last_error(void);
+/* Number of visible HIP devices, or a negative status.  Does not create a context. */
+int tvdn_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Context: per-device scratch for the two-stage reductions (a few hundred KiB).
+ * One context may be used from one stream at a time.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct tvdn_ctx tvdn_ctx;
+int tvdn_ctx_create(tvdn_ctx **out, int device);
+int tvdn_ctx_destroy(tvdn_ctx *ctx);
+
+/* Measurement aid (bench.py): while enabled, every tvdn_iterate_fused call brackets its sweep
+ * kernel (not the small reduction epilogue) with a pair of HIP events recorded on the call's
+ * stream.  tvdn_ctx_timing_read synchronises those events, adds their elapsed times to
+ * *total_ms / *launches, and forgets them. */
+int tvdn_ctx_timing_enable(tvdn_ctx *ctx, int on);
+int tvdn_ctx_timing_read(tvdn_ctx *ctx, double *total_ms, int64_t *launches);
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel-level entry points: one reference pass each, in place, any shape.
+ * ---------------------------------------------------------------------------------------- */
+
+/* accumulator_update_{3D,4D}        (cyTVDN/anisotropic.pyx:169-237, :17-84)     when d == NULL
+ * accumulator_update_{3D,4D}_FISTA  (cyTVDN/anisotropic.pyx:243-317, :89-164)    when d != NULL
+ *   b <- clip((a - a[prev along ax]) + b)  [FISTA: d_new = that; b <- d_new + tk*(d_new - d); d <- d_new]
+ *   *norm_out (device double) <- sum |b_new|   (the reference's return value)
+ * bc_mode 0, 1 or 2 (mirror needs shape[ax] >= 2). */
+int tvdn_accumulator_update(tvdn_ctx *ctx, int dtype, int ndim, const int64_t *shape,
+                            const void *a, void *b, void *d, double tk, int ax, double clip,
+                            int bc_mode, double *norm_out, void *stream);
+
+/* datacube_update_{3D,4D}  (cyTVDN/utils.pyx:131-199, :54-125), bc_mode 0 or 2.
+ *   recon <- orig - sum_ax lambda_mu[ax] * (b_ax - b_ax[next along ax, periodic wrap])
+ *   sums_out[0] <- sum |recon_new - recon_old|, sums_out[1] <- sum |recon_old|  (device doubles;
+ *   the reference returns sums_out[0] / sums_out[1]).
+ * `b` is a HOST array of ndim device pointers; `lambda_mu` a HOST array of ndim doubles.
+ * bc_mode 1 returns TVDN_ERR_UNSUPPORTED: upstream it indexes out of bounds (utils.pyx:117-120). */
+int tvdn_datacube_update(tvdn_ctx *ctx, int dtype, int ndim, const int64_t *shape, const void *orig,
+                         void *recon, const void *const *b, const double *lambda_mu, int bc_mode,
+                         double *sums_out, void *stream);
+
+/* sum_square_error_{3D,4D}  (cyTVDN/utils.pyx:35-49, :14-30):  *out <- sum (a-b)^2. */
+int tvdn_sum_square_error(tvdn_ctx *ctx, int dtype, int ndim, const int64_t *shape, const void *a,
+                          const void *b, double *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Loop-level entry point: ONE full iteration (all accumulator updates + the reconstruction
+ * update, cyTVDN/cyTVDN.py:153-184 / :205-230 / :372-392 / :405-420) as a single fused sweep
+ * that reads every state array once and writes it once.
+ *
+ * State is double-buffered: the sweep reads *_in and writes *_out (no array is updated in
+ * place, so neighbouring tiles may recompute each other's halo values); the caller swaps the
+ * roles after each call.  `d_in`/`d_out` are NULL for the unaccelerated iteration.
+ *
+ * Slab decomposition along axis 0 (one GPU per slab): the local block has `shape[0]` rows of
+ * which rows [row_lo, row_hi) are this slab's own; a row below row_lo / at row_hi is a halo
+ * row holding the neighbour's current recon (exchanged by the caller between iterations).
+ *   lo_mode  TVDN_EDGE_BC    row_lo is the global first row: apply bc_mode there
+ *            TVDN_EDGE_HALO  row row_lo-1 is a halo row
+ *   hi_mode  TVDN_EDGE_BC    row_hi-1 is the global last row and row 0 of this block is the
+ *                            global first row (single-slab case): wrap onto it
+ *            TVDN_EDGE_HALO  row row_hi is a halo row; its axis-0 accumulator is kept locally
+ *            TVDN_EDGE_ZERO  row_hi-1 is the global last row of a multi-slab Jia-Zhao run: the
+ *                            wrapped axis-0 accumulator is identically zero
+ * sums_out (device, 3 doubles): [0] sum over all axes of |b_new| (b_norm), [1] sum |recon_new -
+ * recon_old|, [2] sum |recon_old|, over the slab's own rows only.
+ * ---------------------------------------------------------------------------------------- */
+#define TVDN_EDGE_BC 0
+#define TVDN_EDGE_HALO 1
+#define TVDN_EDGE_ZERO 2
+
+typedef struct tvdn_iter_args {
+    int32_t dtype;        /* tvdn_dtype                                            */
+    int32_t ndim;         /* 3 or 4                                                */
+    int64_t shape[4];     /* local block extents, first ndim entries used          */
+    int64_t row_lo;       /* own rows [row_lo, row_hi) along axis 0                */
+    int64_t row_hi;
+    int32_t lo_mode;      /* TVDN_EDGE_*                                           */
+    int32_t hi_mode;
+    int32_t bc_mode;      /* 0 or 2                                                */
+    int32_t fista;        /* 0: unaccelerated (d_* ignored), 1: FISTA              */
+    double tk;            /* FISTA momentum ratio (tk-1)/tk_new of this iteration  */
+    double clip[4];       /* 1/lambda per axis                                     */
+    double lambda_mu[4];  /* lambda/mu per axis                                    */
+    const void *orig;     /* noisy input, read only                                */
+    const void *recon_in;
+    void *recon_out;
+    const void *b_in[4];
+    void *b_out[4];
+    const void *d_in[4];
+    void *d_out[4];
+} tvdn_iter_args;
+
+int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *args, double *sums_out, void *stream);
+
+/* Synthetic input (cytvdn_amd/synth.py restated on the device, bit-identical): fills rows
+ * [row0, row0+rows) of the GLOBAL cube `shape` into `out` (rows*prod(shape[1:]) elements). */
+int tvdn_synth_fill(int dtype, int ndim, const int64_t *shape, uint64_t seed, int64_t row0,
+                    int64_t rows, void *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TVDN_H */

@@ -1,0 +1,176 @@
+"""Parity of the HIP path (through the C ABI) with the reference's golden vectors and the oracle.
+
+Bars: recon / accumulators bit-exact (same IEEE operations in the same order, no FMA); the scalar
+traces are f64 tree sums here and dtype-width running sums upstream, compared with the size-aware
+tolerance of golden_util.scalar_tol and, tightly (1e-12), with the oracle's f64 yardsticks.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from golden_util import bits_equal, load, scalar_tol
+
+pytestmark = pytest.mark.gpu
+
+K, KMAN = load("kernels")
+L, LMAN = load("loops")
+G, GMAN = load("large")
+
+
+@pytest.fixture(scope="module")
+def tv():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import cytvdn_amd
+    return cytvdn_amd
+
+
+def _close(got, want, dtype, n):
+    tol = scalar_tol(dtype, n)
+    if np.isnan(want):
+        assert np.isnan(got)
+    else:
+        assert got == pytest.approx(want, rel=max(tol, 2e-6 if np.dtype(dtype) == np.float32 else 1e-12), abs=1e-30)
+
+
+@pytest.mark.parametrize("m", KMAN, ids=lambda m: f"{m['i']}-{m['fn']}-{m['dtype']}")
+def test_kernel_golden(tv, m):
+    p = f"k{m['i']:03d}_"
+    fn = m["fn"]
+    if fn.startswith("accumulator_update"):
+        a = K[p + "a"].copy()
+        b = K[p + "b_in"].copy()
+        clip = a.dtype.type(m["clip"])
+        if fn.endswith("FISTA"):
+            d = K[p + "d_in"].copy()
+            ret = getattr(tv, fn)(a, b, d, a.dtype.type(m["tk"]), m["ax"], clip, BC_mode=m["bc"])
+            assert bits_equal(d, K[p + "d_out"])
+        else:
+            ret = getattr(tv, fn)(a, b, m["ax"], clip, BC_mode=m["bc"])
+        assert bits_equal(b, K[p + "b_out"])
+        assert bits_equal(a, K[p + "a"])  # read-only role untouched
+        n = a.size
+    elif fn.startswith("datacube_update"):
+        nd = int(fn[-2])
+        recon = K[p + "recon_in"].copy()
+        bs = [K[p + f"b{q}"].copy() for q in range(nd)]
+        ret = getattr(tv, fn)(K[p + "orig"].copy(), recon, *bs, K[p + "lm"], BC_mode=m["bc"])
+        assert bits_equal(recon, K[p + "recon_out"])
+        n = recon.size
+    else:
+        a = K[p + "a"].copy()
+        ret = getattr(tv, fn)(a, K[p + "b"].copy())
+        n = a.size
+    _close(ret, float(K[p + "ret"]), m["dtype"], n)
+
+
+def _run_loop(tv, m, x, refd):
+    dtype = np.dtype(m["dtype"])
+    mu = np.array(m["mu"], dtype)
+    lam = None if m["lam"] is None else np.array(m["lam"], dtype)
+    fn = tv.denoise4D if m["nd"] == 4 else tv.denoise3D
+    return fn(x, mu, m["iterations"], FISTA=m["FISTA"], BC_mode=m["bc"], lam=lam, reference_data=refd,
+              stopping_relative_change=m["stop"], quiet=True)
+
+
+@pytest.mark.parametrize("m", LMAN, ids=lambda m: f"{m['i']}-{m['nd']}D-{m['dtype']}-it{m['iterations']}-F{int(m['FISTA'])}-bc{m['bc']}")
+def test_loop_golden(tv, m):
+    from cytvdn_amd import synth
+    p = f"l{m['i']:03d}_"
+    dtype = np.dtype(m["dtype"])
+    x = synth.cube(m["shape"], seed=m["seed"], dtype=dtype)
+    x0 = x.copy()
+    refd = synth.cube(m["shape"], seed=m["seed"], dtype=dtype, kind="mean") if m["with_ref"] else None
+    out = _run_loop(tv, m, x, refd)
+    assert bits_equal(x, x0), "input mutated"
+    assert bits_equal(out[0], L[p + "recon"])
+    n = x.size
+    tol = max(scalar_tol(dtype, n), 3e-6 if dtype == np.float32 else 1e-12)
+    for k, name in ((1, "b_norm"), (2, "delta_recon")):
+        want = L[p + name]
+        assert out[k].dtype == dtype and out[k].shape == want.shape
+        # early stopping: identical zero tails (same iteration count)
+        assert np.array_equal(out[k] == 0, want == 0), name
+        np.testing.assert_allclose(out[k], want, rtol=tol)
+    if m["with_ref"]:
+        assert len(out) == 4
+        np.testing.assert_allclose(out[3], L[p + "MSE"], rtol=tol)
+    else:
+        assert len(out) == 3
+
+
+@pytest.mark.parametrize("m", GMAN, ids=lambda m: f"{m['nd']}D-{m['dtype']}-{'x'.join(map(str, m['shape']))}")
+def test_large_golden(tv, m):
+    """config-1 shape (128,128,512) x 200 FISTA iterations, and two 4-D runs: SHA-1 of recon."""
+    from cytvdn_amd import synth
+    dtype = np.dtype(m["dtype"])
+    x = synth.cube(m["shape"], seed=m["seed"], dtype=dtype)
+    assert hashlib.sha1(x.tobytes()).hexdigest() == m["input_sha1"]
+    fn = tv.denoise4D if m["nd"] == 4 else tv.denoise3D
+    recon, bn, dl = fn(x, np.array(m["mu"], dtype), m["iterations"], FISTA=m["FISTA"], quiet=True)
+    assert hashlib.sha1(recon.tobytes()).hexdigest() == m["sha1"]
+    tol = scalar_tol(dtype, x.size)
+    np.testing.assert_allclose(bn, G[f"g{m['i']}_b_norm"], rtol=tol)
+    np.testing.assert_allclose(dl, G[f"g{m['i']}_delta_recon"], rtol=tol)
+
+
+SHAPES = [
+    ((9, 6, 10, 16), np.float32), ((5, 4, 6, 8), np.float64), ((12, 10, 32), np.float32), ((6, 7, 10), np.float64),
+    ((40, 3, 5, 8), np.float32),   # several marching chunks
+    ((70, 4, 4), np.float32), ((3, 5, 7, 9), np.float32), ((2, 1, 1, 4), np.float64), ((1, 1, 1, 1), np.float32),
+    ((1, 6, 8), np.float64),
+]
+
+
+@pytest.mark.parametrize("shape,dtype", SHAPES, ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else np.dtype(v).name)
+@pytest.mark.parametrize("bc", [2, 0])
+@pytest.mark.parametrize("mode", ["fista", "plain", "hybrid"])
+def test_fused_vs_oracle(tv, oracle, shape, dtype, bc, mode):
+    """Seeded inputs at shapes the oracle finishes in milliseconds: vector and scalar paths,
+    chunk seams, unit axes, both boundary conditions; f64 scalars to 1e-12."""
+    from cytvdn_amd import synth
+    dtype = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=77, dtype=dtype) + dtype.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dtype)
+    its = {"fista": 7, "plain": 7, "hybrid": [4, 3]}[mode]
+    fista = mode != "plain"
+    fn = tv.denoise4D if nd == 4 else tv.denoise3D
+    recon, bn, dl = fn(x, mu, its, FISTA=fista, BC_mode=bc, quiet=True)
+    ref = oracle.denoise(x, mu, its, fista, BC_mode=bc)
+    assert bits_equal(recon, ref["recon"])
+    np.testing.assert_allclose(bn.astype(np.float64), ref["b_norm64"].astype(dtype).astype(np.float64), rtol=1e-6 if dtype == np.float32 else 1e-12)
+    want = (ref["delta64"].astype(dtype) / ref["rnorm64"].astype(dtype)).astype(np.float64)
+    np.testing.assert_allclose(dl.astype(np.float64), want, rtol=1e-6 if dtype == np.float32 else 1e-12)
+
+
+def test_device_tensors_in_place(tv, oracle):
+    """Kernel-level calls on torch CUDA tensors update HBM in place."""
+    import torch
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((4, 5, 6, 8)).astype(np.float32)
+    b = rng.standard_normal((4, 5, 6, 8)).astype(np.float32)
+    d = rng.standard_normal((4, 5, 6, 8)).astype(np.float32)
+    ta, tb, td = (torch.from_numpy(v.copy()).cuda() for v in (a, b, d))
+    ret = tv.accumulator_update_4D_FISTA(ta, tb, td, 0.3, 2, np.float32(0.8))
+    b2, d2 = b.copy(), d.copy()
+    nT, n64 = oracle.acc_update(a, b2, d2, np.float32(0.3), 2, np.float32(0.8), 2)
+    assert bits_equal(tb.cpu().numpy(), b2) and bits_equal(td.cpu().numpy(), d2)
+    assert ret == pytest.approx(n64, rel=1e-12)
+
+
+def test_nonfinite_and_strided_views(tv, oracle):
+    """NaN propagates through clip as upstream; non-contiguous writable views are accepted
+    by the kernel-level functions."""
+    rng = np.random.default_rng(6)
+    a = rng.standard_normal((6, 5, 4)).astype(np.float64)
+    a[2, 3, 1] = np.nan
+    big = rng.standard_normal((6, 5, 8)).astype(np.float64)
+    b = big[:, :, ::2]
+    assert not b.flags["C_CONTIGUOUS"]
+    b_ref = np.ascontiguousarray(b).copy()
+    tv.accumulator_update_3D(a, b, 1, 0.7, BC_mode=0)
+    oracle.acc_update(a, b_ref, None, 0.0, 1, 0.7, 0)
+    assert bits_equal(np.ascontiguousarray(b), b_ref)
+    assert np.isnan(b[2, 3, 1]) and np.isnan(b[2, 4, 1])
