@@ -31,7 +31,7 @@ def _close(got, want, dtype, n):
     if np.isnan(want):
         assert np.isnan(got)
     else:
-        assert got == pytest.approx(want, rel=max(tol, 2e-6 if np.dtype(dtype) == np.float32 else 1e-12), abs=1e-30)
+        assert got == pytest.approx(want, rel=tol, abs=1e-30)
 
 
 @pytest.mark.parametrize("m", KMAN, ids=lambda m: f"{m['i']}-{m['fn']}-{m['dtype']}")
@@ -86,7 +86,7 @@ def test_loop_golden(tv, m):
     assert bits_equal(x, x0), "input mutated"
     assert bits_equal(out[0], L[p + "recon"])
     n = x.size
-    tol = max(scalar_tol(dtype, n), 3e-6 if dtype == np.float32 else 1e-12)
+    tol = scalar_tol(dtype, n)
     for k, name in ((1, "b_norm"), (2, "delta_recon")):
         want = L[p + name]
         assert out[k].dtype == dtype and out[k].shape == want.shape
