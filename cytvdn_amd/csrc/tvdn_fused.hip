@@ -19,6 +19,8 @@
 //     cross-section tiles.
 // Slab decomposition along M (one GPU per slab) is expressed by row_lo/row_hi and the edge modes
 // of tvdn.h; the caller exchanges recon halo rows between iterations.
+#include <cstdlib>
+
 #include "tvdn_common.hpp"
 
 namespace tvdn {
@@ -67,6 +69,10 @@ struct FusedParams {
     int chunk;        // rows per workgroup march
     long long tiles;  // workgroups per cross-section
     long long units;  // A * B * (C / VEC)
+    int wga, wgb;     // rows of A and of B covered by one workgroup (0: linear thread->unit map)
+    int sync;         // keep the workgroup's waves in step (one barrier per row)
+    int xcd;          // 1: remap workgroup ids so each XCD sweeps a contiguous run of tiles
+    int fake;         // MEASUREMENT ONLY (wrong results): bit0 zero the A offsets, bit1 the B offsets, bit2 the C offsets
     double *partials;
 };
 
@@ -162,11 +168,22 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
     // each XCD gets a contiguous run of logical ids.
     const long long G = gridDim.x, bid = blockIdx.x;
     const long long q8 = G / 8, r8 = G % 8, xcd = bid % 8;
-    const long long L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
+    const long long L = p.xcd ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8 : bid;
     const long long chunk_id = L / p.tiles, tile = L % p.tiles;
 
-    const long long u = tile * kFusedBlock + threadIdx.x;
     double acc[3] = {0.0, 0.0, 0.0};  // b_norm, sum|delta|, sum|old|
+    const long long LRk = p.C / VEC;
+    long long u;
+    if (p.wga > 0) {
+        // 2-D workgroup tile: wga rows of A x wgb rows of B, each row LRk lanes wide
+        const long long tilesB = p.B / p.wgb;
+        const long long ta = tile / tilesB, tb = tile % tilesB;
+        const long long row = threadIdx.x / LRk, cvk = threadIdx.x % LRk;
+        const long long ra = row / p.wgb, rb = row % p.wgb;
+        u = ((ta * p.wga + ra) * p.B + (tb * p.wgb + rb)) * LRk + cvk;
+    } else {
+        u = tile * kFusedBlock + threadIdx.x;
+    }
 
     const long long m0 = p.row_lo + chunk_id * p.chunk;
     const long long m1 = (m0 + p.chunk < p.row_hi) ? m0 + p.chunk : p.row_hi;
@@ -189,6 +206,10 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
         const long long offA_next = HAS_A ? (wrapA ? -(p.A - 1) * SA : SA) : 0;
         const long long offB_next = wrapB ? -(p.B - 1) * SB : SB;
         const long long offC_next = wrapC ? -(p.C - VEC) : VEC;
+        // (timing experiments only; never set by the product path)
+        const long long offA_prev_ = (p.fake & 1) ? 0 : offA_prev, offA_next_ = (p.fake & 1) ? 0 : offA_next;
+        const long long offB_prev_ = (p.fake & 2) ? 0 : offB_prev, offB_next_ = (p.fake & 2) ? 0 : offB_next;
+        const long long offC_prev_ = (p.fake & 4) ? 0 : offC_prev, offC_next_ = (p.fake & 4) ? 0 : offC_next;
         // a wrapped neighbour sits at index 0, where under Jia-Zhao its own "prev" is itself
         const bool selfA = wrapA && bc2, selfB = wrapB && bc2, selfC = wrapC && bc2;
 
@@ -220,6 +241,7 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
 
         // ---- march -------------------------------------------------------------------------------
         for (long long m = m0; m < m1; ++m) {
+            if (p.sync) __syncthreads();
             const long long x = m * SM + xs;
             const bool last = (m + 1 == m1);
             const bool at_end = (m + 1 == p.row_hi);
@@ -257,11 +279,11 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
             for (int j = 0; j < VEC; ++j) sum.v[j] = lmM * (bM_cur.v[j] - bM_next.v[j]);
             if (HAS_A)
                 axis_pack<T, VEC, FISTA>(r_cur, p.r_in, p.b_in[iA], p.d_in[iA], p.b_out[iA], p.d_out[iA], x,
-                                         offA_prev, offA_next, selfA, tk, p.clip[iA], p.lm[iA], sum, acc[0]);
-            axis_pack<T, VEC, FISTA>(r_cur, p.r_in, p.b_in[iB], p.d_in[iB], p.b_out[iB], p.d_out[iB], x, offB_prev,
-                                     offB_next, selfB, tk, clB, lmB, sum, acc[0]);
-            axis_contig<T, VEC, FISTA>(r_cur, p.r_in, p.b_in[iC], p.d_in[iC], p.b_out[iC], p.d_out[iC], x, offC_prev,
-                                       offC_next, selfC, tk, clC, lmC, sum, acc[0]);
+                                         offA_prev_, offA_next_, selfA, tk, p.clip[iA], p.lm[iA], sum, acc[0]);
+            axis_pack<T, VEC, FISTA>(r_cur, p.r_in, p.b_in[iB], p.d_in[iB], p.b_out[iB], p.d_out[iB], x, offB_prev_,
+                                     offB_next_, selfB, tk, clB, lmB, sum, acc[0]);
+            axis_contig<T, VEC, FISTA>(r_cur, p.r_in, p.b_in[iC], p.d_in[iC], p.b_out[iC], p.d_out[iC], x, offC_prev_,
+                                       offC_next_, selfC, tk, clC, lmC, sum, acc[0]);
 
             // (3) reconstruction update at row m (utils.pyx:90-104)
             const P og = ldv<T, VEC>(p.orig + x);
@@ -322,10 +344,28 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
     const int vec = (al && (p.C % VMAX == 0)) ? VMAX : 1;
     p.units = p.A * p.B * (p.C / vec);
     p.tiles = (p.units + kFusedBlock - 1) / kFusedBlock;
+    // tuning knobs (measurement only): TVDN_WGA = rows of A per workgroup, TVDN_SYNC, TVDN_CHUNK
+    const char *e_wga = getenv("TVDN_WGA"), *e_sync = getenv("TVDN_SYNC"), *e_chunk = getenv("TVDN_CHUNK");
+    p.wga = 0; p.wgb = 0; p.sync = 0;
+    p.xcd = getenv("TVDN_XCD") ? atoi(getenv("TVDN_XCD")) : 1;
+    p.fake = getenv("TVDN_FAKE") ? atoi(getenv("TVDN_FAKE")) : 0;
+    {
+        const long long lr = p.C / vec;
+        const long long rows_wg = (lr <= kFusedBlock && kFusedBlock % lr == 0) ? kFusedBlock / lr : 0;
+        int want = e_wga ? atoi(e_wga) : 0;
+        if (rows_wg > 0 && want > 0 && rows_wg % want == 0 && p.A % want == 0 && p.B % (rows_wg / want) == 0) {
+            p.wga = want;
+            p.wgb = (int)(rows_wg / want);
+            // a uniform barrier needs every thread of the workgroup in the loop: true for full tiles
+            p.sync = e_sync ? atoi(e_sync) : 0;
+        }
+    }
     const long long rows = p.row_hi - p.row_lo;
-    // rows per march: long enough to amortise the look-ahead row (3 extra pack loads per chunk),
-    // short enough that the grid covers the chip several times over
-    long long chunk = 32;
+    // rows per march: long enough to amortise the look-ahead row (3 extra pack loads per chunk); short
+    // marches measured best on MI355X (2..8 rows: 14.7-14.9 ms, 32 rows: 15.3 ms on 256x256x128x128 f32):
+    // many short-lived workgroups keep the set of open DRAM pages compact
+    long long chunk = e_chunk ? atoll(e_chunk) : 8;
+    if (chunk < 1) chunk = 1;
     while (chunk > 4 && p.tiles * ((rows + chunk - 1) / chunk) < 256 * 8) chunk /= 2;
     while (p.tiles * ((rows + chunk - 1) / chunk) > kMaxPartialBlocks && chunk < rows) chunk *= 2;
     p.chunk = (int)chunk;
