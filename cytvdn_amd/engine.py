@@ -277,6 +277,47 @@ class SlabRunner:
         return s
 
 
+class LocalSlabs:
+    """Several slabs of one cube advanced in lockstep inside ONE process, halo rows moved by plain
+    device copies instead of messages.  Same SlabLayout, same backend calls and the same exchange
+    pattern as the multi-process path (it is how the per-slab semantics of the HIP sweep are tested
+    on a single GPU, and the building block for staging slabs of a cube that exceeds HBM)."""
+
+    def __init__(self, backends):
+        self.bes = list(backends)
+        self.world = len(self.bes)
+        for r, be in enumerate(self.bes):
+            if be.layout.rank != r or be.layout.world != self.world:
+                raise ValueError("backends must be given in rank order with world == len(backends)")
+
+    def exchange_halos(self):
+        for be in self.bes:
+            lay = be.layout
+            r = be.recon_tensor()
+            if lay.left is not None:
+                lb = self.bes[lay.left]
+                lb.recon_tensor()[lb.layout.row_hi].copy_(r[lay.row_lo])          # my first row -> left's high halo
+            if lay.right is not None:
+                rb = self.bes[lay.right]
+                rb.recon_tensor()[rb.layout.row_lo - 1].copy_(r[lay.row_hi - 1])  # my last row -> right's low halo
+
+    def run(self, n_fista: int, n_plain: int):
+        ratios = fista_ratios(n_fista)
+        slot = 0
+        for i in range(n_fista + n_plain):
+            tk = float(ratios[i]) if i < n_fista else None
+            for be in self.bes:
+                be.step(tk, slot)
+            self.exchange_halos()
+            slot += 1
+
+    def gather_recon(self) -> torch.Tensor:
+        return torch.cat([be.recon_tensor()[be.layout.row_lo:be.layout.row_hi] for be in self.bes], dim=0)
+
+    def global_sums(self) -> torch.Tensor:
+        return sum(be.sums_tensor() for be in self.bes)
+
+
 def hbm_plan(shape, dtype, fista: bool, world: int = 1) -> dict:
     """Bytes of HBM one slab needs in the fused (double-buffered) engine (cf. check_memory)."""
     n = int(np.prod(shape)) // max(world, 1)
@@ -286,4 +327,4 @@ def hbm_plan(shape, dtype, fista: bool, world: int = 1) -> dict:
     return dict(arrays=arrays, bytes=arrays * n * item, per_array=n * item)
 
 
-__all__ = ["SlabLayout", "HipBackend", "SlabRunner", "fista_ratios", "hbm_plan"]
+__all__ = ["SlabLayout", "HipBackend", "SlabRunner", "LocalSlabs", "fista_ratios", "hbm_plan"]

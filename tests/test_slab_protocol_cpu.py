@@ -1,0 +1,119 @@
+"""The N>1 path without a GPU: SlabLayout bookkeeping, and SlabRunner's halo exchange rehearsed
+with the gloo backend (world_size 2 and 3) on a CPU test double of the HIP backend.
+
+What is proven here: cutting axis 0 into slabs, advancing each slab with the per-slab semantics of
+tvdn_iterate_fused and exchanging ONE recon row per neighbour per iteration reproduces the
+single-process result bit for bit, for Jia-Zhao (chain) and periodic (ring) BCs.
+The HIP kernel's own per-slab semantics are checked on the GPU in test_gpu_slabs.py.
+"""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from cytvdn_amd import _lib, synth
+from cytvdn_amd.engine import SlabLayout, SlabRunner, fista_ratios
+
+
+def test_layout_chain_and_ring():
+    lay = [SlabLayout((10, 3, 4, 5), r, 3, 2) for r in range(3)]
+    assert [(l.g0, l.g1) for l in lay] == [(0, 3), (3, 6), (6, 10)]
+    assert [l.halo_lo for l in lay] == [0, 1, 1] and [l.halo_hi for l in lay] == [1, 1, 0]
+    assert [l.lo_mode for l in lay] == [_lib.EDGE_BC, _lib.EDGE_HALO, _lib.EDGE_HALO]
+    assert [l.hi_mode for l in lay] == [_lib.EDGE_HALO, _lib.EDGE_HALO, _lib.EDGE_ZERO]
+    assert [l.left for l in lay] == [None, 0, 1] and [l.right for l in lay] == [1, 2, None]
+    assert lay[1].local_shape == (5, 3, 4, 5) and (lay[1].row_lo, lay[1].row_hi) == (1, 4)
+    assert list(lay[2].local_rows_global()) == [5, 6, 7, 8, 9]
+    ring = [SlabLayout((10, 3, 4), r, 3, 0) for r in range(3)]
+    assert all(l.halo_lo == 1 and l.halo_hi == 1 for l in ring)
+    assert [l.left for l in ring] == [2, 0, 1] and [l.right for l in ring] == [1, 2, 0]
+    assert list(ring[0].local_rows_global()) == [9, 0, 1, 2, 3]
+    assert all(l.lo_mode == _lib.EDGE_HALO and l.hi_mode == _lib.EDGE_HALO for l in ring)
+    one = SlabLayout((4, 2, 2), 0, 1, 0)
+    assert one.local_shape == (4, 2, 2) and one.lo_mode == _lib.EDGE_BC and one.hi_mode == _lib.EDGE_BC
+    with pytest.raises(ValueError):
+        SlabLayout((2, 4, 4), 0, 3, 2)
+    with pytest.raises(NotImplementedError):
+        SlabLayout((8, 4, 4), 0, 2, 1)
+
+
+def test_fista_schedule_matches_reference_recurrence():
+    r = fista_ratios(5)
+    assert r[0] == 0.0
+    tk = 1.0
+    for i in range(5):
+        tk_new = (1 + np.sqrt(1 + 4 * tk ** 2)) / 2
+        assert r[i] == (tk - 1.0) / tk_new
+        tk = tk_new
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, shape, dtype_name, bc, n_f, n_p, outdir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from slab_cpu_backend import OracleSlabBackend
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dtype = np.dtype(dtype_name)
+        nd = len(shape)
+        lay = SlabLayout(tuple(shape), rank, world, bc)
+        be = OracleSlabBackend(lay, dtype, n_f > 0, max_iters=n_f + n_p)
+        mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dtype)
+        lam = mu / dtype.type(32.0 if nd == 4 else 16.0)
+        be.set_params(1.0 / lam, (lam / mu).astype(dtype))
+        full = synth.cube(shape, seed=91, dtype=dtype) + dtype.type(0.25)
+        be.set_input(full[lay.local_rows_global()])          # own rows + halo rows (periodic wrap applied)
+        runner = SlabRunner(be)
+        runner.run(n_f, n_p)
+        own = be.recon_tensor().numpy()[lay.row_lo:lay.row_hi]
+        sums = runner.global_sums().numpy()
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), own=own, g0=lay.g0, g1=lay.g1, sums=sums)
+    finally:
+        dist.destroy_process_group()
+
+
+CASES = [
+    # world, shape, dtype, bc, n_fista, n_plain
+    (2, (7, 3, 4, 8), "float32", 2, 5, 0),
+    (2, (6, 5, 8), "float64", 2, 0, 5),
+    (2, (5, 3, 4, 4), "float32", 0, 4, 2),      # periodic ring of two: one peer is both neighbours
+    (3, (8, 2, 3, 4), "float64", 2, 3, 2),
+    (3, (7, 4, 6), "float32", 0, 4, 0),
+    (2, (2, 3, 3, 4), "float32", 2, 3, 0),      # one row per slab
+]
+
+
+@pytest.mark.parametrize("world,shape,dtype,bc,n_f,n_p", CASES,
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_slabs_reproduce_single_process(oracle, world, shape, dtype, bc, n_f, n_p):
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(world, _free_port(), shape, dtype, bc, n_f, n_p, tmp), nprocs=world, join=True)
+        parts = [np.load(os.path.join(tmp, f"r{r}.npz")) for r in range(world)]
+    recon = np.concatenate([p["own"] for p in parts], axis=0)
+    x = synth.cube(shape, seed=91, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    its = [n_f, n_p] if (n_f and n_p) else (n_f or n_p)
+    ref = oracle.denoise(x, mu, its, n_f > 0, BC_mode=bc)
+    assert recon.tobytes() == ref["recon"].tobytes()
+    sums = parts[0]["sums"]
+    for p in parts[1:]:
+        assert np.array_equal(p["sums"], sums)           # all-reduced: every rank holds the global sums
+    np.testing.assert_allclose(sums[:, 0], ref["b_norm64"], rtol=1e-12)
+    np.testing.assert_allclose(sums[:, 1], ref["delta64"], rtol=1e-12)
+    np.testing.assert_allclose(sums[:, 2], ref["rnorm64"], rtol=1e-12)
