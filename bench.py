@@ -45,10 +45,22 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) // int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(target_s):
     """Reference OpenMP kernels (or the port) on a bounded sample: 32x64x128x128 f32 FISTA."""
     import numpy as np
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     os.environ.setdefault("OMP_PROC_BIND", "spread")
     os.environ.setdefault("OMP_PLACES", "cores")
@@ -149,10 +161,11 @@ def main():
     ratios = fista_ratios(a.steps + a.warmup)
 
     def step(i):
-        be.step(float(ratios[i]) if fista else None, i)
-        runner.exchange_halos()
+        # world > 1: edge rows first, their RCCL transfer on a side stream under the interior sweep
+        runner._step(float(ratios[i]) if fista else None, i)
 
     def fence():
+        runner.finish()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -170,7 +183,8 @@ def main():
     tot_ms, nl = C.c_double(), C.c_int64()
     _lib.check(_lib.lib().tvdn_ctx_timing_read(be.ctx, C.byref(tot_ms), C.byref(nl)))
     _lib.check(_lib.lib().tvdn_ctx_timing_enable(be.ctx, 0))
-    kern_ms = tot_ms.value / max(nl.value, 1)
+    # mean sweep-kernel time per iteration (with N > 1 an iteration is three launches: two edge rows + interior)
+    kern_ms = tot_ms.value / max(a.steps, 1)
 
     t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device="cuda")
     if world > 1:

@@ -43,6 +43,7 @@ class IterArgs(C.Structure):
         ("tk", C.c_double), ("clip", C.c_double * 4), ("lambda_mu", C.c_double * 4),
         ("orig", C.c_void_p), ("recon_in", C.c_void_p), ("recon_out", C.c_void_p),
         ("b_in", C.c_void_p * 4), ("b_out", C.c_void_p * 4), ("d_in", C.c_void_p * 4), ("d_out", C.c_void_p * 4),
+        ("sweep_lo", C.c_int64), ("sweep_hi", C.c_int64), ("accumulate", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

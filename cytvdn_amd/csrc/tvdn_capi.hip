@@ -25,7 +25,7 @@ void set_error(const char *fmt, ...)
 
 // ---- second reduction stage ------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) finalize_kernel(const double *partials, int nblocks, int nv,
-                                                         double *out)
+                                                         double *out, int accumulate)
 {
     __shared__ double red[kPartialWidth][16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -39,13 +39,13 @@ __global__ void __launch_bounds__(1024) finalize_kernel(const double *partials, 
     if ((int)threadIdx.x < nv) {
         double s = 0.0;
         for (int i = 0; i < 16; ++i) s += red[threadIdx.x][i];
-        out[threadIdx.x] = s;
+        out[threadIdx.x] = accumulate ? out[threadIdx.x] + s : s;
     }
 }
 
-int launch_finalize(tvdn_ctx *ctx, int nblocks, int nv, double *out, hipStream_t s)
+int launch_finalize(tvdn_ctx *ctx, int nblocks, int nv, double *out, hipStream_t s, bool accumulate)
 {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, s, ctx->partials, nblocks, nv, out);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, s, ctx->partials, nblocks, nv, out, accumulate ? 1 : 0);
     TVDN_HIP(hipGetLastError());
     return TVDN_OK;
 }

@@ -112,6 +112,6 @@ __device__ __forceinline__ void block_store_partials(const double (&v)[NV], doub
     }
 }
 
-int launch_finalize(tvdn_ctx *ctx, int nblocks, int nv, double *out, hipStream_t s);
+int launch_finalize(tvdn_ctx *ctx, int nblocks, int nv, double *out, hipStream_t s, bool accumulate = false);
 
 }  // namespace tvdn

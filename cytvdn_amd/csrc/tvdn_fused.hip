@@ -65,6 +65,7 @@ struct FusedParams {
     T lm[4];
     long long M, A, B, C;
     long long row_lo, row_hi;
+    long long sweep_lo, sweep_hi;  // rows advanced by this launch, inside [row_lo, row_hi)
     int lo_mode, hi_mode, bc;
     int chunk;        // rows per workgroup march
     long long tiles;  // workgroups per cross-section
@@ -185,8 +186,8 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
         u = tile * kFusedBlock + threadIdx.x;
     }
 
-    const long long m0 = p.row_lo + chunk_id * p.chunk;
-    const long long m1 = (m0 + p.chunk < p.row_hi) ? m0 + p.chunk : p.row_hi;
+    const long long m0 = p.sweep_lo + chunk_id * p.chunk;
+    const long long m1 = (m0 + p.chunk < p.sweep_hi) ? m0 + p.chunk : p.sweep_hi;
 
     if (u < p.units && m0 < m1) {
         const long long LR = p.C / VEC;
@@ -338,6 +339,9 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
     p.tk = (T)a->tk;
     p.M = g.n[0]; p.A = g.n[1]; p.B = g.n[2]; p.C = g.n[3];
     p.row_lo = a->row_lo; p.row_hi = a->row_hi;
+    const bool whole = (a->sweep_lo == 0 && a->sweep_hi == 0);
+    p.sweep_lo = whole ? a->row_lo : a->sweep_lo;
+    p.sweep_hi = whole ? a->row_hi : a->sweep_hi;
     p.lo_mode = a->lo_mode; p.hi_mode = a->hi_mode; p.bc = a->bc_mode;
     p.partials = ctx->partials;
 
@@ -360,7 +364,7 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
             p.sync = e_sync ? atoi(e_sync) : 0;
         }
     }
-    const long long rows = p.row_hi - p.row_lo;
+    const long long rows = p.sweep_hi - p.sweep_lo;
     // rows per march: long enough to amortise the look-ahead row (3 extra pack loads per chunk); short
     // marches measured best on MI355X (2..8 rows: 14.7-14.9 ms, 32 rows: 15.3 ms on 256x256x128x128 f32):
     // many short-lived workgroups keep the set of open DRAM pages compact
@@ -394,7 +398,7 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
         ctx->events.emplace_back(ev0, ev1);
     }
     if (rc) return rc;
-    return launch_finalize(ctx, (int)grid, 3, sums_out, s);
+    return launch_finalize(ctx, (int)grid, 3, sums_out, s, a->accumulate != 0);
 }
 
 }  // namespace tvdn
@@ -415,6 +419,9 @@ extern "C" int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *a, double
     TVDN_REQUIRE(0 <= a->row_lo && a->row_lo < a->row_hi && a->row_hi <= a->shape[0],
                  "own rows [%lld,%lld) not inside 0..%lld", (long long)a->row_lo, (long long)a->row_hi,
                  (long long)a->shape[0]);
+    TVDN_REQUIRE((a->sweep_lo == 0 && a->sweep_hi == 0) ||
+                     (a->row_lo <= a->sweep_lo && a->sweep_lo < a->sweep_hi && a->sweep_hi <= a->row_hi),
+                 "sweep rows [%lld,%lld) not inside the own rows", (long long)a->sweep_lo, (long long)a->sweep_hi);
     TVDN_REQUIRE(a->lo_mode == TVDN_EDGE_BC || a->lo_mode == TVDN_EDGE_HALO, "bad lo_mode %d", a->lo_mode);
     TVDN_REQUIRE(a->hi_mode >= TVDN_EDGE_BC && a->hi_mode <= TVDN_EDGE_ZERO, "bad hi_mode %d", a->hi_mode);
     TVDN_REQUIRE(!(a->lo_mode == TVDN_EDGE_HALO && a->row_lo < 1), "lo_mode HALO needs a row below row_lo");

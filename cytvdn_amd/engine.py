@@ -163,7 +163,12 @@ class HipBackend:
         self.orig.copy_(t, non_blocking=False)
         self.recon[self.cur].copy_(self.orig)
 
-    def step(self, tk_ratio, slot: int):
+    supports_partial_sweeps = True
+
+    def step(self, tk_ratio, slot: int, rows=None, accumulate: bool = False):
+        """One iteration over the own rows, or over the sub-range `rows` = (lo, hi) of them; the state
+        buffers flip when the last own row has been advanced (callers sweep sub-ranges so that the
+        range ending at row_hi comes last, or call `flip()` themselves)."""
         a = self._args
         i, o = self.cur, self.cur ^ 1
         use_fista = tk_ratio is not None
@@ -178,9 +183,23 @@ class HipBackend:
                 a.d_in[q], a.d_out[q] = self.d[q][i].data_ptr(), self.d[q][o].data_ptr()
             else:
                 a.d_in[q], a.d_out[q] = None, None
+        if rows is None:
+            a.sweep_lo, a.sweep_hi = 0, 0
+        else:
+            a.sweep_lo, a.sweep_hi = int(rows[0]), int(rows[1])
+        a.accumulate = 1 if accumulate else 0
         _lib.check(_lib.lib().tvdn_iterate_fused(self.ctx, C.byref(a), C.c_void_p(self.sums[slot].data_ptr()),
                                                  _lib.current_stream(self.device)))
-        self.cur = o
+        if rows is None:
+            self.cur = o
+
+    def flip(self):
+        """Make the freshly written buffers current (after a set of partial sweeps)."""
+        self.cur ^= 1
+
+    def recon_next(self) -> torch.Tensor:
+        """The buffer the sweeps of the current iteration write into."""
+        return self.recon[self.cur ^ 1]
 
     def recon_tensor(self) -> torch.Tensor:
         return self.recon[self.cur]
@@ -212,6 +231,8 @@ class SlabRunner:
         self.group = group
         self.iter = 0
         self.ran = []  # slots of the iterations that actually ran
+        self._side = None
+        self.overlap = True
         if self.layout.world > 1:
             import torch.distributed as dist
             if not dist.is_initialized():
@@ -242,10 +263,61 @@ class SlabRunner:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
 
+    def _ops(self, r):
+        lay, dist = self.layout, self.dist
+        ops = []
+        if lay.left is not None:
+            ops.append(dist.P2POp(dist.isend, r[lay.row_lo], self._peer(lay.left), self.group, tag=1))
+        if lay.right is not None:
+            ops.append(dist.P2POp(dist.isend, r[lay.row_hi - 1], self._peer(lay.right), self.group, tag=2))
+            ops.append(dist.P2POp(dist.irecv, r[lay.row_hi], self._peer(lay.right), self.group, tag=1))
+        if lay.left is not None:
+            ops.append(dist.P2POp(dist.irecv, r[lay.row_lo - 1], self._peer(lay.left), self.group, tag=2))
+        return ops
+
+    def step_overlapped(self, tk_ratio, slot: int):
+        """One iteration with the halo exchange hidden behind the interior sweep:
+        the two edge rows are advanced first, their transfer runs on a side HIP stream while the main
+        stream sweeps the interior rows, and the next iteration waits for the transfer."""
+        lay, be = self.layout, self.be
+        lo, hi = lay.row_lo, lay.row_hi
+        if lay.world == 1 or hi - lo < 3 or not getattr(be, "supports_partial_sweeps", False) \
+                or not be.recon_tensor().is_cuda:
+            be.step(tk_ratio, slot)
+            self.exchange_halos()
+            return
+        main = torch.cuda.current_stream(be.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=be.device)
+        main.wait_stream(self._side)                     # the previous exchange has filled my halo rows
+        be.step(tk_ratio, slot, rows=(lo, lo + 1), accumulate=False)
+        be.step(tk_ratio, slot, rows=(hi - 1, hi), accumulate=True)
+        edge_done = torch.cuda.Event()
+        edge_done.record(main)
+        r_next = be.recon_next()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(edge_done)
+            for w in self.dist.batch_isend_irecv(self._ops(r_next)):
+                w.wait()                                 # blocks the side stream only
+        be.step(tk_ratio, slot, rows=(lo + 1, hi - 1), accumulate=True)
+        be.flip()
+
+    def finish(self):
+        """Join the side stream (call before reading recon or the sums)."""
+        if self._side is not None:
+            torch.cuda.current_stream(self.be.device).wait_stream(self._side)
+
     def _peer(self, rank_in_group: int) -> int:
         if self.group is None:
             return rank_in_group
         return self.dist.get_global_rank(self.group, rank_in_group)
+
+    def _step(self, tk_ratio, slot):
+        if self.overlap:
+            self.step_overlapped(tk_ratio, slot)
+        else:
+            self.be.step(tk_ratio, slot)
+            self.exchange_halos()
 
     def run(self, n_fista: int, n_plain: int, on_iter=None):
         """n_fista FISTA iterations then n_plain unaccelerated ones (hybrid mode of the reference,
@@ -253,24 +325,24 @@ class SlabRunner:
         slot = self.iter
         ratios = fista_ratios(n_fista)
         for i in range(n_fista):
-            self.be.step(float(ratios[i]), slot)
-            self.exchange_halos()
+            self._step(float(ratios[i]), slot)
             self.ran.append(slot)
             slot += 1
             if on_iter is not None and on_iter(slot - 1):
                 break
         slot = self.iter + n_fista  # the plain phase starts at its own slot even after an early break
         for _ in range(n_plain):
-            self.be.step(None, slot)
-            self.exchange_halos()
+            self._step(None, slot)
             self.ran.append(slot)
             slot += 1
             if on_iter is not None and on_iter(slot - 1):
                 break
         self.iter += n_fista + n_plain
+        self.finish()
 
     def global_sums(self) -> torch.Tensor:
         """[iters,3] f64 sums over ALL slabs (b_norm, sum|delta|, sum|old|)."""
+        self.finish()
         s = self.be.sums_tensor().clone()
         if self.layout.world > 1:
             self.dist.all_reduce(s, group=self.group)
@@ -283,9 +355,10 @@ class LocalSlabs:
     pattern as the multi-process path (it is how the per-slab semantics of the HIP sweep are tested
     on a single GPU, and the building block for staging slabs of a cube that exceeds HBM)."""
 
-    def __init__(self, backends):
+    def __init__(self, backends, split_sweeps: bool = False):
         self.bes = list(backends)
         self.world = len(self.bes)
+        self.split = split_sweeps  # advance edge rows and interior rows in separate launches
         for r, be in enumerate(self.bes):
             if be.layout.rank != r or be.layout.world != self.world:
                 raise ValueError("backends must be given in rank order with world == len(backends)")
@@ -307,7 +380,14 @@ class LocalSlabs:
         for i in range(n_fista + n_plain):
             tk = float(ratios[i]) if i < n_fista else None
             for be in self.bes:
-                be.step(tk, slot)
+                lo, hi = be.layout.row_lo, be.layout.row_hi
+                if self.split and hi - lo >= 3:
+                    be.step(tk, slot, rows=(lo, lo + 1), accumulate=False)
+                    be.step(tk, slot, rows=(hi - 1, hi), accumulate=True)
+                    be.step(tk, slot, rows=(lo + 1, hi - 1), accumulate=True)
+                    be.flip()
+                else:
+                    be.step(tk, slot)
             self.exchange_halos()
             slot += 1
 

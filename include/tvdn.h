@@ -139,6 +139,14 @@ typedef struct tvdn_iter_args {
     void *b_out[4];
     const void *d_in[4];
     void *d_out[4];
+    /* Partial sweep, for overlapping the halo exchange with the bulk of the work: advance only rows
+     * [sweep_lo, sweep_hi) of the own rows (0,0 = all own rows).  Rows outside the sweep but inside
+     * [row_lo,row_hi) are treated like any in-slab neighbour (read, never written).  With
+     * `accumulate` != 0 the three sums are ADDED to sums_out instead of overwriting it. */
+    int64_t sweep_lo;
+    int64_t sweep_hi;
+    int32_t accumulate;
+    int32_t reserved;
 } tvdn_iter_args;
 
 int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *args, double *sums_out, void *stream);

@@ -1,0 +1,139 @@
+"""Host-side contract of the drop-in boundary, checked WITHOUT a GPU:
+ * the C-ABI library loads and exports every symbol include/tvdn.h declares;
+ * the Python surface has the reference's names, signatures and defaults (cyTVDN/cyTVDN.py:19-31, :250-260);
+ * argument errors surface as the reference's exception types BEFORE any device work;
+ * with no GPU the product raises (no CPU fallback, and nothing under cytvdn_amd imports oracle/).
+"""
+import ctypes
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import cytvdn_amd as tv
+from cytvdn_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NO_GPU = not torch.cuda.is_available()
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "tvdn.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(tvdn_[a-z_0-9]+)\s*\(", hdr))
+    assert {"tvdn_iterate_fused", "tvdn_accumulator_update", "tvdn_datacube_update", "tvdn_sum_square_error",
+            "tvdn_ctx_create", "tvdn_synth_fill"} <= declared
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/tvdn.h but not exported"
+    assert declared == set(_lib.EXPORTS)
+    assert _lib.lib().tvdn_abi_version() == 1
+
+
+def test_iter_args_struct_matches_header_layout():
+    # 2 int32 + 4 int64 + 2 int64 + 4 int32 + 1 double + 8 doubles + 3 ptr + 16 ptr + 2 int64 + 2 int32
+    assert ctypes.sizeof(_lib.IterArgs) == 8 + 32 + 16 + 16 + 8 + 64 + 24 + 128 + 16 + 8
+    assert _lib.IterArgs.shape.offset == 8 and _lib.IterArgs.tk.offset == 72 and _lib.IterArgs.orig.offset == 144
+    assert _lib.IterArgs.sweep_lo.offset == 296
+
+
+def test_public_names_and_signatures():
+    for n in ("denoise4D", "denoise3D", "check_memory", "accumulator_update_4D", "accumulator_update_4D_FISTA",
+              "accumulator_update_3D", "accumulator_update_3D_FISTA", "datacube_update_4D", "datacube_update_3D",
+              "sum_square_error_4D", "sum_square_error_3D", "iso_accumulator_update_4D",
+              "iso_accumulator_update_4D_FISTA"):
+        assert callable(getattr(tv, n))
+    p4 = inspect.signature(tv.denoise4D).parameters
+    assert list(p4)[:11] == ["datacube", "mu", "iterations", "FISTA", "stopping_relative_change", "isotropic_R",
+                             "isotropic_Q", "reference_data", "BC_mode", "lam", "quiet"]
+    assert (p4["iterations"].default, p4["FISTA"].default, p4["BC_mode"].default, p4["quiet"].default) == (10, True, 2, False)
+    p3 = inspect.signature(tv.denoise3D).parameters
+    assert list(p3)[:9] == ["datacube", "mu", "iterations", "stopping_relative_change", "BC_mode", "FISTA",
+                            "reference_data", "lam", "quiet"]
+    assert (p3["iterations"].default, p3["FISTA"].default, p3["BC_mode"].default) == (7500, False, 2)
+    pa = inspect.signature(tv.accumulator_update_4D_FISTA).parameters
+    assert list(pa) == ["a", "b", "d", "tk", "ax", "clip", "BC_mode"] and pa["BC_mode"].default == 2
+    pd = inspect.signature(tv.datacube_update_3D).parameters
+    assert list(pd) == ["orig", "recon", "b1", "b2", "b3", "lambda_mu", "BC_mode"]
+
+
+def test_driver_assertions_match_reference():
+    x = np.zeros((2, 3, 4, 4), np.float32)
+    mu = np.ones(4, np.float32)
+    with pytest.raises(AssertionError, match="floating point"):
+        tv.denoise4D(x.astype(np.int32), mu, 1, quiet=True)
+    with pytest.raises(AssertionError, match="Lambda must have same dtype"):
+        tv.denoise4D(x, mu, 1, lam=np.ones(4, np.float64) / 32, quiet=True)
+    with pytest.raises(AssertionError, match="Mu must have same dtype"):
+        tv.denoise4D(x, np.ones(4, np.float64), 1, lam=mu / 32, quiet=True)
+    with pytest.raises(AssertionError, match="C-contiguous"):
+        tv.denoise4D(np.asfortranarray(x), mu, 1, quiet=True)
+    with pytest.raises(NotImplementedError):
+        tv.denoise4D(x, mu, 1, isotropic_R=True, quiet=True)
+    with pytest.raises(NotImplementedError):
+        tv.denoise4D(x, mu, 1, BC_mode=1, quiet=True)
+    y = np.zeros((3, 4, 4), np.float64)
+    with pytest.raises(AssertionError, match="Lambda must have same dtype"):
+        tv.denoise3D(y, np.ones(3, np.float32), 1, quiet=True)     # wrong-dtype mu trips the lam assert (cyTVDN.py:297)
+    with pytest.raises(AssertionError, match="Parameters must satisfy"):
+        tv.denoise3D(y, np.ones(3), 1, lam=np.ones(3) / 8, quiet=True)
+    with pytest.raises(TypeError, match="No matching signature"):
+        tv.denoise4D(y, np.ones(4), 1, quiet=True)
+    with pytest.raises(TypeError, match="No matching signature"):
+        tv.denoise3D(x, np.ones(3, np.float32), 1, quiet=True)
+
+
+def test_kernel_level_argument_errors():
+    a = np.zeros((2, 3, 4, 4), np.float32)
+    with pytest.raises(TypeError, match="No matching signature"):
+        tv.accumulator_update_4D(a[0], a[0], 0, 1.0)                       # wrong rank
+    with pytest.raises(TypeError, match="No matching signature"):
+        tv.accumulator_update_4D(a.astype(np.int32), a.astype(np.int32), 0, 1.0)
+    with pytest.raises(ValueError, match="Buffer dtype mismatch, expected 'float' but got 'double'"):
+        tv.accumulator_update_4D(a, a.astype(np.float64), 0, 1.0)
+    ro = a.copy()
+    ro.flags.writeable = False
+    with pytest.raises(ValueError, match="read-only"):
+        tv.accumulator_update_4D(ro, a.copy(), 0, 1.0)
+    with pytest.raises(ValueError, match="ax"):
+        tv.accumulator_update_4D(a, a.copy(), 4, 1.0)
+    with pytest.raises(ValueError, match="BC_mode"):
+        tv.accumulator_update_4D(a, a.copy(), 0, 1.0, BC_mode=7)
+    with pytest.raises(ValueError, match="shapes disagree"):
+        tv.accumulator_update_4D(a, np.zeros((2, 3, 4, 5), np.float32), 0, 1.0)
+    with pytest.raises(NotImplementedError):
+        tv.datacube_update_4D(a, a.copy(), a, a, a, a, np.ones(4, np.float32), BC_mode=1)
+    with pytest.raises(ValueError, match="Buffer dtype mismatch"):
+        tv.datacube_update_4D(a, a.copy(), a, a, a, a, np.ones(4, np.float64))
+    with pytest.raises(NotImplementedError):
+        tv.iso_accumulator_update_4D(a, a, a, 0, 1, 1.0)
+
+
+@pytest.mark.skipif(not NO_GPU, reason="only meaningful on a box without a GPU")
+def test_no_cpu_fallback():
+    x = np.ones((2, 3, 4, 4), np.float32)
+    with pytest.raises(_lib.TvdnError, match="no CPU fallback"):
+        tv.denoise4D(x, np.ones(4, np.float32), 2, quiet=True)
+    with pytest.raises(_lib.TvdnError, match="no CPU fallback"):
+        tv.sum_square_error_4D(x, x)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "cytvdn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "libtvdn_oracle" not in src and "oracle/_ref" not in src, f
+
+
+def test_hbm_plan_counts_arrays():
+    from cytvdn_amd.engine import hbm_plan
+    assert hbm_plan((256, 256, 128, 128), np.float32, True)["arrays"] == 19
+    assert hbm_plan((256, 256, 128, 128), np.float32, True)["bytes"] == 19 * 4 * 2 ** 30
+    assert hbm_plan((256, 256, 128, 128), np.float64, False)["arrays"] == 11
+    assert hbm_plan((128, 128, 512), np.float32, True)["arrays"] == 15

@@ -17,12 +17,15 @@ CASES = [
     (8, (16, 2, 5, 7), "float32", 2, 6, 0),      # 8 slabs of 2 rows, scalar path
     (5, (5, 4, 8), "float32", 2, 3, 1),          # one row per slab
     (2, (40, 4, 4, 8), "float32", 2, 3, 0),      # several marching chunks per slab
+    (1, (11, 3, 4, 8), "float32", 0, 3, 2),      # single slab, periodic, swept as edge rows + interior
+    (1, (11, 5, 12), "float64", 2, 3, 2),
 ]
 
 
 @pytest.mark.parametrize("world,shape,dtype,bc,n_f,n_p", CASES,
                          ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
-def test_logical_slabs_match_oracle(oracle, world, shape, dtype, bc, n_f, n_p):
+@pytest.mark.parametrize("split", [False, True], ids=["whole", "edge-rows-first"])
+def test_logical_slabs_match_oracle(oracle, world, shape, dtype, bc, n_f, n_p, split):
     import torch
     from cytvdn_amd import synth
     from cytvdn_amd.engine import HipBackend, LocalSlabs, SlabLayout
@@ -39,7 +42,7 @@ def test_logical_slabs_match_oracle(oracle, world, shape, dtype, bc, n_f, n_p):
         be.set_params(1.0 / lam, (lam / mu).astype(dt))
         be.set_input(x[lay.local_rows_global()])
         bes.append(be)
-    grp = LocalSlabs(bes)
+    grp = LocalSlabs(bes, split_sweeps=split)
     grp.run(n_f, n_p)
     recon = grp.gather_recon().cpu().numpy()
     its = [n_f, n_p] if (n_f and n_p) else (n_f or n_p)
