@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--shape", type=str, default=None, help="override the global shape, e.g. 64x64x128x128")
     ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "f64"])
     ap.add_argument("--plain", action="store_true", help="unaccelerated iteration instead of FISTA")
+    ap.add_argument("--state", type=str, default="compact", choices=["compact", "reference"],
+                    help="accumulator state in HBM: compact = rotating d arrays (15 passes per 4-D FISTA iteration), "
+                         "reference = the reference's (b, d) pairs (19 passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     return ap.parse_args()
@@ -146,7 +149,7 @@ def main():
                 + (f", {world} slabs along axis 0" if world > 1 else ""))
 
     lay = SlabLayout(shape, rank, world, 2)
-    be = HipBackend(lay, dtype, fista, device=local_rank, max_iters=a.steps + a.warmup)
+    be = HipBackend(lay, dtype, fista, device=local_rank, max_iters=a.steps + a.warmup, state=a.state)
     mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dtype)
     lam = mu / dtype(32.0 if nd == 4 else 16.0)
     be.set_params(1.0 / lam, (lam / mu).astype(dtype))
@@ -197,6 +200,10 @@ def main():
     value = total_vox * a.steps / elapsed / 1e9
     bpv = BYTES_PER_VOXEL_ITER.get((a.dtype, fista, nd))
     achieved = own_vox * bpv / (kern_ms * 1e-3) / 1e9 if bpv else None
+    # bytes the sweep really has to move per voxel-iteration with the chosen state representation
+    item = 4 if a.dtype == "f32" else 8
+    passes = 3 + nd * ((3 if a.state == "compact" else 4) if fista else 2)
+    moved_bpv = passes * item
     if rank == 0:
         out = {
             "metric": "Gvoxel-iters/s (4D aniso FISTA)", "value": round(value, 3), "unit": "Gvoxel-iters/s",
@@ -204,12 +211,14 @@ def main():
             "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_shape": list(shape), "bc_mode": 2,
-                       "state_arrays": 1 + 2 + 2 * nd * (2 if fista else 1),
+                       "state_arrays": be.n_arrays(), "state": a.state,
                        "parallelism": f"slab{world}" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": None, "kernel": "fused_iter_kernel", "kernel_ms": round(kern_ms, 4),
-                         "algorithmic_bytes_per_launch": own_vox * bpv if bpv else None},
+                         "algorithmic_bytes_per_launch": own_vox * bpv if bpv else None,
+                         "moved_bytes_per_voxel": moved_bpv,
+                         "moved_GBps": round(own_vox * moved_bpv / (kern_ms * 1e-3) / 1e9, 1)},
             "cpu_baseline": cpu,
             "check": {"b_norm_last": float(sums[a.warmup + a.steps - 1, 0]),
                       "delta_last": float(sums[a.warmup + a.steps - 1, 1] / sums[a.warmup + a.steps - 1, 2])},

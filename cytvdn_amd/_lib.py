@@ -21,6 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libtvdn_hip.so")
 
 TVDN_F32, TVDN_F64 = 0, 1
 EDGE_BC, EDGE_HALO, EDGE_ZERO = 0, 1, 2
+ITER_PLAIN, ITER_FISTA, ITER_FISTA_D, ITER_FISTA_D_TO_PLAIN = 0, 1, 2, 3
 
 EXPORTS = (
     "tvdn_abi_version", "tvdn_last_error", "tvdn_device_count", "tvdn_ctx_create", "tvdn_ctx_destroy",
@@ -39,10 +40,11 @@ class IterArgs(C.Structure):
     _fields_ = [
         ("dtype", C.c_int32), ("ndim", C.c_int32), ("shape", C.c_int64 * 4),
         ("row_lo", C.c_int64), ("row_hi", C.c_int64),
-        ("lo_mode", C.c_int32), ("hi_mode", C.c_int32), ("bc_mode", C.c_int32), ("fista", C.c_int32),
-        ("tk", C.c_double), ("clip", C.c_double * 4), ("lambda_mu", C.c_double * 4),
+        ("lo_mode", C.c_int32), ("hi_mode", C.c_int32), ("bc_mode", C.c_int32), ("mode", C.c_int32),
+        ("tk", C.c_double), ("tk_prev", C.c_double), ("clip", C.c_double * 4), ("lambda_mu", C.c_double * 4),
         ("orig", C.c_void_p), ("recon_in", C.c_void_p), ("recon_out", C.c_void_p),
         ("b_in", C.c_void_p * 4), ("b_out", C.c_void_p * 4), ("d_in", C.c_void_p * 4), ("d_out", C.c_void_p * 4),
+        ("dprev_in", C.c_void_p * 4),
         ("sweep_lo", C.c_int64), ("sweep_hi", C.c_int64), ("accumulate", C.c_int32), ("reserved", C.c_int32),
     ]
 

@@ -1,13 +1,21 @@
 // Fused anisotropic-TV iteration for gfx950: all accumulator updates and the reconstruction
 // update of one iteration (cyTVDN/cyTVDN.py:153-184, :205-230, :372-392, :405-420) in ONE sweep
-// that reads each state array once and writes it once (19 array passes for 4-D FISTA instead of
-// the reference's 27).
+// that reads each state array once and writes it once.
 //
 // Why it is legal: recon_new(x) needs b_new_ax(x) and b_new_ax(x+e_ax); b_new_ax(y) needs the OLD
-// recon at y and y-e_ax and the OLD b_ax, d_ax at y.  All state is double-buffered (the sweep
+// recon at y and y-e_ax and the OLD accumulator state at y.  All state is multi-buffered (the sweep
 // reads *_in, writes *_out), so a thread may recompute its +1 neighbour's b_new from old values
 // that nobody overwrites.  The recomputed value is bit-identical to the owner's (same inputs,
 // same operations, no FMA contraction: this file is compiled with -ffp-contract=off).
+//
+// State representations (tvdn.h TVDN_ITER_*):
+//   PLAIN        b            -> b'                      2 passes per axis
+//   FISTA        (b, d)       -> (b', d')                4 passes per axis: the reference's own state
+//   FISTA_D      (d_k, d_k-1) -> d_k+1                   3 passes per axis: b_k is not stored but rebuilt
+//                as d_k + tk_prev*(d_k - d_k-1), the very expression (anisotropic.pyx:128) that produced it
+//   FISTA_D_TO_PLAIN  (d_k, d_k-1) -> b'                 first unaccelerated iteration of a hybrid run
+// so a 4-D FISTA iteration moves 15 arrays (r, orig, 8 d in; r, 4 d out) instead of the 19 of the
+// reference's representation and the 27 of its five separate passes.
 //
 // Decomposition: canonical block (M, A, B, C), C contiguous (3-D data: A == 1 and absent).
 //   * a thread owns VEC consecutive C-elements (16 bytes) of one (a, b) row and MARCHES along M
@@ -51,16 +59,32 @@ __device__ __forceinline__ void stv(T *p, const Pack<T, VEC> &x)
     *reinterpret_cast<Pack<T, VEC> *>(p) = x;
 }
 
+// Per-axis accumulator state as the kernel sees it.  Which arrays exist depends on the mode:
+//   in1: b (PLAIN, FISTA) or d_k-1 (FISTA_D*);  in2: d_k (all FISTA modes)
+//   out1: b' (PLAIN, FISTA, FISTA_D_TO_PLAIN);  out2: d' (FISTA, FISTA_D)
+template <typename T>
+struct AxisState {
+    const T *in1;
+    const T *in2;
+    T *out1;
+    T *out2;
+};
+
+template <int MODE>
+struct ModeTraits {
+    static constexpr bool kIn2 = (MODE != TVDN_ITER_PLAIN);
+    static constexpr bool kOut1 = (MODE != TVDN_ITER_FISTA_D);
+    static constexpr bool kOut2 = (MODE == TVDN_ITER_FISTA || MODE == TVDN_ITER_FISTA_D);
+};
+
 template <typename T>
 struct FusedParams {
     const T *orig;
     const T *r_in;
     T *r_out;
-    const T *b_in[4];
-    T *b_out[4];
-    const T *d_in[4];
-    T *d_out[4];
-    T tk;
+    AxisState<T> ax[4];
+    T tk;       // momentum ratio of this iteration
+    T tk_prev;  // momentum ratio of the previous iteration (FISTA_D*: rebuilds b_k)
     T clip[4];
     T lm[4];
     long long M, A, B, C;
@@ -70,98 +94,112 @@ struct FusedParams {
     int chunk;        // rows per workgroup march
     long long tiles;  // workgroups per cross-section
     long long units;  // A * B * (C / VEC)
-    int wga, wgb;     // rows of A and of B covered by one workgroup (0: linear thread->unit map)
-    int sync;         // keep the workgroup's waves in step (one barrier per row)
     int xcd;          // 1: remap workgroup ids so each XCD sweeps a contiguous run of tiles
-    int fake;         // MEASUREMENT ONLY (wrong results): bit0 zero the A offsets, bit1 the B offsets, bit2 the C offsets
     double *partials;
 };
 
 constexpr int kFusedBlock = 256;
 
-// One accumulator update (anisotropic.pyx:50-54 plain, :127-132 FISTA); returns b_new, sets d_new.
-template <typename T, bool FISTA>
-__device__ __forceinline__ T acc_new(T r_x, T r_prev, T b, T d, T tk, T clip, T &d_new)
+// One accumulator update at one voxel.  v1/v2 are the values loaded from in1/in2.
+// Returns b_new (what the divergence and b_norm use); o1/o2 are what out1/out2 receive.
+//   plain  anisotropic.pyx:50-54     b' = clip((r - r_prev) + b)
+//   FISTA  anisotropic.pyx:127-132   d' = clip((r - r_prev) + b); b' = d' + tk*(d' - d)
+template <typename T, int MODE>
+__device__ __forceinline__ T acc_new(T r_x, T r_prev, T v1, T v2, T tk, T tk_prev, T clip, T &o1, T &o2)
 {
-    const T v = (r_x - r_prev) + b;
-    const T dn = clipv(v, clip);
-    d_new = dn;
-    if (FISTA) return dn + tk * (dn - d);
-    return dn;
+    T b;
+    if (MODE == TVDN_ITER_FISTA_D || MODE == TVDN_ITER_FISTA_D_TO_PLAIN)
+        b = v2 + tk_prev * (v2 - v1);  // b_k rebuilt exactly as the previous iteration formed it
+    else
+        b = v1;
+    const T dn = clipv((r_x - r_prev) + b, clip);
+    if (MODE == TVDN_ITER_PLAIN || MODE == TVDN_ITER_FISTA_D_TO_PLAIN) {
+        o1 = dn;
+        o2 = dn;
+        return dn;
+    }
+    const T bn = dn + tk * (dn - v2);
+    o1 = bn;
+    o2 = dn;
+    return bn;
 }
 
-// Axis whose neighbours are whole packs (A and B): update own b/d at x, recompute b_new at the
+// Axis whose neighbours are whole packs (A and B): update own state at x, recompute b_new at the
 // +1 neighbour, add lm * (b_new(x) - b_new(x+e)) to `sum` (left-to-right as utils.c:5641).
-template <typename T, int VEC, bool FISTA>
+template <typename T, int VEC, int MODE>
 __device__ __forceinline__ void axis_pack(const Pack<T, VEC> &r_cur, const T *__restrict__ r_in,
-                                          const T *__restrict__ b_in, const T *__restrict__ d_in,
-                                          T *__restrict__ b_out, T *__restrict__ d_out, long long x,
-                                          long long off_prev, long long off_next, bool self_next, T tk, T cl,
-                                          T lm, Pack<T, VEC> &sum, double &bnorm)
+                                          const AxisState<T> &s, long long x, long long off_prev,
+                                          long long off_next, bool self_next, T tk, T tkp, T cl, T lm,
+                                          Pack<T, VEC> &sum, double &bnorm)
 {
     using P = Pack<T, VEC>;
+    using M = ModeTraits<MODE>;
     const P rp = ldv<T, VEC>(r_in + x + off_prev);
     const P rn = ldv<T, VEC>(r_in + x + off_next);
-    const P b_own = ldv<T, VEC>(b_in + x);
-    const P b_nx = ldv<T, VEC>(b_in + x + off_next);
-    P d_own, d_nx;
-    if (FISTA) {
-        d_own = ldv<T, VEC>(d_in + x);
-        d_nx = ldv<T, VEC>(d_in + x + off_next);
+    const P v1_own = ldv<T, VEC>(s.in1 + x);
+    const P v1_nx = ldv<T, VEC>(s.in1 + x + off_next);
+    P v2_own, v2_nx;
+    if (M::kIn2) {
+        v2_own = ldv<T, VEC>(s.in2 + x);
+        v2_nx = ldv<T, VEC>(s.in2 + x + off_next);
     }
-    P bn_own, dn_own;
+    P o1, o2;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        bn_own.v[j] = acc_new<T, FISTA>(r_cur.v[j], rp.v[j], b_own.v[j], FISTA ? d_own.v[j] : (T)0, tk, cl, dn_own.v[j]);
-        T unused;
-        const T bn_next = acc_new<T, FISTA>(rn.v[j], self_next ? rn.v[j] : r_cur.v[j], b_nx.v[j],
-                                            FISTA ? d_nx.v[j] : (T)0, tk, cl, unused);
-        sum.v[j] = sum.v[j] + lm * (bn_own.v[j] - bn_next);
-        bnorm += fabs((double)bn_own.v[j]);
+        const T bn_own = acc_new<T, MODE>(r_cur.v[j], rp.v[j], v1_own.v[j], M::kIn2 ? v2_own.v[j] : (T)0, tk, tkp, cl,
+                                          o1.v[j], o2.v[j]);
+        T u1, u2;
+        const T bn_next = acc_new<T, MODE>(rn.v[j], self_next ? rn.v[j] : r_cur.v[j], v1_nx.v[j],
+                                           M::kIn2 ? v2_nx.v[j] : (T)0, tk, tkp, cl, u1, u2);
+        sum.v[j] = sum.v[j] + lm * (bn_own - bn_next);
+        bnorm += fabs((double)bn_own);
     }
-    stv<T, VEC>(b_out + x, bn_own);
-    if (FISTA) stv<T, VEC>(d_out + x, dn_own);
+    if (M::kOut1) stv<T, VEC>(s.out1 + x, o1);
+    if (M::kOut2) stv<T, VEC>(s.out2 + x, o2);
 }
 
 // Contiguous axis C: neighbours inside the pack come from registers; only the element before the
 // pack and the one after it are fetched.
-template <typename T, int VEC, bool FISTA>
+template <typename T, int VEC, int MODE>
 __device__ __forceinline__ void axis_contig(const Pack<T, VEC> &r_cur, const T *__restrict__ r_in,
-                                            const T *__restrict__ b_in, const T *__restrict__ d_in,
-                                            T *__restrict__ b_out, T *__restrict__ d_out, long long x,
-                                            long long off_prev, long long off_next, bool self_next, T tk, T cl,
-                                            T lm, Pack<T, VEC> &sum, double &bnorm)
+                                            const AxisState<T> &s, long long x, long long off_prev,
+                                            long long off_next, bool self_next, T tk, T tkp, T cl, T lm,
+                                            Pack<T, VEC> &sum, double &bnorm)
 {
     using P = Pack<T, VEC>;
+    using M = ModeTraits<MODE>;
     const T r_before = r_in[x + off_prev];
     const T r_after = r_in[x + off_next];
-    const T b_after = b_in[x + off_next];
-    const T d_after = FISTA ? d_in[x + off_next] : (T)0;
-    const P b_own = ldv<T, VEC>(b_in + x);
-    P d_own;
-    if (FISTA) d_own = ldv<T, VEC>(d_in + x);
-    P bn_own, dn_own;
+    const T v1_after = s.in1[x + off_next];
+    const T v2_after = M::kIn2 ? s.in2[x + off_next] : (T)0;
+    const P v1_own = ldv<T, VEC>(s.in1 + x);
+    P v2_own;
+    if (M::kIn2) v2_own = ldv<T, VEC>(s.in2 + x);
+    P o1, o2, bn_own;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const T rp = (j == 0) ? r_before : r_cur.v[j > 0 ? j - 1 : 0];
-        bn_own.v[j] = acc_new<T, FISTA>(r_cur.v[j], rp, b_own.v[j], FISTA ? d_own.v[j] : (T)0, tk, cl, dn_own.v[j]);
+        bn_own.v[j] = acc_new<T, MODE>(r_cur.v[j], rp, v1_own.v[j], M::kIn2 ? v2_own.v[j] : (T)0, tk, tkp, cl, o1.v[j],
+                                       o2.v[j]);
         bnorm += fabs((double)bn_own.v[j]);
     }
-    T unused;
-    const T bn_after = acc_new<T, FISTA>(r_after, self_next ? r_after : r_cur.v[VEC - 1], b_after, d_after, tk, cl, unused);
+    T u1, u2;
+    const T bn_after = acc_new<T, MODE>(r_after, self_next ? r_after : r_cur.v[VEC - 1], v1_after, v2_after, tk, tkp,
+                                        cl, u1, u2);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const T bn_next = (j + 1 < VEC) ? bn_own.v[j + 1 < VEC ? j + 1 : 0] : bn_after;
         sum.v[j] = sum.v[j] + lm * (bn_own.v[j] - bn_next);
     }
-    stv<T, VEC>(b_out + x, bn_own);
-    if (FISTA) stv<T, VEC>(d_out + x, dn_own);
+    if (M::kOut1) stv<T, VEC>(s.out1 + x, o1);
+    if (M::kOut2) stv<T, VEC>(s.out2 + x, o2);
 }
 
-template <typename T, int VEC, int NAX, bool FISTA>
+template <typename T, int VEC, int NAX, int MODE>
 __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> p)
 {
     using P = Pack<T, VEC>;
+    using MT = ModeTraits<MODE>;
     constexpr int iM = 0, iA = 1, iB = NAX - 2, iC = NAX - 1;  // accumulator slot per canonical axis
     constexpr bool HAS_A = (NAX == 4);
 
@@ -172,19 +210,8 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
     const long long L = p.xcd ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8 : bid;
     const long long chunk_id = L / p.tiles, tile = L % p.tiles;
 
+    const long long u = tile * kFusedBlock + threadIdx.x;
     double acc[3] = {0.0, 0.0, 0.0};  // b_norm, sum|delta|, sum|old|
-    const long long LRk = p.C / VEC;
-    long long u;
-    if (p.wga > 0) {
-        // 2-D workgroup tile: wga rows of A x wgb rows of B, each row LRk lanes wide
-        const long long tilesB = p.B / p.wgb;
-        const long long ta = tile / tilesB, tb = tile % tilesB;
-        const long long row = threadIdx.x / LRk, cvk = threadIdx.x % LRk;
-        const long long ra = row / p.wgb, rb = row % p.wgb;
-        u = ((ta * p.wga + ra) * p.B + (tb * p.wgb + rb)) * LRk + cvk;
-    } else {
-        u = tile * kFusedBlock + threadIdx.x;
-    }
 
     const long long m0 = p.sweep_lo + chunk_id * p.chunk;
     const long long m1 = (m0 + p.chunk < p.sweep_hi) ? m0 + p.chunk : p.sweep_hi;
@@ -207,16 +234,13 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
         const long long offA_next = HAS_A ? (wrapA ? -(p.A - 1) * SA : SA) : 0;
         const long long offB_next = wrapB ? -(p.B - 1) * SB : SB;
         const long long offC_next = wrapC ? -(p.C - VEC) : VEC;
-        // (timing experiments only; never set by the product path)
-        const long long offA_prev_ = (p.fake & 1) ? 0 : offA_prev, offA_next_ = (p.fake & 1) ? 0 : offA_next;
-        const long long offB_prev_ = (p.fake & 2) ? 0 : offB_prev, offB_next_ = (p.fake & 2) ? 0 : offB_next;
-        const long long offC_prev_ = (p.fake & 4) ? 0 : offC_prev, offC_next_ = (p.fake & 4) ? 0 : offC_next;
         // a wrapped neighbour sits at index 0, where under Jia-Zhao its own "prev" is itself
         const bool selfA = wrapA && bc2, selfB = wrapB && bc2, selfC = wrapC && bc2;
 
-        const T tk = p.tk;
+        const T tk = p.tk, tkp = p.tk_prev;
         const T clM = p.clip[iM], clB = p.clip[iB], clC = p.clip[iC];
         const T lmM = p.lm[iM], lmB = p.lm[iB], lmC = p.lm[iC];
+        const AxisState<T> sM = p.ax[iM];
 
         // ---- prologue: M-axis accumulator of row m0 -----------------------------------------------
         P r_cur = ldv<T, VEC>(p.r_in + m0 * SM + xs);
@@ -227,22 +251,23 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
                 mp = m0 - 1;
             else
                 mp = bc2 ? m0 : p.row_hi - 1;  // TVDN_EDGE_BC: Jia-Zhao -> itself, periodic -> last row
+            const long long x0 = m0 * SM + xs;
             const P r_prev = ldv<T, VEC>(p.r_in + mp * SM + xs);
-            const P b0 = ldv<T, VEC>(p.b_in[iM] + m0 * SM + xs);
-            P d0, dn;
-            if (FISTA) d0 = ldv<T, VEC>(p.d_in[iM] + m0 * SM + xs);
+            const P v1 = ldv<T, VEC>(sM.in1 + x0);
+            P v2, o1, o2;
+            if (MT::kIn2) v2 = ldv<T, VEC>(sM.in2 + x0);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                bM_cur.v[j] = acc_new<T, FISTA>(r_cur.v[j], r_prev.v[j], b0.v[j], FISTA ? d0.v[j] : (T)0, tk, clM, dn.v[j]);
+                bM_cur.v[j] = acc_new<T, MODE>(r_cur.v[j], r_prev.v[j], v1.v[j], MT::kIn2 ? v2.v[j] : (T)0, tk, tkp, clM,
+                                               o1.v[j], o2.v[j]);
                 acc[0] += fabs((double)bM_cur.v[j]);
             }
-            stv<T, VEC>(p.b_out[iM] + m0 * SM + xs, bM_cur);
-            if (FISTA) stv<T, VEC>(p.d_out[iM] + m0 * SM + xs, dn);
+            if (MT::kOut1) stv<T, VEC>(sM.out1 + x0, o1);
+            if (MT::kOut2) stv<T, VEC>(sM.out2 + x0, o2);
         }
 
         // ---- march -------------------------------------------------------------------------------
         for (long long m = m0; m < m1; ++m) {
-            if (p.sync) __syncthreads();
             const long long x = m * SM + xs;
             const bool last = (m + 1 == m1);
             const bool at_end = (m + 1 == p.row_hi);
@@ -255,18 +280,18 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
                 const bool wrap = at_end && p.hi_mode == TVDN_EDGE_BC;
                 const long long xn = (wrap ? p.row_lo : m + 1) * SM + xs;
                 r_next = ldv<T, VEC>(p.r_in + xn);
-                const P bn = ldv<T, VEC>(p.b_in[iM] + xn);
-                P dn_in, dn;
-                if (FISTA) dn_in = ldv<T, VEC>(p.d_in[iM] + xn);
+                const P v1 = ldv<T, VEC>(sM.in1 + xn);
+                P v2, o1, o2;
+                if (MT::kIn2) v2 = ldv<T, VEC>(sM.in2 + xn);
                 const bool self = wrap && bc2;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j)
-                    bM_next.v[j] = acc_new<T, FISTA>(r_next.v[j], self ? r_next.v[j] : r_cur.v[j], bn.v[j],
-                                                     FISTA ? dn_in.v[j] : (T)0, tk, clM, dn.v[j]);
+                    bM_next.v[j] = acc_new<T, MODE>(r_next.v[j], self ? r_next.v[j] : r_cur.v[j], v1.v[j],
+                                                    MT::kIn2 ? v2.v[j] : (T)0, tk, tkp, clM, o1.v[j], o2.v[j]);
                 // rows inside the chunk are owned here, and so is a halo row sitting at row_hi
                 if (!last || (at_end && p.hi_mode == TVDN_EDGE_HALO)) {
-                    stv<T, VEC>(p.b_out[iM] + xn, bM_next);
-                    if (FISTA) stv<T, VEC>(p.d_out[iM] + xn, dn);
+                    if (MT::kOut1) stv<T, VEC>(sM.out1 + xn, o1);
+                    if (MT::kOut2) stv<T, VEC>(sM.out2 + xn, o2);
                 }
                 if (!last) {
 #pragma unroll
@@ -279,12 +304,12 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
 #pragma unroll
             for (int j = 0; j < VEC; ++j) sum.v[j] = lmM * (bM_cur.v[j] - bM_next.v[j]);
             if (HAS_A)
-                axis_pack<T, VEC, FISTA>(r_cur, p.r_in, p.b_in[iA], p.d_in[iA], p.b_out[iA], p.d_out[iA], x,
-                                         offA_prev_, offA_next_, selfA, tk, p.clip[iA], p.lm[iA], sum, acc[0]);
-            axis_pack<T, VEC, FISTA>(r_cur, p.r_in, p.b_in[iB], p.d_in[iB], p.b_out[iB], p.d_out[iB], x, offB_prev_,
-                                     offB_next_, selfB, tk, clB, lmB, sum, acc[0]);
-            axis_contig<T, VEC, FISTA>(r_cur, p.r_in, p.b_in[iC], p.d_in[iC], p.b_out[iC], p.d_out[iC], x, offC_prev_,
-                                       offC_next_, selfC, tk, clC, lmC, sum, acc[0]);
+                axis_pack<T, VEC, MODE>(r_cur, p.r_in, p.ax[iA], x, offA_prev, offA_next, selfA, tk, tkp, p.clip[iA],
+                                        p.lm[iA], sum, acc[0]);
+            axis_pack<T, VEC, MODE>(r_cur, p.r_in, p.ax[iB], x, offB_prev, offB_next, selfB, tk, tkp, clB, lmB, sum,
+                                    acc[0]);
+            axis_contig<T, VEC, MODE>(r_cur, p.r_in, p.ax[iC], x, offC_prev, offC_next, selfC, tk, tkp, clC, lmC, sum,
+                                      acc[0]);
 
             // (3) reconstruction update at row m (utils.pyx:90-104)
             const P og = ldv<T, VEC>(p.orig + x);
@@ -305,12 +330,23 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
     block_store_partials<3, kFusedBlock>(acc, p.partials);
 }
 
-template <typename T, int VEC, int NAX, bool FISTA>
-static int launch_fused_t(tvdn_ctx *ctx, const FusedParams<T> &p, int grid, hipStream_t s)
+template <typename T, int VEC, int NAX, int MODE>
+static int launch_fused_t(const FusedParams<T> &p, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((fused_iter_kernel<T, VEC, NAX, FISTA>), dim3(grid), dim3(kFusedBlock), 0, s, p);
+    hipLaunchKernelGGL((fused_iter_kernel<T, VEC, NAX, MODE>), dim3(grid), dim3(kFusedBlock), 0, s, p);
     TVDN_HIP(hipGetLastError());
     return TVDN_OK;
+}
+
+template <typename T, int VEC, int NAX>
+static int launch_fused_m(const FusedParams<T> &p, int mode, int grid, hipStream_t s)
+{
+    switch (mode) {
+    case TVDN_ITER_PLAIN: return launch_fused_t<T, VEC, NAX, TVDN_ITER_PLAIN>(p, grid, s);
+    case TVDN_ITER_FISTA: return launch_fused_t<T, VEC, NAX, TVDN_ITER_FISTA>(p, grid, s);
+    case TVDN_ITER_FISTA_D: return launch_fused_t<T, VEC, NAX, TVDN_ITER_FISTA_D>(p, grid, s);
+    default: return launch_fused_t<T, VEC, NAX, TVDN_ITER_FISTA_D_TO_PLAIN>(p, grid, s);
+    }
 }
 
 static bool aligned16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
@@ -321,6 +357,7 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
     constexpr int VMAX = 16 / sizeof(T);
     const Geom g = make_geom(a->ndim, a->shape);
     const int nax = a->ndim;
+    const int mode = a->mode;
     FusedParams<T> p;
     std::memset(&p, 0, sizeof p);
     p.orig = (const T *)a->orig;
@@ -328,15 +365,28 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
     p.r_out = (T *)a->recon_out;
     bool al = aligned16(p.orig) && aligned16(p.r_in) && aligned16(p.r_out);
     for (int q = 0; q < nax; ++q) {
-        p.b_in[q] = (const T *)a->b_in[q];
-        p.b_out[q] = (T *)a->b_out[q];
-        p.d_in[q] = a->fista ? (const T *)a->d_in[q] : nullptr;
-        p.d_out[q] = a->fista ? (T *)a->d_out[q] : nullptr;
+        AxisState<T> &x = p.ax[q];
+        switch (mode) {
+        case TVDN_ITER_PLAIN:
+            x.in1 = (const T *)a->b_in[q]; x.out1 = (T *)a->b_out[q];
+            break;
+        case TVDN_ITER_FISTA:
+            x.in1 = (const T *)a->b_in[q]; x.in2 = (const T *)a->d_in[q];
+            x.out1 = (T *)a->b_out[q]; x.out2 = (T *)a->d_out[q];
+            break;
+        case TVDN_ITER_FISTA_D:
+            x.in1 = (const T *)a->dprev_in[q]; x.in2 = (const T *)a->d_in[q]; x.out2 = (T *)a->d_out[q];
+            break;
+        default:  // TVDN_ITER_FISTA_D_TO_PLAIN
+            x.in1 = (const T *)a->dprev_in[q]; x.in2 = (const T *)a->d_in[q]; x.out1 = (T *)a->b_out[q];
+            break;
+        }
         p.clip[q] = (T)a->clip[q];
         p.lm[q] = (T)a->lambda_mu[q];
-        al = al && aligned16(p.b_in[q]) && aligned16(p.b_out[q]) && aligned16(p.d_in[q]) && aligned16(p.d_out[q]);
+        al = al && aligned16(x.in1) && aligned16(x.in2) && aligned16(x.out1) && aligned16(x.out2);
     }
     p.tk = (T)a->tk;
+    p.tk_prev = (T)a->tk_prev;
     p.M = g.n[0]; p.A = g.n[1]; p.B = g.n[2]; p.C = g.n[3];
     p.row_lo = a->row_lo; p.row_hi = a->row_hi;
     const bool whole = (a->sweep_lo == 0 && a->sweep_hi == 0);
@@ -348,22 +398,9 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
     const int vec = (al && (p.C % VMAX == 0)) ? VMAX : 1;
     p.units = p.A * p.B * (p.C / vec);
     p.tiles = (p.units + kFusedBlock - 1) / kFusedBlock;
-    // tuning knobs (measurement only): TVDN_WGA = rows of A per workgroup, TVDN_SYNC, TVDN_CHUNK
-    const char *e_wga = getenv("TVDN_WGA"), *e_sync = getenv("TVDN_SYNC"), *e_chunk = getenv("TVDN_CHUNK");
-    p.wga = 0; p.wgb = 0; p.sync = 0;
-    p.xcd = getenv("TVDN_XCD") ? atoi(getenv("TVDN_XCD")) : 1;
-    p.fake = getenv("TVDN_FAKE") ? atoi(getenv("TVDN_FAKE")) : 0;
-    {
-        const long long lr = p.C / vec;
-        const long long rows_wg = (lr <= kFusedBlock && kFusedBlock % lr == 0) ? kFusedBlock / lr : 0;
-        int want = e_wga ? atoi(e_wga) : 0;
-        if (rows_wg > 0 && want > 0 && rows_wg % want == 0 && p.A % want == 0 && p.B % (rows_wg / want) == 0) {
-            p.wga = want;
-            p.wgb = (int)(rows_wg / want);
-            // a uniform barrier needs every thread of the workgroup in the loop: true for full tiles
-            p.sync = e_sync ? atoi(e_sync) : 0;
-        }
-    }
+    // tuning knobs (measurement only): TVDN_CHUNK = rows per march, TVDN_XCD = 0 disables the XCD remap
+    const char *e_chunk = getenv("TVDN_CHUNK"), *e_xcd = getenv("TVDN_XCD");
+    p.xcd = e_xcd ? atoi(e_xcd) : 1;
     const long long rows = p.sweep_hi - p.sweep_lo;
     // rows per march: long enough to amortise the look-ahead row (3 extra pack loads per chunk); short
     // marches measured best on MI355X (2..8 rows: 14.7-14.9 ms, 32 rows: 15.3 ms on 256x256x128x128 f32):
@@ -384,15 +421,10 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
         TVDN_HIP(hipEventRecord(ev0, s));
     }
     int rc;
-#define TVDN_LAUNCH(V, N, F) rc = launch_fused_t<T, V, N, F>(ctx, p, (int)grid, s)
-    if (vec == VMAX) {
-        if (nax == 4) { if (a->fista) TVDN_LAUNCH(VMAX, 4, true); else TVDN_LAUNCH(VMAX, 4, false); }
-        else          { if (a->fista) TVDN_LAUNCH(VMAX, 3, true); else TVDN_LAUNCH(VMAX, 3, false); }
-    } else {
-        if (nax == 4) { if (a->fista) TVDN_LAUNCH(1, 4, true); else TVDN_LAUNCH(1, 4, false); }
-        else          { if (a->fista) TVDN_LAUNCH(1, 3, true); else TVDN_LAUNCH(1, 3, false); }
-    }
-#undef TVDN_LAUNCH
+    if (vec == VMAX)
+        rc = (nax == 4) ? launch_fused_m<T, VMAX, 4>(p, mode, (int)grid, s) : launch_fused_m<T, VMAX, 3>(p, mode, (int)grid, s);
+    else
+        rc = (nax == 4) ? launch_fused_m<T, 1, 4>(p, mode, (int)grid, s) : launch_fused_m<T, 1, 3>(p, mode, (int)grid, s);
     if (ctx->timing) {
         TVDN_HIP(hipEventRecord(ev1, s));
         ctx->events.emplace_back(ev0, ev1);
@@ -416,6 +448,7 @@ extern "C" int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *a, double
         return TVDN_ERR_UNSUPPORTED;
     }
     TVDN_REQUIRE(a->bc_mode == 0 || a->bc_mode == 2, "bc_mode must be 0 or 2, got %d", a->bc_mode);
+    TVDN_REQUIRE(a->mode >= TVDN_ITER_PLAIN && a->mode <= TVDN_ITER_FISTA_D_TO_PLAIN, "bad mode %d", a->mode);
     TVDN_REQUIRE(0 <= a->row_lo && a->row_lo < a->row_hi && a->row_hi <= a->shape[0],
                  "own rows [%lld,%lld) not inside 0..%lld", (long long)a->row_lo, (long long)a->row_hi,
                  (long long)a->shape[0]);
@@ -432,8 +465,20 @@ extern "C" int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *a, double
     TVDN_REQUIRE(a->orig && a->recon_in && a->recon_out, "NULL state pointer");
     TVDN_REQUIRE(a->recon_in != a->recon_out, "the fused sweep is not in-place: recon_in == recon_out");
     for (int q = 0; q < a->ndim; ++q) {
-        TVDN_REQUIRE(a->b_in[q] && a->b_out[q] && a->b_in[q] != a->b_out[q], "b_in[%d]/b_out[%d] NULL or aliased", q, q);
-        if (a->fista) TVDN_REQUIRE(a->d_in[q] && a->d_out[q] && a->d_in[q] != a->d_out[q], "d_in[%d]/d_out[%d] NULL or aliased", q, q);
+        const bool need_b_in = (a->mode == TVDN_ITER_PLAIN || a->mode == TVDN_ITER_FISTA);
+        const bool need_b_out = (a->mode != TVDN_ITER_FISTA_D);
+        const bool need_d_in = (a->mode != TVDN_ITER_PLAIN);
+        const bool need_d_out = (a->mode == TVDN_ITER_FISTA || a->mode == TVDN_ITER_FISTA_D);
+        const bool need_dprev = (a->mode == TVDN_ITER_FISTA_D || a->mode == TVDN_ITER_FISTA_D_TO_PLAIN);
+        if (need_b_in) TVDN_REQUIRE(a->b_in[q] != nullptr, "b_in[%d] is NULL", q);
+        if (need_b_out) TVDN_REQUIRE(a->b_out[q] != nullptr && a->b_out[q] != a->b_in[q], "b_out[%d] NULL or aliases b_in", q);
+        if (need_d_in) TVDN_REQUIRE(a->d_in[q] != nullptr, "d_in[%d] is NULL", q);
+        if (need_d_out) TVDN_REQUIRE(a->d_out[q] != nullptr && a->d_out[q] != a->d_in[q], "d_out[%d] NULL or aliases d_in", q);
+        if (need_dprev) {
+            TVDN_REQUIRE(a->dprev_in[q] != nullptr, "dprev_in[%d] is NULL", q);
+            if (need_d_out) TVDN_REQUIRE(a->d_out[q] != a->dprev_in[q], "d_out[%d] aliases dprev_in", q);
+            if (need_b_out) TVDN_REQUIRE(a->b_out[q] != a->dprev_in[q] && a->b_out[q] != a->d_in[q], "b_out[%d] aliases the d state", q);
+        }
     }
     return a->dtype == TVDN_F32 ? iterate_fused_impl<float>(ctx, a, sums_out, (hipStream_t)stream)
                                 : iterate_fused_impl<double>(ctx, a, sums_out, (hipStream_t)stream);

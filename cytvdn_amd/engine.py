@@ -19,12 +19,17 @@ SlabRunner   drives a backend: FISTA schedule (float64 on the host as upstream, 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
 import torch
 
 from . import _lib
+
+
+# accumulator state representation used by HipBackend unless told otherwise (see its docstring)
+DEFAULT_STATE = os.environ.get("TVDN_STATE", "compact")
 
 
 def fista_ratios(n: int) -> np.ndarray:
@@ -121,13 +126,26 @@ class SlabLayout:
 
 
 class HipBackend:
-    """State of one slab in HBM + the fused sweep.  torch is the allocator, nothing more."""
+    """State of one slab in HBM + the fused sweep.  torch is the allocator, nothing more.
 
-    def __init__(self, layout: SlabLayout, dtype, fista: bool, device: int = 0, max_iters: int = 1):
+    state="compact" (default): FISTA keeps, per axis, three rotating arrays d_k+1 / d_k / d_k-1 and
+    rebuilds b_k = d_k + tk_prev*(d_k - d_k-1) on the fly (tvdn.h TVDN_ITER_FISTA_D): 15 arrays and
+    15 array passes per 4-D iteration.  Unaccelerated iterations ping-pong b in two of those arrays.
+    state="reference": the reference's own (b, d) pair per axis, double-buffered (TVDN_ITER_FISTA):
+    19 arrays, 19 passes; kept for cross-checks."""
+
+    supports_partial_sweeps = True
+
+    def __init__(self, layout: SlabLayout, dtype, fista: bool, device: int = 0, max_iters: int = 1,
+                 state: str = None):
+        state = DEFAULT_STATE if state is None else state
+        if state not in ("compact", "reference"):
+            raise ValueError("state must be 'compact' or 'reference'")
         self.layout = layout
         self.dtype = np.dtype(dtype)
         self.code = _lib.dtype_code(self.dtype)
         self.fista = bool(fista)
+        self.state = state
         self.device = int(device)
         self.nd = len(layout.shape)
         if self.nd not in (3, 4):
@@ -136,12 +154,25 @@ class HipBackend:
         tdt = torch.float32 if self.dtype == np.float32 else torch.float64
         dev = torch.device("cuda", self.device)
         ls = layout.local_shape
-        self.orig = torch.zeros(ls, dtype=tdt, device=dev)
-        self.recon = [torch.zeros(ls, dtype=tdt, device=dev) for _ in range(2)]
-        self.b = [[torch.zeros(ls, dtype=tdt, device=dev) for _ in range(2)] for _ in range(self.nd)]
-        self.d = [[torch.zeros(ls, dtype=tdt, device=dev) for _ in range(2)] for _ in range(self.nd)] if fista else None
+
+        def z():
+            return torch.zeros(ls, dtype=tdt, device=dev)
+
+        self.orig = z()
+        self.recon = [z(), z()]
+        if state == "reference":
+            self.b = [[z(), z()] for _ in range(self.nd)]
+            self.d = [[z(), z()] for _ in range(self.nd)] if fista else None
+        else:
+            # S[q][k]: k-th rotating array of axis q (3 with FISTA: d_k, d_k-1, next; 2 without: b, next)
+            self.S = [[z() for _ in range(3 if fista else 2)] for _ in range(self.nd)]
+            self.i_d, self.i_prev, self.i_out = 0, 1, 2      # roles while the state is in d-form
+            self.i_b, self.i_bout = 0, 1                     # roles while the state is in b-form
+            self.d_form = bool(fista)                        # all-zero d_k, d_k-1 == all-zero b
+        self.tk_prev = 0.0
         self.sums = torch.zeros((max(int(max_iters), 1), 3), dtype=torch.float64, device=dev)
         self.cur = 0
+        self._mode = None
         self._args = _lib.IterArgs()
         a = self._args
         a.dtype, a.ndim = self.code, self.nd
@@ -163,26 +194,50 @@ class HipBackend:
         self.orig.copy_(t, non_blocking=False)
         self.recon[self.cur].copy_(self.orig)
 
-    supports_partial_sweeps = True
-
-    def step(self, tk_ratio, slot: int, rows=None, accumulate: bool = False):
-        """One iteration over the own rows, or over the sub-range `rows` = (lo, hi) of them; the state
-        buffers flip when the last own row has been advanced (callers sweep sub-ranges so that the
-        range ending at row_hi comes last, or call `flip()` themselves)."""
+    def _bind(self, tk_ratio):
+        """Point the argument block at the arrays of the iteration about to run."""
         a = self._args
         i, o = self.cur, self.cur ^ 1
         use_fista = tk_ratio is not None
         if use_fista and not self.fista:
             raise ValueError("backend was allocated without FISTA state")
-        a.fista = 1 if use_fista else 0
         a.tk = float(tk_ratio) if use_fista else 0.0
+        a.tk_prev = float(self.tk_prev)
         a.recon_in, a.recon_out = self.recon[i].data_ptr(), self.recon[o].data_ptr()
         for q in range(self.nd):
-            a.b_in[q], a.b_out[q] = self.b[q][i].data_ptr(), self.b[q][o].data_ptr()
-            if use_fista:
-                a.d_in[q], a.d_out[q] = self.d[q][i].data_ptr(), self.d[q][o].data_ptr()
-            else:
-                a.d_in[q], a.d_out[q] = None, None
+            a.b_in[q] = a.b_out[q] = a.d_in[q] = a.d_out[q] = a.dprev_in[q] = None
+        if self.state == "reference":
+            mode = _lib.ITER_FISTA if use_fista else _lib.ITER_PLAIN
+            for q in range(self.nd):
+                a.b_in[q], a.b_out[q] = self.b[q][i].data_ptr(), self.b[q][o].data_ptr()
+                if use_fista:
+                    a.d_in[q], a.d_out[q] = self.d[q][i].data_ptr(), self.d[q][o].data_ptr()
+        elif use_fista:
+            if not self.d_form:
+                raise ValueError("a FISTA iteration cannot follow an unaccelerated one (nor does it upstream)")
+            mode = _lib.ITER_FISTA_D
+            for q in range(self.nd):
+                S = self.S[q]
+                a.d_in[q], a.dprev_in[q], a.d_out[q] = S[self.i_d].data_ptr(), S[self.i_prev].data_ptr(), S[self.i_out].data_ptr()
+        elif self.d_form:
+            mode = _lib.ITER_FISTA_D_TO_PLAIN
+            for q in range(self.nd):
+                S = self.S[q]
+                a.d_in[q], a.dprev_in[q], a.b_out[q] = S[self.i_d].data_ptr(), S[self.i_prev].data_ptr(), S[self.i_out].data_ptr()
+        else:
+            mode = _lib.ITER_PLAIN
+            for q in range(self.nd):
+                S = self.S[q]
+                a.b_in[q], a.b_out[q] = S[self.i_b].data_ptr(), S[self.i_bout].data_ptr()
+        a.mode = mode
+        self._mode = (mode, tk_ratio)
+
+    def step(self, tk_ratio, slot: int, rows=None, accumulate: bool = False):
+        """One iteration over the own rows, or over the sub-range `rows` = (lo, hi) of them.  The state
+        arrays rotate when the whole range has been advanced: automatically for a full sweep, by
+        `flip()` after a set of partial sweeps."""
+        self._bind(tk_ratio)
+        a = self._args
         if rows is None:
             a.sweep_lo, a.sweep_hi = 0, 0
         else:
@@ -191,11 +246,22 @@ class HipBackend:
         _lib.check(_lib.lib().tvdn_iterate_fused(self.ctx, C.byref(a), C.c_void_p(self.sums[slot].data_ptr()),
                                                  _lib.current_stream(self.device)))
         if rows is None:
-            self.cur = o
+            self.flip()
 
     def flip(self):
-        """Make the freshly written buffers current (after a set of partial sweeps)."""
+        """Make the freshly written arrays current (after a full sweep or a set of partial sweeps)."""
+        mode, tk_ratio = self._mode
         self.cur ^= 1
+        if self.state == "compact":
+            if mode == _lib.ITER_FISTA_D:
+                self.i_d, self.i_prev, self.i_out = self.i_out, self.i_d, self.i_prev
+            elif mode == _lib.ITER_FISTA_D_TO_PLAIN:
+                self.i_b, self.i_bout = self.i_out, self.i_prev      # b now lives where d_k+1 would have gone
+                self.d_form = False
+            elif mode == _lib.ITER_PLAIN:
+                self.i_b, self.i_bout = self.i_bout, self.i_b
+        if tk_ratio is not None:
+            self.tk_prev = float(tk_ratio)
 
     def recon_next(self) -> torch.Tensor:
         """The buffer the sweeps of the current iteration write into."""
@@ -217,9 +283,13 @@ class HipBackend:
                                                     refo.data_ptr(), own.data_ptr(), out.data_ptr(),
                                                     _lib.current_stream(self.device)))
 
+    def n_arrays(self) -> int:
+        if self.state == "reference":
+            return 1 + 2 + 2 * self.nd * (2 if self.fista else 1)
+        return 1 + 2 + self.nd * (3 if self.fista else 2)
+
     def state_bytes(self) -> int:
-        n = 1 + 2 + 2 * self.nd * (2 if self.fista else 1)
-        return n * int(np.prod(self.layout.local_shape)) * self.dtype.itemsize
+        return self.n_arrays() * int(np.prod(self.layout.local_shape)) * self.dtype.itemsize
 
 
 class SlabRunner:
@@ -403,7 +473,7 @@ def hbm_plan(shape, dtype, fista: bool, world: int = 1) -> dict:
     n = int(np.prod(shape)) // max(world, 1)
     item = np.dtype(dtype).itemsize
     nd = len(shape)
-    arrays = 1 + 2 + 2 * nd * (2 if fista else 1)
+    arrays = 1 + 2 + nd * (3 if fista else 2)   # orig, recon x2, rotating accumulator arrays per axis
     return dict(arrays=arrays, bytes=arrays * n * item, per_array=n * item)
 
 

@@ -98,9 +98,17 @@ int tvdn_sum_square_error(tvdn_ctx *ctx, int dtype, int ndim, const int64_t *sha
  * update, cyTVDN/cyTVDN.py:153-184 / :205-230 / :372-392 / :405-420) as a single fused sweep
  * that reads every state array once and writes it once.
  *
- * State is double-buffered: the sweep reads *_in and writes *_out (no array is updated in
- * place, so neighbouring tiles may recompute each other's halo values); the caller swaps the
- * roles after each call.  `d_in`/`d_out` are NULL for the unaccelerated iteration.
+ * State is multi-buffered: the sweep reads *_in and writes *_out (no array is updated in place, so
+ * neighbouring tiles may recompute each other's halo values); the caller rotates the roles after
+ * each call.  Four state representations (`mode`):
+ *   TVDN_ITER_PLAIN            b_in -> b_out                       unaccelerated iteration
+ *   TVDN_ITER_FISTA            (b_in, d_in) -> (b_out, d_out)      the reference's own (b, d) state
+ *   TVDN_ITER_FISTA_D          (d_in = d_k, dprev_in = d_k-1) -> d_out = d_k+1
+ *                              b_k is not stored: it is rebuilt as d_k + tk_prev*(d_k - d_k-1), the
+ *                              expression that formed it (anisotropic.pyx:128) -- same bits, 15 array
+ *                              passes per 4-D iteration instead of 19.  The first call passes zeros.
+ *   TVDN_ITER_FISTA_D_TO_PLAIN (d_in, dprev_in) -> b_out           first unaccelerated iteration after
+ *                              FISTA_D iterations (hybrid schedule, cyTVDN.py:99-108)
  *
  * Slab decomposition along axis 0 (one GPU per slab): the local block has `shape[0]` rows of
  * which rows [row_lo, row_hi) are this slab's own; a row below row_lo / at row_hi is a halo
@@ -119,6 +127,11 @@ int tvdn_sum_square_error(tvdn_ctx *ctx, int dtype, int ndim, const int64_t *sha
 #define TVDN_EDGE_HALO 1
 #define TVDN_EDGE_ZERO 2
 
+#define TVDN_ITER_PLAIN 0
+#define TVDN_ITER_FISTA 1
+#define TVDN_ITER_FISTA_D 2
+#define TVDN_ITER_FISTA_D_TO_PLAIN 3
+
 typedef struct tvdn_iter_args {
     int32_t dtype;        /* tvdn_dtype                                            */
     int32_t ndim;         /* 3 or 4                                                */
@@ -128,8 +141,9 @@ typedef struct tvdn_iter_args {
     int32_t lo_mode;      /* TVDN_EDGE_*                                           */
     int32_t hi_mode;
     int32_t bc_mode;      /* 0 or 2                                                */
-    int32_t fista;        /* 0: unaccelerated (d_* ignored), 1: FISTA              */
+    int32_t mode;         /* TVDN_ITER_*                                           */
     double tk;            /* FISTA momentum ratio (tk-1)/tk_new of this iteration  */
+    double tk_prev;       /* ... of the previous iteration (TVDN_ITER_FISTA_D*)    */
     double clip[4];       /* 1/lambda per axis                                     */
     double lambda_mu[4];  /* lambda/mu per axis                                    */
     const void *orig;     /* noisy input, read only                                */
@@ -139,6 +153,7 @@ typedef struct tvdn_iter_args {
     void *b_out[4];
     const void *d_in[4];
     void *d_out[4];
+    const void *dprev_in[4]; /* d of the iteration before d_in (TVDN_ITER_FISTA_D*) */
     /* Partial sweep, for overlapping the halo exchange with the bulk of the work: advance only rows
      * [sweep_lo, sweep_hi) of the own rows (0,0 = all own rows).  Rows outside the sweep but inside
      * [row_lo,row_hi) are treated like any in-slab neighbour (read, never written).  With

@@ -34,10 +34,10 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_iter_args_struct_matches_header_layout():
-    # 2 int32 + 4 int64 + 2 int64 + 4 int32 + 1 double + 8 doubles + 3 ptr + 16 ptr + 2 int64 + 2 int32
-    assert ctypes.sizeof(_lib.IterArgs) == 8 + 32 + 16 + 16 + 8 + 64 + 24 + 128 + 16 + 8
-    assert _lib.IterArgs.shape.offset == 8 and _lib.IterArgs.tk.offset == 72 and _lib.IterArgs.orig.offset == 144
-    assert _lib.IterArgs.sweep_lo.offset == 296
+    # 2 int32 + 4 int64 + 2 int64 + 4 int32 + 2 double + 8 doubles + 3 ptr + 20 ptr + 2 int64 + 2 int32
+    assert ctypes.sizeof(_lib.IterArgs) == 8 + 32 + 16 + 16 + 16 + 64 + 24 + 160 + 16 + 8
+    assert _lib.IterArgs.shape.offset == 8 and _lib.IterArgs.tk.offset == 72 and _lib.IterArgs.orig.offset == 152
+    assert _lib.IterArgs.dprev_in.offset == 304 and _lib.IterArgs.sweep_lo.offset == 336
 
 
 def test_public_names_and_signatures():
@@ -133,7 +133,7 @@ def test_product_never_imports_the_oracle():
 
 def test_hbm_plan_counts_arrays():
     from cytvdn_amd.engine import hbm_plan
-    assert hbm_plan((256, 256, 128, 128), np.float32, True)["arrays"] == 19
-    assert hbm_plan((256, 256, 128, 128), np.float32, True)["bytes"] == 19 * 4 * 2 ** 30
+    assert hbm_plan((256, 256, 128, 128), np.float32, True)["arrays"] == 15
+    assert hbm_plan((256, 256, 128, 128), np.float32, True)["bytes"] == 15 * 4 * 2 ** 30
     assert hbm_plan((256, 256, 128, 128), np.float64, False)["arrays"] == 11
-    assert hbm_plan((128, 128, 512), np.float32, True)["arrays"] == 15
+    assert hbm_plan((128, 128, 512), np.float32, True)["arrays"] == 12
