@@ -27,7 +27,7 @@ EXPORTS = (
     "tvdn_abi_version", "tvdn_last_error", "tvdn_device_count", "tvdn_ctx_create", "tvdn_ctx_destroy",
     "tvdn_ctx_timing_enable", "tvdn_ctx_timing_read",
     "tvdn_accumulator_update", "tvdn_datacube_update", "tvdn_sum_square_error", "tvdn_iterate_fused",
-    "tvdn_synth_fill",
+    "tvdn_synth_fill", "tvdn_run",
 )
 
 
@@ -46,6 +46,18 @@ class IterArgs(C.Structure):
         ("b_in", C.c_void_p * 4), ("b_out", C.c_void_p * 4), ("d_in", C.c_void_p * 4), ("d_out", C.c_void_p * 4),
         ("dprev_in", C.c_void_p * 4),
         ("sweep_lo", C.c_int64), ("sweep_hi", C.c_int64), ("accumulate", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class RunArgs(C.Structure):
+    """struct tvdn_run_args (include/tvdn.h)."""
+    _fields_ = [
+        ("dtype", C.c_int32), ("ndim", C.c_int32), ("shape", C.c_int64 * 4),
+        ("bc_mode", C.c_int32), ("device", C.c_int32), ("n_fista", C.c_int32), ("n_plain", C.c_int32),
+        ("use_stop", C.c_int32), ("reserved", C.c_int32), ("stop", C.c_double),
+        ("clip", C.c_double * 4), ("lambda_mu", C.c_double * 4),
+        ("data", C.c_void_p), ("reference", C.c_void_p), ("recon_out", C.c_void_p),
+        ("sums_out", C.c_void_p), ("mse_out", C.c_void_p), ("iters_run", C.c_void_p),
     ]
 
 
@@ -86,6 +98,7 @@ def lib():
     L.tvdn_sum_square_error.argtypes = [C.c_void_p, C.c_int, C.c_int, i64p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]
     L.tvdn_iterate_fused.argtypes = [C.c_void_p, C.POINTER(IterArgs), C.c_void_p, C.c_void_p]
+    L.tvdn_run.argtypes = [C.POINTER(RunArgs)]
     L.tvdn_synth_fill.argtypes = [C.c_int, C.c_int, i64p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header and library out of step

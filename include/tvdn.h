@@ -166,6 +166,43 @@ typedef struct tvdn_iter_args {
 
 int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *args, double *sums_out, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Whole-loop entry point on HOST arrays: what denoise4D / denoise3D do between their argument
+ * checks and their return (cyTVDN/cyTVDN.py:122-247, :345-435), for callers that are not Python.
+ * Copies `data` to HBM once, runs n_fista FISTA iterations then n_plain unaccelerated ones
+ * (float64 tk recurrence of cyTVDN.py:153-156; compact d-rotation state), copies recon back once.
+ *   sums_out  host, (n_fista+n_plain) x 3 doubles: sum|b_new|, sum|recon_new-recon_old|, sum|recon_old|
+ *             per iteration (the reference's b_norm[i] and delta_recon[i] = [1]/[2]); rows of
+ *             iterations that did not run stay zero
+ *   mse_out   host, n_fista+n_plain+1 doubles, or NULL; needs `reference` (sum of squared errors)
+ *   use_stop  when non-zero a phase ends as soon as delta_recon (formed in the data dtype, as upstream)
+ *             drops below `stop`; a FISTA-phase stop still falls through to the unaccelerated phase
+ *             (cyTVDN.py:189-195)
+ *   iters_run host, optional: number of iterations executed
+ * ---------------------------------------------------------------------------------------- */
+typedef struct tvdn_run_args {
+    int32_t dtype;
+    int32_t ndim;
+    int64_t shape[4];
+    int32_t bc_mode;       /* 0 or 2 */
+    int32_t device;
+    int32_t n_fista;
+    int32_t n_plain;
+    int32_t use_stop;
+    int32_t reserved;
+    double stop;
+    double clip[4];        /* 1/lambda per axis, already rounded to the data dtype by the caller */
+    double lambda_mu[4];   /* lambda/mu per axis, idem */
+    const void *data;      /* host, C-contiguous, never written */
+    const void *reference; /* host or NULL */
+    void *recon_out;       /* host, same shape/dtype as data */
+    double *sums_out;
+    double *mse_out;
+    int32_t *iters_run;
+} tvdn_run_args;
+
+int tvdn_run(const tvdn_run_args *args);
+
 /* Synthetic input (cytvdn_amd/synth.py restated on the device, bit-identical): fills rows
  * [row0, row0+rows) of the GLOBAL cube `shape` into `out` (rows*prod(shape[1:]) elements). */
 int tvdn_synth_fill(int dtype, int ndim, const int64_t *shape, uint64_t seed, int64_t row0,

@@ -179,3 +179,50 @@ def test_nonfinite_and_strided_views(tv, oracle):
     oracle.acc_update(a, b_ref, None, 0.0, 1, 0.7, 0)
     assert bits_equal(np.ascontiguousarray(b), b_ref)
     assert np.isnan(b[2, 3, 1]) and np.isnan(b[2, 4, 1])
+
+
+@pytest.mark.parametrize("shape,dtype,its,fista,stop,with_ref", [
+    ((6, 5, 8, 12), np.float32, 7, True, None, False),
+    ((7, 6, 16), np.float64, [4, 3], True, None, True),
+    ((6, 5, 8, 12), np.float32, 40, False, 0.02, False),
+    ((5, 3, 7, 9), np.float64, [30, 6], True, 0.03, True),
+])
+def test_tvdn_run_host_entry(tv, shape, dtype, its, fista, stop, with_ref):
+    """The C whole-loop entry point (tvdn_run, host pointers) gives what denoise3D/4D give, bit for bit,
+    including its own float64 tk recurrence and the early-stop bookkeeping."""
+    import ctypes as C
+    from cytvdn_amd import _lib, synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=31, dtype=dt)
+    refd = synth.cube(shape, seed=31, dtype=dt, kind="mean") if with_ref else None
+    mu = np.array([1.0, 1.0, 0.5, 0.5][:nd], dt)
+    lam = mu / dt.type(32.0 if nd == 4 else 16.0)
+    fn = tv.denoise4D if nd == 4 else tv.denoise3D
+    want = fn(x, mu, its, FISTA=fista, stopping_relative_change=stop, reference_data=refd, quiet=True)
+    n_f, n_p = (its if isinstance(its, list) else ((its, 0) if fista else (0, its)))
+    n = n_f + n_p
+    a = _lib.RunArgs(dtype=_lib.dtype_code(dt), ndim=nd, bc_mode=2, device=0, n_fista=n_f, n_plain=n_p,
+                     use_stop=int(stop is not None), stop=float(stop or 0.0))
+    for i, s in enumerate(shape):
+        a.shape[i] = s
+    for q in range(nd):
+        a.clip[q] = float((1.0 / lam)[q])
+        a.lambda_mu[q] = float((lam / mu).astype(dt)[q])
+    recon = np.empty_like(x)
+    sums = np.zeros((n, 3))
+    mse = np.zeros(n + 1)
+    ran = C.c_int32(0)
+    a.data, a.recon_out, a.sums_out = x.ctypes.data, recon.ctypes.data, sums.ctypes.data
+    if with_ref:
+        a.reference, a.mse_out = refd.ctypes.data, mse.ctypes.data
+    a.iters_run = C.addressof(ran)
+    _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+    assert bits_equal(recon, want[0])
+    assert ran.value == int(np.count_nonzero(want[2]))
+    assert bits_equal(np.where(sums[:, 2] != 0, sums[:, 0], 0).astype(dt), want[1])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dl = np.where(sums[:, 2] != 0, sums[:, 1].astype(dt) / sums[:, 2].astype(dt), 0).astype(dt)
+    assert bits_equal(dl, want[2])
+    if with_ref:
+        assert bits_equal(mse.astype(dt), want[3])
