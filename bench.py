@@ -133,9 +133,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: cytvdn_amd has no CPU fallback")
+    backend = os.environ.get("TVDN_DIST_BACKEND", "nccl")   # "gloo": rehearsal with host-staged halo rows
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()             # several ranks may then share one GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     dtype = np.float32 if a.dtype == "f32" else np.float64
     if a.shape:

@@ -302,12 +302,48 @@ class SlabRunner:
         self.iter = 0
         self.ran = []  # slots of the iterations that actually ran
         self._side = None
+        self._p2p = None
+        self._stage = None
         self.overlap = True
         if self.layout.world > 1:
             import torch.distributed as dist
             if not dist.is_initialized():
                 raise RuntimeError("world > 1 needs an initialised torch.distributed process group")
             self.dist = dist
+
+    def _device_p2p(self) -> bool:
+        """True when the process group can send device memory directly (RCCL); a gloo group moves the
+        rows through pinned host buffers instead (used to rehearse multi-rank runs on one GPU)."""
+        if self._p2p is None:
+            self._p2p = self.dist.get_backend(self.group) != "gloo" or not self.be.recon_tensor().is_cuda
+        return self._p2p
+
+    def _exchange_staged(self, r):
+        """Same messages as `_ops`, staged through pinned host memory."""
+        lay, dist = self.layout, self.dist
+        if self._stage is None:
+            row = r[lay.row_lo]
+            self._stage = [torch.empty(row.shape, dtype=row.dtype, pin_memory=True) for _ in range(4)]
+        s_lo, s_hi, r_lo, r_hi = self._stage
+        ops = []
+        if lay.left is not None:
+            s_lo.copy_(r[lay.row_lo])
+        if lay.right is not None:
+            s_hi.copy_(r[lay.row_hi - 1])
+        torch.cuda.current_stream(r.device).synchronize()
+        if lay.left is not None:
+            ops.append(dist.P2POp(dist.isend, s_lo, self._peer(lay.left), self.group, tag=1))
+        if lay.right is not None:
+            ops.append(dist.P2POp(dist.isend, s_hi, self._peer(lay.right), self.group, tag=2))
+            ops.append(dist.P2POp(dist.irecv, r_hi, self._peer(lay.right), self.group, tag=1))
+        if lay.left is not None:
+            ops.append(dist.P2POp(dist.irecv, r_lo, self._peer(lay.left), self.group, tag=2))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if lay.right is not None:
+            r[lay.row_hi].copy_(r_hi)
+        if lay.left is not None:
+            r[lay.row_lo - 1].copy_(r_lo)
 
     def exchange_halos(self):
         """Send my first/last own recon rows to the neighbours, receive theirs into my halo rows.
@@ -319,6 +355,9 @@ class SlabRunner:
             return
         dist = self.dist
         r = self.be.recon_tensor()
+        if not self._device_p2p():
+            self._exchange_staged(r)
+            return
         # Order matters where RCCL matches messages per peer in issue order and one peer is both
         # neighbours (periodic ring of two): sends go (first row -> left, last row -> right), so the
         # receives are posted (from right, from left).
@@ -352,7 +391,7 @@ class SlabRunner:
         lay, be = self.layout, self.be
         lo, hi = lay.row_lo, lay.row_hi
         if lay.world == 1 or hi - lo < 3 or not getattr(be, "supports_partial_sweeps", False) \
-                or not be.recon_tensor().is_cuda:
+                or not be.recon_tensor().is_cuda or not self._device_p2p():
             be.step(tk_ratio, slot)
             self.exchange_halos()
             return
