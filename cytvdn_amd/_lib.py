@@ -147,5 +147,15 @@ def ctx(device: int) -> C.c_void_p:
     return h
 
 
+def new_ctx(device: int) -> C.c_void_p:
+    """A private context (own reduction scratch) for callers that drive a second stream."""
+    if not torch.cuda.is_available():
+        raise TvdnError("no MI355X visible (torch.cuda.is_available() is False): cytvdn_amd has no CPU fallback")
+    h = C.c_void_p()
+    with torch.cuda.device(device):
+        check(lib().tvdn_ctx_create(C.byref(h), int(device)))
+    return h
+
+
 def current_stream(device: int) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

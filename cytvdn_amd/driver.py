@@ -18,6 +18,7 @@ Differences, all deliberate:
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -80,6 +81,10 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
 
     if device is None:
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    staged = _staging_plan(datacube, FISTA, BC_mode, device, stopping_relative_change)
+    if staged is not None:
+        return _run_staged(staged, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain,
+                           stopping_relative_change, reference_data, BC_mode, quiet, device)
     layout = SlabLayout(tuple(datacube.shape), 0, 1, int(BC_mode))
     be = HipBackend(layout, dtype, FISTA, device=device, max_iters=n_total)   # raises without a GPU
     be.set_params(lambdaInv, lam_mu)
@@ -141,6 +146,68 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
 
     if calculate_MSE:
         return recon, b_norm, delta_recon, mse_dev.cpu().numpy().astype(dtype)
+    return recon, b_norm, delta_recon
+
+
+def _staging_plan(datacube, FISTA, BC_mode, device, stop):
+    """None when the state fits in HBM; otherwise (block_rows, k) for the out-of-core engine.
+    TVDN_STAGED="rows,k" forces staging (tests, measurements)."""
+    forced = os.environ.get("TVDN_STAGED")
+    plane_bytes = int(np.prod(datacube.shape[1:])) * datacube.dtype.itemsize
+    n_arr = hbm_plan(datacube.shape, datacube.dtype, FISTA)["arrays"]
+    if forced:
+        rows, k = (int(v) for v in forced.split(","))
+    else:
+        fr = _hbm_free(device)
+        if fr is None or n_arr * datacube.nbytes < 0.9 * fr[0]:
+            return None
+        # two staging buffers of (rows + 2k) rows each must fit in 80 % of the free HBM
+        k = 16
+        rows = int(0.8 * fr[0] / (2 * (n_arr + 1) * plane_bytes)) - 2 * k
+        if rows < 1:
+            k = 1
+            rows = max(1, int(0.8 * fr[0] / (2 * (n_arr + 1) * plane_bytes)) - 2)
+    if stop is not None:
+        k = 1      # the stopping test is per iteration (cyTVDN.py:189-194): no temporal blocking then
+    if BC_mode != 2:
+        raise NotImplementedError("a cube that needs staging through host memory supports BC_mode=2 only")
+    return max(1, rows), max(1, k)
+
+
+def _run_staged(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, stop, reference_data,
+                BC_mode, quiet, device):
+    from .outofcore import StagedRunner
+    dtype = datacube.dtype
+    n_total = n_fista + n_plain
+    rows, k = plan
+    if not quiet:
+        print(f"State exceeds HBM: staging {rows}-row blocks through pinned host memory, {k} iterations per pass",
+              flush=True)
+    sr = StagedRunner(datacube, FISTA, lambdaInv, lam_mu, bc_mode=int(BC_mode), device=device, block_rows=rows, k=k,
+                      max_iters=n_total, reference=reference_data)
+    ran = np.zeros(n_total, dtype=bool)
+
+    def on_ss(first, count):
+        ran[first:first + count] = True
+        if stop is None:
+            return False
+        sm = sr.sums()[first]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return bool(dtype.type(dtype.type(sm[1]) / dtype.type(sm[2])) < stop)
+
+    if FISTA and n_fista:
+        sr.run(n_fista, 0, on_ss)
+        sr.iters_done = n_fista
+    if unaccelerated and n_plain:
+        sr.run(0, n_plain, on_ss)
+    sums = sr.sums()[:n_total] if n_total else np.zeros((0, 3))
+    b_norm = np.where(ran, sums[:, 0], 0.0).astype(dtype)
+    num, den = sums[:, 1].astype(dtype), sums[:, 2].astype(dtype)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        delta_recon = np.where(ran, num / den, dtype.type(0)).astype(dtype)
+    recon = sr.recon()
+    if reference_data is not None:
+        return recon, b_norm, delta_recon, sr.mse().astype(dtype)
     return recon, b_norm, delta_recon
 
 

@@ -137,7 +137,7 @@ class HipBackend:
     supports_partial_sweeps = True
 
     def __init__(self, layout: SlabLayout, dtype, fista: bool, device: int = 0, max_iters: int = 1,
-                 state: str = None):
+                 state: str = None, private_ctx: bool = False):
         state = DEFAULT_STATE if state is None else state
         if state not in ("compact", "reference"):
             raise ValueError("state must be 'compact' or 'reference'")
@@ -150,7 +150,9 @@ class HipBackend:
         self.nd = len(layout.shape)
         if self.nd not in (3, 4):
             raise TypeError("No matching signature found")
-        self.ctx = _lib.ctx(self.device)  # raises without a GPU: no CPU fallback
+        # raises without a GPU: no CPU fallback.  A private context = own reduction scratch, needed when two
+        # backends are driven from two streams at once (cytvdn_amd/outofcore.py)
+        self.ctx = _lib.new_ctx(self.device) if private_ctx else _lib.ctx(self.device)
         tdt = torch.float32 if self.dtype == np.float32 else torch.float64
         dev = torch.device("cuda", self.device)
         ls = layout.local_shape
@@ -262,6 +264,32 @@ class HipBackend:
                 self.i_b, self.i_bout = self.i_bout, self.i_b
         if tk_ratio is not None:
             self.tk_prev = float(tk_ratio)
+
+    # -- staging support (cytvdn_amd/outofcore.py): a backend reused for blocks of varying height ----------
+    def set_block(self, rows: int, hi_mode: int):
+        """Use only the first `rows` rows of every array (a contiguous prefix) as the local block."""
+        if not (1 <= rows <= self.orig.shape[0]):
+            raise ValueError("block height out of range")
+        a = self._args
+        a.shape[0] = int(rows)
+        a.row_lo, a.row_hi = 0, int(rows)
+        a.lo_mode, a.hi_mode = _lib.EDGE_BC, int(hi_mode)
+
+    def set_form(self, d_form: bool, tk_prev: float):
+        """Declare what the state arrays hold after an upload: (d_k, d_k-1) pairs or b."""
+        if self.state != "compact":
+            raise ValueError("staging uses the compact state")
+        self.d_form = bool(d_form)
+        self.i_d, self.i_prev, self.i_out = 0, 1, 2
+        self.i_b, self.i_bout = 0, 1
+        self.cur = 0
+        self.tk_prev = float(tk_prev)
+
+    def state_tensors(self):
+        """Per axis, the arrays that define the accumulator state right now (upload/download order)."""
+        if self.d_form:
+            return [[S[self.i_d], S[self.i_prev]] for S in self.S]
+        return [[S[self.i_b]] for S in self.S]
 
     def recon_next(self) -> torch.Tensor:
         """The buffer the sweeps of the current iteration write into."""

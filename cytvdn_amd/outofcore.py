@@ -1,0 +1,205 @@
+"""Out-of-core engine: a cube whose state does not fit in HBM, staged through pinned host memory.
+
+The state (orig, recon, the compact accumulator arrays) lives in pinned host RAM.  Axis 0 is cut
+into blocks; a block is copied to the GPU together with `k` halo rows per interior side, advanced by
+`k` iterations there (temporal blocking: each iteration the sweep shrinks by one row per interior
+side, because that row's neighbour is no longer current), and its own rows are copied back.  Two
+staging buffers on two HIP streams overlap the PCIe copies of one block with the sweeps of the
+other.  PCIe traffic per voxel is (10·(1+2k/R) arrays up + 9 arrays down) per k iterations instead of
+per iteration, which is what makes the mode usable at all: PCIe Gen5 moves ≈ 55 GB/s per direction,
+HBM ≈ 5 600 GB/s.
+
+Results are bit-identical to the in-core engine: the sweeps are the same `tvdn_iterate_fused`
+launches over sub-ranges of rows (SURVEY.md §7 hard part 6, §8d config 5).  Jia-Zhao BC only.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import HipBackend, fista_ratios
+
+
+class _BlockLayout:
+    """Duck-typed layout of a staging buffer: `rows` x plane, every row 'own' (see HipBackend.set_block)."""
+
+    def __init__(self, rows, plane, bc_mode):
+        self.shape = (rows,) + tuple(plane)
+        self.local_shape = self.shape
+        self.row_lo, self.row_hi = 0, rows
+        self.lo_mode, self.hi_mode = _lib.EDGE_BC, _lib.EDGE_BC
+        self.bc_mode = bc_mode
+        self.rank, self.world = 0, 1
+
+
+def plan_blocks(n_rows: int, block_rows: int):
+    """Own-row ranges [g0, g1) of the blocks."""
+    block_rows = max(1, int(block_rows))
+    return [(g, min(g + block_rows, n_rows)) for g in range(0, n_rows, block_rows)]
+
+
+class StagedRunner:
+    """Runs the denoise loop on a host-resident cube through two staging buffers on one GPU."""
+
+    def __init__(self, datacube: np.ndarray, fista: bool, clip, lam_mu, bc_mode: int = 2, device: int = 0,
+                 block_rows: int = 32, k: int = 8, max_iters: int = 1, reference: np.ndarray = None,
+                 pin: bool = True):
+        if bc_mode != 2:
+            raise NotImplementedError("the staged engine supports the Jia-Zhao boundary condition (BC_mode=2) only")
+        self.shape = tuple(int(s) for s in datacube.shape)
+        self.nd = len(self.shape)
+        self.dtype = datacube.dtype
+        self.fista = bool(fista)
+        self.device = int(device)
+        self.k = max(1, int(k))
+        self.blocks = plan_blocks(self.shape[0], block_rows)
+        self.max_iters = max(1, int(max_iters))
+        tdt = torch.float32 if self.dtype == np.float32 else torch.float64
+        plane = self.shape[1:]
+
+        def host(fill=None):
+            t = torch.empty(self.shape, dtype=tdt, pin_memory=pin)
+            if fill is None:
+                t.zero_()
+            else:
+                t.copy_(torch.from_numpy(fill))
+            return t
+
+        # host state: orig, recon old/new, per axis up to two state arrays old/new
+        self.orig_h = host(np.ascontiguousarray(datacube))
+        self.recon_h = [self.orig_h.clone().pin_memory() if pin else self.orig_h.clone(), host()]
+        n_state = 2 if self.fista else 1
+        self.state_h = [[[host() for _ in range(n_state)] for _ in range(self.nd)] for _ in range(2)]  # [old/new][axis][j]
+        self.ref_h = host(np.ascontiguousarray(reference)) if reference is not None else None
+        self.h_old = 0
+        self.d_form = self.fista
+        self.tk_prev = 0.0
+        self.iters_done = 0
+
+        max_rows = min(self.shape[0], max(g1 - g0 for g0, g1 in self.blocks) + 2 * self.k)
+        self.stages = []
+        for _ in range(2):
+            be = HipBackend(_BlockLayout(max_rows, plane, bc_mode), self.dtype, self.fista, device=self.device,
+                            max_iters=self.max_iters + 1, private_ctx=True)       # last sums row: discard slot
+            be.set_params(clip, lam_mu)
+            be.stream = torch.cuda.Stream(device=self.device)
+            be.ref = torch.empty_like(be.orig) if reference is not None else None
+            be.mse = torch.zeros(self.max_iters + 1, dtype=torch.float64, device=be.orig.device) if reference is not None else None
+            be.tmp = torch.zeros(1, dtype=torch.float64, device=be.orig.device)
+            self.stages.append(be)
+        self.bytes_h2d = 0
+        self.bytes_d2h = 0
+        if self.ref_h is not None:  # MSE[0]: input against reference (cyTVDN.py:124-125), block by block
+            be = self.stages[0]
+            with torch.cuda.stream(be.stream):
+                for g0, g1 in self.blocks:
+                    n = g1 - g0
+                    be.orig[:n].copy_(self.orig_h[g0:g1], non_blocking=True)
+                    be.ref[:n].copy_(self.ref_h[g0:g1], non_blocking=True)
+                    self._sse(be, be.orig[:n], be.ref[:n], 0)
+            be.stream.synchronize()
+
+    def _sse(self, be, a, b, slot):
+        _lib.check(_lib.lib().tvdn_sum_square_error(be.ctx, be.code, self.nd, _lib.shape_arr(a.shape), a.data_ptr(),
+                                                    b.data_ptr(), be.tmp.data_ptr(), _lib.current_stream(self.device)))
+        be.mse[slot:slot + 1] += be.tmp
+
+    # one super-step: `ratios` holds the tk ratio of each iteration (None = unaccelerated)
+    def _superstep(self, ratios, slot0):
+        kk = len(ratios)
+        N0 = self.shape[0]
+        old, new = self.h_old, self.h_old ^ 1
+        discard = self.max_iters                      # sums row nobody reads
+        form_after = tk_after = None
+        for bi, (g0, g1) in enumerate(self.blocks):
+            be = self.stages[bi % 2]
+            s0, s1 = max(0, g0 - kk), min(N0, g1 + kk)
+            rows = s1 - s0
+            lo_edge, hi_edge = (s0 == 0), (s1 == N0)
+            whole = lo_edge and hi_edge
+            with torch.cuda.stream(be.stream):
+                be.set_block(rows, _lib.EDGE_BC if (whole or not hi_edge) else _lib.EDGE_ZERO)
+                be.set_form(self.d_form, self.tk_prev)
+                # ---- upload the block with its halo rows --------------------------------------------
+                be.orig[:rows].copy_(self.orig_h[s0:s1], non_blocking=True)
+                be.recon[be.cur][:rows].copy_(self.recon_h[old][s0:s1], non_blocking=True)
+                n_up = 2
+                for q, arrs in enumerate(be.state_tensors()):
+                    for j, t in enumerate(arrs):
+                        t[:rows].copy_(self.state_h[old][q][j][s0:s1], non_blocking=True)
+                        n_up += 1
+                if self.ref_h is not None:
+                    be.ref[:g1 - g0].copy_(self.ref_h[g0:g1], non_blocking=True)
+                    self.bytes_h2d += (g1 - g0) * self._row_bytes()
+                self.bytes_h2d += n_up * rows * self._row_bytes()
+                # ---- k iterations on a shrinking range of rows ----------------------------------------
+                v0, v1 = 0, rows                      # rows whose state is current
+                o0, o1 = g0 - s0, g1 - s0             # own rows, local
+                for j, tk in enumerate(ratios):
+                    a = v0 if lo_edge else v0 + 1
+                    b = v1 if hi_edge else v1 - 1
+                    slot = slot0 + j
+                    # the sums count own rows only: halo rows go to a discard slot
+                    if a < o0:
+                        be.step(tk, discard, rows=(a, o0), accumulate=True)
+                    be.step(tk, slot, rows=(o0, o1), accumulate=True)
+                    if o1 < b:
+                        be.step(tk, discard, rows=(o1, b), accumulate=True)
+                    be.flip()
+                    v0, v1 = a, b
+                    if self.ref_h is not None:
+                        self._sse(be, be.ref[:o1 - o0], be.recon_tensor()[o0:o1], slot + 1)
+                # ---- download the own rows ----------------------------------------------------------------
+                self.recon_h[new][g0:g1].copy_(be.recon_tensor()[o0:o1], non_blocking=True)
+                n_down = 1
+                st = be.state_tensors()
+                for q, arrs in enumerate(st):
+                    for j, t in enumerate(arrs):
+                        self.state_h[new][q][j][g0:g1].copy_(t[o0:o1], non_blocking=True)
+                        n_down += 1
+                self.bytes_d2h += n_down * (g1 - g0) * self._row_bytes()
+                form_after, tk_after = be.d_form, be.tk_prev
+        for be in self.stages:
+            be.stream.synchronize()
+        self.h_old = new
+        self.d_form, self.tk_prev = form_after, tk_after
+        self.iters_done += kk
+
+    def _row_bytes(self):
+        return int(np.prod(self.shape[1:])) * self.dtype.itemsize
+
+    def run(self, n_fista: int, n_plain: int, on_superstep=None):
+        """n_fista FISTA iterations then n_plain unaccelerated ones, k at a time.
+        `on_superstep(first_slot, count)` may return True to stop the current phase."""
+        slot = self.iters_done
+        ratios = [float(r) for r in fista_ratios(n_fista)]
+        i = 0
+        while i < n_fista:
+            grp = ratios[i:i + self.k]
+            self._superstep(grp, slot + i)
+            i += len(grp)
+            if on_superstep is not None and on_superstep(slot + i - len(grp), len(grp)):
+                break
+        slot += n_fista
+        j = 0
+        while j < n_plain:
+            n = min(self.k, n_plain - j)
+            self._superstep([None] * n, slot + j)
+            j += n
+            if on_superstep is not None and on_superstep(slot + j - n, n):
+                break
+
+    def sums(self) -> np.ndarray:
+        """[max_iters, 3] f64: b_norm, sum|delta|, sum|old| per iteration, summed over the blocks."""
+        t = sum(be.sums[: self.max_iters] for be in self.stages)
+        return t.cpu().numpy()
+
+    def mse(self) -> np.ndarray:
+        return sum(be.mse for be in self.stages).cpu().numpy()
+
+    def recon(self) -> np.ndarray:
+        return self.recon_h[self.h_old].numpy().copy()
+
+
+__all__ = ["StagedRunner", "plan_blocks"]
