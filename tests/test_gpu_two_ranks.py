@@ -71,3 +71,47 @@ def test_two_rank_processes_on_one_gpu(oracle, world, shape, dtype, bc, n_f, n_p
     assert bits_equal(recon, ref["recon"])
     np.testing.assert_allclose(parts[0]["sums"][:, 0], ref["b_norm64"], rtol=1e-12)
     np.testing.assert_allclose(parts[0]["sums"][:, 1], ref["delta64"], rtol=1e-12)
+
+
+def _worker_api(rank, world, port, shape, dtype_name, its, fista, stop, outdir):
+    import torch
+    import torch.distributed as dist
+    from cytvdn_amd import synth
+    from cytvdn_amd.distributed import denoise_slabs, slab_rows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        dt = np.dtype(dtype_name)
+        nd = len(shape)
+        full = synth.cube(shape, seed=14, dtype=dt)
+        g0, g1 = slab_rows(shape, rank, world)
+        mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
+        own, bn, dl = denoise_slabs(full[g0:g1], shape, mu, its, FISTA=fista, stopping_relative_change=stop, device=0)
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), own=own, bn=bn, dl=dl)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,dtype,its,fista,stop", [
+    (2, (6, 5, 8, 12), "float32", 40, False, 0.02),
+    (2, (7, 6, 16), "float64", [30, 6], True, 0.03),
+], ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_denoise_slabs_on_gpu_matches_single_process(oracle, world, shape, dtype, its, fista, stop):
+    """The user-facing slab API (global traces, global stopping criterion) through the HIP sweep."""
+    import torch.multiprocessing as mp
+    from cytvdn_amd import synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.start_processes(_worker_api, args=(world, _free_port(), shape, dtype, its, fista, stop, tmp), nprocs=world,
+                           join=True, start_method="spawn")
+        parts = [np.load(os.path.join(tmp, f"r{r}.npz")) for r in range(world)]
+    x = synth.cube(shape, seed=14, dtype=dt)
+    mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
+    ref = oracle.denoise(x, mu, its, fista, stopping_relative_change=stop)
+    assert bits_equal(np.concatenate([p["own"] for p in parts]), ref["recon"])
+    for p in parts:
+        assert np.array_equal(p["dl"] == 0, ref["delta_recon"] == 0)
+        np.testing.assert_allclose(p["dl"], ref["delta_recon"], rtol=1e-4 if dt == np.float32 else 1e-12)

@@ -117,3 +117,48 @@ def test_slabs_reproduce_single_process(oracle, world, shape, dtype, bc, n_f, n_
     np.testing.assert_allclose(sums[:, 0], ref["b_norm64"], rtol=1e-12)
     np.testing.assert_allclose(sums[:, 1], ref["delta64"], rtol=1e-12)
     np.testing.assert_allclose(sums[:, 2], ref["rnorm64"], rtol=1e-12)
+
+
+def _worker_api(rank, world, port, shape, dtype_name, its, fista, stop, outdir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from slab_cpu_backend import OracleSlabBackend
+    from cytvdn_amd.distributed import denoise_slabs, slab_rows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dtype = np.dtype(dtype_name)
+        nd = len(shape)
+        full = synth.cube(shape, seed=14, dtype=dtype)
+        g0, g1 = slab_rows(shape, rank, world)
+        mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dtype)
+        n = sum(its) if isinstance(its, list) else its
+        fac = lambda lay: OracleSlabBackend(lay, dtype, fista or isinstance(its, list), max_iters=n)
+        own, bn, dl = denoise_slabs(full[g0:g1], shape, mu, its, FISTA=fista, stopping_relative_change=stop,
+                                    backend_factory=fac)
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), own=own, bn=bn, dl=dl)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,dtype,its,fista,stop", [
+    (2, (6, 5, 8, 12), "float32", 40, False, 0.02),       # global stopping criterion hit mid-run
+    (3, (7, 6, 16), "float64", [30, 6], True, 0.03),       # hybrid: FISTA phase stops early, plain phase still runs
+    (2, (6, 5, 8, 12), "float64", 9, True, None),
+], ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_denoise_slabs_api_matches_single_process(oracle, world, shape, dtype, its, fista, stop):
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker_api, args=(world, _free_port(), shape, dtype, its, fista, stop, tmp), nprocs=world, join=True)
+        parts = [np.load(os.path.join(tmp, f"r{r}.npz")) for r in range(world)]
+    x = synth.cube(shape, seed=14, dtype=dt)
+    mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
+    ref = oracle.denoise(x, mu, its, fista, stopping_relative_change=stop)
+    assert np.concatenate([p["own"] for p in parts]).tobytes() == ref["recon"].tobytes()
+    for p in parts:
+        assert np.array_equal(p["dl"] == 0, ref["delta_recon"] == 0)          # same iteration count on every rank
+        np.testing.assert_allclose(p["dl"], ref["delta_recon"], rtol=1e-4 if dt == np.float32 else 1e-12)
+        np.testing.assert_allclose(p["bn"], ref["b_norm"], rtol=1e-4 if dt == np.float32 else 1e-12)

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Config-5-style measurement on ONE GPU: a cube held in pinned host memory, advanced by the staged
+(out-of-core, temporally blocked) engine.  Reported separately from bench.py: this mode is PCIe-bound.
+
+    python tools/bench_outofcore.py --shape 128x256x128x128 --rows 64 --k 16 --iters 32
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="128x256x128x128")
+    ap.add_argument("--rows", type=int, default=64)
+    ap.add_argument("--k", type=int, default=16)
+    ap.add_argument("--iters", type=int, default=32)
+    ap.add_argument("--check", action="store_true", help="also run in-core and compare bit for bit")
+    a = ap.parse_args()
+    import numpy as np
+    import torch
+    from cytvdn_amd import _lib, synth
+    from cytvdn_amd.outofcore import StagedRunner
+    shape = tuple(int(v) for v in a.shape.split("x"))
+    nd = len(shape)
+    dt = np.dtype(np.float32)
+    _lib.ctx(0)
+    # synthesise on the device in slices, land in host memory
+    t0 = time.perf_counter()
+    x = np.empty(shape, dt)
+    step = max(1, (1 << 28) // int(np.prod(shape[1:])))
+    buf = torch.empty((step,) + shape[1:], dtype=torch.float32, device="cuda")
+    for r in range(0, shape[0], step):
+        n = min(step, shape[0] - r)
+        _lib.check(_lib.lib().tvdn_synth_fill(0, nd, _lib.shape_arr(shape), synth.SEED_4D if nd == 4 else synth.SEED_3D,
+                                              r, n, buf.data_ptr(), _lib.current_stream(0)))
+        x[r:r + n] = buf[:n].cpu().numpy()
+    t_syn = time.perf_counter() - t0
+    mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
+    lam = mu / dt.type(32.0 if nd == 4 else 16.0)
+    t0 = time.perf_counter()
+    sr = StagedRunner(x, True, 1.0 / lam, (lam / mu).astype(dt), device=0, block_rows=a.rows, k=a.k, max_iters=a.iters)
+    t_alloc = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sr.run(a.iters, 0)
+    torch.cuda.synchronize()
+    dt_run = time.perf_counter() - t0
+    vox = float(np.prod(shape))
+    out = {"metric": "Gvoxel-iters/s (4D aniso FISTA, out-of-core single GPU)", "value": round(vox * a.iters / dt_run / 1e9, 3),
+           "unit": "Gvoxel-iters/s", "shape": list(shape), "block_rows": a.rows, "iters_per_pass": a.k, "iters": a.iters,
+           "seconds": round(dt_run, 3), "h2d_GBps": round(sr.bytes_h2d / dt_run / 1e9, 1),
+           "d2h_GBps": round(sr.bytes_d2h / dt_run / 1e9, 1), "h2d_GB": round(sr.bytes_h2d / 1e9, 1),
+           "d2h_GB": round(sr.bytes_d2h / 1e9, 1), "synth_s": round(t_syn, 1), "pin_alloc_s": round(t_alloc, 1),
+           "b_norm_last": float(sr.sums()[a.iters - 1, 0])}
+    if a.check:
+        import cytvdn_amd as tv
+        want = tv.denoise4D(x, mu, a.iters, quiet=True)[0]
+        out["bit_identical_to_in_core"] = bool(want.tobytes() == sr.recon().tobytes())
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
