@@ -1,0 +1,135 @@
+"""Parity at BASELINE.json's full sizes (config 2/3 shape 256x256x128x128, config 1 shape), through
+size-independent properties:
+
+ * locality: after k iterations a voxel depends on the input within L1 distance 2k only, so a window of the
+   full-size result must equal, bit for bit, the oracle run on that window of the input enlarged by a 2k halo
+   (windows at cube corners use the true boundary on the sides that coincide with it);
+ * determinism: two runs give identical bits;
+ * representation independence: compact (d-rotation) and reference (b, d) state give identical bits;
+ * partition independence: 2 logical slabs == 1 slab at full size;
+ * scalar conservation: the per-slab sums add up to the single-slab sums (1e-12).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from golden_util import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+SHAPE = (256, 256, 128, 128)
+K = 3  # iterations
+
+
+def _sha(t):
+    return hashlib.sha1(t.cpu().numpy().tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def full_run():
+    """Config-2 input synthesised in HBM, K FISTA iterations in both state representations."""
+    import torch
+    from cytvdn_amd import _lib, synth
+    from cytvdn_amd.engine import HipBackend, SlabLayout, SlabRunner
+    assert torch.cuda.is_available()
+    dt = np.dtype(np.float32)
+    mu = np.array([1.0, 1.0, 0.5, 0.5], dt)
+    lam = mu / dt.type(32.0)
+    out = {}
+    for state in ("compact", "reference"):
+        lay = SlabLayout(SHAPE, 0, 1, 2)
+        be = HipBackend(lay, dt, True, device=0, max_iters=K, state=state)
+        be.set_params(1.0 / lam, (lam / mu).astype(dt))
+        _lib.check(_lib.lib().tvdn_synth_fill(be.code, 4, _lib.shape_arr(SHAPE), synth.SEED_4D, 0, SHAPE[0],
+                                              be.orig.data_ptr(), _lib.current_stream(0)))
+        be.recon[be.cur].copy_(be.orig)
+        SlabRunner(be).run(K, 0)
+        out[state] = dict(recon=be.recon_tensor().clone(), sums=be.sums.cpu().numpy().copy())
+        if state == "compact":
+            out["orig"] = be.orig.clone()
+        del be
+        torch.cuda.empty_cache()
+    out["mu"], out["lam"] = mu, lam
+    return out
+
+
+def test_state_representations_agree_at_full_size(full_run):
+    assert _sha(full_run["compact"]["recon"]) == _sha(full_run["reference"]["recon"])
+    np.testing.assert_allclose(full_run["compact"]["sums"], full_run["reference"]["sums"], rtol=1e-12)
+
+
+WINDOWS = [
+    # (start index per axis, extent per axis): corners, faces, interior
+    ((0, 0, 0, 0), (10, 9, 12, 16)),
+    ((246, 247, 116, 112), (10, 9, 12, 16)),
+    ((100, 0, 60, 112), (8, 8, 8, 16)),
+    ((0, 200, 0, 40), (7, 9, 10, 12)),
+    ((131, 77, 59, 64), (9, 8, 11, 12)),
+]
+
+
+@pytest.mark.parametrize("start,ext", WINDOWS, ids=lambda v: "-".join(map(str, v)))
+def test_locality_window_matches_oracle(oracle, full_run, start, ext):
+    halo = 2 * K
+    lo = [max(0, s - halo) for s in start]
+    hi = [min(n, s + e + halo) for s, e, n in zip(start, ext, SHAPE)]
+    sl = tuple(slice(a, b) for a, b in zip(lo, hi))
+    x = full_run["orig"][sl].cpu().numpy().copy()
+    ref = oracle.denoise(x, full_run["mu"], K, True)["recon"]
+    # inside the enlarged window, only voxels at least `halo` away from an ARTIFICIAL face are exact;
+    # faces that coincide with the true cube boundary are exact as they are
+    inner = tuple(slice(s - a, s - a + e) for s, a, e in zip(start, lo, ext))
+    got = full_run["compact"]["recon"][tuple(slice(s, s + e) for s, e in zip(start, ext))].cpu().numpy()
+    assert bits_equal(got, ref[inner])
+
+
+def test_determinism_and_two_slabs_at_full_size(full_run):
+    import torch
+    from cytvdn_amd import _lib, synth
+    from cytvdn_amd.engine import HipBackend, LocalSlabs, SlabLayout
+    dt = np.dtype(np.float32)
+    mu, lam = full_run["mu"], full_run["lam"]
+    bes = []
+    for r in range(2):
+        lay = SlabLayout(SHAPE, r, 2, 2)
+        be = HipBackend(lay, dt, True, device=0, max_iters=K)
+        be.set_params(1.0 / lam, (lam / mu).astype(dt))
+        _lib.check(_lib.lib().tvdn_synth_fill(be.code, 4, _lib.shape_arr(SHAPE), synth.SEED_4D, lay.g0 - lay.halo_lo,
+                                              lay.local_shape[0], be.orig.data_ptr(), _lib.current_stream(0)))
+        be.recon[be.cur].copy_(be.orig)
+        bes.append(be)
+    grp = LocalSlabs(bes, split_sweeps=True)
+    grp.run(K, 0)
+    recon = grp.gather_recon()
+    assert _sha(recon) == _sha(full_run["compact"]["recon"])       # same bits as the single slab, run earlier
+    np.testing.assert_allclose(grp.global_sums().cpu().numpy(), full_run["compact"]["sums"], rtol=1e-12)
+    del grp, bes, recon
+    torch.cuda.empty_cache()
+
+
+def test_config3_f64_plain_locality(oracle):
+    """Config 3 (float64, unaccelerated) at full size: one window against the oracle."""
+    import torch
+    from cytvdn_amd import _lib, synth
+    from cytvdn_amd.engine import HipBackend, SlabLayout, SlabRunner
+    dt = np.dtype(np.float64)
+    mu = np.array([1.0, 1.0, 0.5, 0.5], dt)
+    lam = mu / 32.0
+    be = HipBackend(SlabLayout(SHAPE, 0, 1, 2), dt, False, device=0, max_iters=K)
+    be.set_params(1.0 / lam, lam / mu)
+    _lib.check(_lib.lib().tvdn_synth_fill(be.code, 4, _lib.shape_arr(SHAPE), synth.SEED_4D, 0, SHAPE[0],
+                                          be.orig.data_ptr(), _lib.current_stream(0)))
+    be.recon[be.cur].copy_(be.orig)
+    SlabRunner(be).run(0, K)
+    start, ext = (250, 3, 120, 0), (6, 8, 8, 16)
+    halo = 2 * K
+    lo = [max(0, s - halo) for s in start]
+    hi = [min(n, s + e + halo) for s, e, n in zip(start, ext, SHAPE)]
+    x = be.orig[tuple(slice(a, b) for a, b in zip(lo, hi))].cpu().numpy().copy()
+    ref = oracle.denoise(x, mu, K, False)["recon"]
+    inner = tuple(slice(s - a, s - a + e) for s, a, e in zip(start, lo, ext))
+    got = be.recon_tensor()[tuple(slice(s, s + e) for s, e in zip(start, ext))].cpu().numpy()
+    assert bits_equal(got, ref[inner])
+    del be
+    torch.cuda.empty_cache()
