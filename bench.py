@@ -129,6 +129,11 @@ def main():
     import torch
     import torch.distributed as dist
     from cytvdn_amd import _lib, synth
+    if not os.path.exists(_lib.LIB_PATH):       # fresh checkout: compile the HIP library in-tree (hipcc, ~20 s)
+        if rank == 0:
+            _lib.build()
+        while not os.path.exists(_lib.LIB_PATH):
+            time.sleep(1.0)
     from cytvdn_amd.engine import HipBackend, SlabLayout, SlabRunner, fista_ratios
 
     if not torch.cuda.is_available():
