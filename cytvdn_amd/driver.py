@@ -24,7 +24,6 @@ from typing import Optional, Tuple
 import numpy as np
 import torch
 
-from . import _lib
 from .engine import HipBackend, SlabLayout, SlabRunner, hbm_plan
 
 try:  # tqdm is what upstream shows (cyTVDN.py:148-152); it is optional here

@@ -1,0 +1,73 @@
+"""Randomised parity (hypothesis): arbitrary small shapes, dtypes, schedules, boundary conditions and
+parameter scales through the fused HIP sweep and the one-pass kernels, against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from golden_util import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+dims4 = st.tuples(st.integers(1, 9), st.integers(1, 6), st.integers(1, 7), st.sampled_from([1, 2, 3, 4, 5, 8, 12, 16, 20]))
+dims3 = st.tuples(st.integers(1, 12), st.integers(1, 9), st.sampled_from([1, 2, 4, 6, 7, 8, 16, 24, 36]))
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(shape=st.one_of(dims4, dims3), f64=st.booleans(), bc=st.sampled_from([0, 2]),
+       sched=st.sampled_from(["fista", "plain", "hybrid"]), seed=st.integers(0, 2 ** 31 - 1),
+       scale=st.sampled_from([1e-3, 1.0, 37.0]), lam_div=st.sampled_from([None, 40.0, 333.0]))
+def test_fused_loop_random(oracle, shape, f64, bc, sched, seed, scale, lam_div):
+    import cytvdn_amd as tv
+    dt = np.dtype(np.float64 if f64 else np.float32)
+    nd = len(shape)
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(shape) * scale + rng.poisson(3.0, shape)).astype(dt)
+    mu = (np.array([1.0, 0.7, 0.5, 1.3][:nd]) * scale).astype(dt)
+    lam = None if lam_div is None else (mu / dt.type(lam_div)).astype(dt)
+    its = {"fista": 5, "plain": 4, "hybrid": [3, 2]}[sched]
+    fista = sched != "plain"
+    fn = tv.denoise4D if nd == 4 else tv.denoise3D
+    got = fn(x, mu, its, FISTA=fista, BC_mode=bc, lam=lam, quiet=True)
+    ref = oracle.denoise(x, mu, its, fista, BC_mode=bc, lam=lam)
+    assert bits_equal(got[0], ref["recon"])
+    tol = 1e-6 if dt == np.float32 else 1e-12
+    np.testing.assert_allclose(got[1].astype(np.float64), ref["b_norm64"].astype(dt).astype(np.float64), rtol=tol)
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(shape=st.one_of(dims4, dims3), f64=st.booleans(), bc=st.sampled_from([0, 1, 2]), fista=st.booleans(),
+       seed=st.integers(0, 2 ** 31 - 1), data=st.data())
+def test_one_pass_kernels_random(oracle, shape, f64, bc, fista, seed, data):
+    import cytvdn_amd as tv
+    dt = np.dtype(np.float64 if f64 else np.float32)
+    nd = len(shape)
+    ax = data.draw(st.integers(0, nd - 1))
+    if bc == 1 and shape[ax] < 2:
+        bc = 2
+    rng = np.random.default_rng(seed)
+    a = (rng.standard_normal(shape) * 3).astype(dt)
+    b = (rng.standard_normal(shape) * 0.7).astype(dt)
+    d = (rng.standard_normal(shape) * 0.7).astype(dt)
+    if data.draw(st.booleans()):
+        a.flat[int(rng.integers(a.size))] = np.inf       # non-finite input propagates as upstream
+    b2, d2 = b.copy(), d.copy()
+    clip, tk = dt.type(0.8), dt.type(0.41)
+    suffix = f"{nd}D_FISTA" if fista else f"{nd}D"
+    if fista:
+        ret = getattr(tv, "accumulator_update_" + suffix)(a, b, d, tk, ax, clip, BC_mode=bc)
+        _, n64 = oracle.acc_update(a, b2, d2, tk, ax, clip, bc)
+        assert bits_equal(d, d2)
+    else:
+        ret = getattr(tv, "accumulator_update_" + suffix)(a, b, ax, clip, BC_mode=bc)
+        _, n64 = oracle.acc_update(a, b2, None, 0.0, ax, clip, bc)
+    assert bits_equal(b, b2)
+    assert (np.isnan(ret) and np.isnan(n64)) or ret == pytest.approx(n64, rel=1e-12)
+    if bc != 1:
+        orig = (rng.standard_normal(shape) * 3).astype(dt)
+        recon = (rng.standard_normal(shape) * 3).astype(dt)
+        bs = [(rng.standard_normal(shape) * 0.7).astype(dt) for _ in range(nd)]
+        lm = (np.array([1 / 32, 1 / 40, 1 / 64, 1 / 33][:nd])).astype(dt)
+        r2 = recon.copy()
+        getattr(tv, f"datacube_update_{nd}D")(orig, recon, *bs, lm, BC_mode=bc)
+        oracle.recon_update(orig, r2, bs, lm, bc)
+        assert bits_equal(recon, r2)

@@ -12,7 +12,6 @@ import tempfile
 
 import numpy as np
 import pytest
-import torch
 import torch.multiprocessing as mp
 
 from cytvdn_amd import _lib, synth
