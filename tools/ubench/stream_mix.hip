@@ -92,7 +92,11 @@ int main()
     run<10, 9, false>("mix span 8192", p, n4, 0, 8192);
     run<10, 9, false>("mix span 65536", p, n4, 0, 65536);
     run<10, 9, true>("mix nt span 8192", p, n4, 0, 8192);
-    run<10, 0, false>("read only x10", p, n4, 256 * 8, 0);
+    run<10, 5, false>("10R 5W gridstride 8192", p, n4, 256 * 32, 0);
+    run<10, 5, false>("10R 5W one-elem-per-thread", p, n4, (int)(n4 / 256), 0);
+    run<10, 5, true>("10R 5W nt one-elem-per-thread", p, n4, (int)(n4 / 256), 0);
+    run<10, 5, false>("10R 5W span 8192", p, n4, 0, 8192);
+    run<6, 5, false>("6R 5W one-elem-per-thread", p, n4, (int)(n4 / 256), 0);
     run<1, 9, false>("1R 9W", p, n4, 256 * 8, 0);
     run<5, 5, false>("5R 5W", p, n4, 256 * 8, 0);
     return 0;
