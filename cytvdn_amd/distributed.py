@@ -23,10 +23,14 @@ def slab_rows(global_shape, rank: int, world: int, bc_mode: int = 2):
 
 
 def denoise_slabs(my_rows, global_shape, mu, iterations=10, FISTA=True, stopping_relative_change=None,
-                  BC_mode=2, lam=None, group=None, device=None, backend_factory=None):
+                  BC_mode=2, lam=None, group=None, device=None, backend_factory=None, staged=None):
     """Slab-parallel denoise3D/denoise4D.  Returns (own rows of recon, b_norm, delta_recon); the traces
     are global (all-reduced) and identical on every rank.  Semantics of `iterations` ([nF, nU] hybrid),
-    `lam` defaults and the stopping rule follow cyTVDN/cyTVDN.py:67-68 / :294-295, :99-108, :189-195."""
+    `lam` defaults and the stopping rule follow cyTVDN/cyTVDN.py:67-68 / :294-295, :99-108, :189-195.
+
+    `staged=(block_rows, k)` keeps each rank's slab in pinned host memory and streams it through the GPU in
+    blocks, k iterations per visit (cytvdn_amd/outofcore.py): for cubes whose state exceeds the HBM of the
+    GPUs at hand (BASELINE config 5).  Without it the slab must fit in HBM."""
     import torch.distributed as dist
     if not dist.is_initialized():
         raise RuntimeError("initialise torch.distributed first (backend 'nccl' = RCCL on ROCm)")
@@ -57,6 +61,9 @@ def denoise_slabs(my_rows, global_shape, mu, iterations=10, FISTA=True, stopping
     n = n_f + n_p
     if device is None:
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if staged is not None:
+        return _denoise_slabs_staged(my_rows, lay, dtype, mu, lam, FISTA, unacc, n_f, n_p, stopping_relative_change,
+                                     group, device, staged, rank, world)
     be = (backend_factory or (lambda l: HipBackend(l, dtype, FISTA, device=device, max_iters=n)))(lay)
     be.set_params(1.0 / lam, (lam / mu).astype(dtype))
     # own rows in, halo rows from the neighbours
@@ -90,6 +97,39 @@ def denoise_slabs(my_rows, global_shape, mu, iterations=10, FISTA=True, stopping
         delta = np.where(ran, sums[:, 1].astype(dtype) / sums[:, 2].astype(dtype), dt(0)).astype(dtype)
     own = be.recon_tensor()[lay.row_lo:lay.row_hi]
     return (own if is_t and my_rows.is_cuda else own.cpu().numpy()), b_norm, delta
+
+
+def _denoise_slabs_staged(my_rows, lay, dtype, mu, lam, FISTA, unacc, n_f, n_p, stop, group, device, staged, rank, world):
+    from .outofcore import StagedRunner
+    rows, k = int(staged[0]), int(staged[1])
+    if stop is not None:
+        k = 1
+    n = n_f + n_p
+    own = my_rows.cpu().numpy() if isinstance(my_rows, torch.Tensor) else np.ascontiguousarray(my_rows)
+    sr = StagedRunner(own, FISTA, 1.0 / lam, (lam / mu).astype(dtype), bc_mode=lay.bc_mode, device=device,
+                      block_rows=rows, k=min(k, lay.own_rows), max_iters=n, global_rows=lay.shape[0], row0=lay.g0,
+                      group=group, world=world, rank=rank)
+    ran = np.zeros(n, dtype=bool)
+    dt = dtype.type
+
+    def on_ss(first, count):
+        ran[first:first + count] = True
+        if stop is None:
+            return False
+        sm = sr.sums()[first]                     # all-reduced: the same decision on every rank
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return bool(dt(dt(sm[1]) / dt(sm[2])) < stop)
+
+    if FISTA and n_f:
+        sr.run(n_f, 0, on_ss)
+        sr.iters_done = n_f
+    if unacc and n_p:
+        sr.run(0, n_p, on_ss)
+    sums = sr.sums()[:n]
+    b_norm = np.where(ran, sums[:, 0], 0.0).astype(dtype)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        delta = np.where(ran, sums[:, 1].astype(dtype) / sums[:, 2].astype(dtype), dt(0)).astype(dtype)
+    return sr.recon(), b_norm, delta
 
 
 __all__ = ["denoise_slabs", "slab_rows"]

@@ -40,35 +40,53 @@ def plan_blocks(n_rows: int, block_rows: int):
 
 
 class StagedRunner:
-    """Runs the denoise loop on a host-resident cube through two staging buffers on one GPU."""
+    """Runs the denoise loop on a host-resident cube (or, with `world` > 1, on this rank's slab of it)
+    through two staging buffers on one GPU.
+
+    Slab mode: `datacube` holds this rank's own rows [row0, row0+rows) of a cube with `global_rows` rows;
+    the host arrays carry up to `k` extra rows per interior side, refreshed from the neighbouring ranks
+    before every pass (k rows of recon and of every accumulator-state array: a temporally blocked pass needs
+    the neighbours' full state k rows deep, against one row of recon per iteration for the in-core engine)."""
 
     def __init__(self, datacube: np.ndarray, fista: bool, clip, lam_mu, bc_mode: int = 2, device: int = 0,
                  block_rows: int = 32, k: int = 8, max_iters: int = 1, reference: np.ndarray = None,
-                 pin: bool = True):
+                 pin: bool = True, global_rows: int = None, row0: int = 0, group=None, world: int = 1, rank: int = 0):
         if bc_mode != 2:
             raise NotImplementedError("the staged engine supports the Jia-Zhao boundary condition (BC_mode=2) only")
-        self.shape = tuple(int(s) for s in datacube.shape)
-        self.nd = len(self.shape)
+        own_shape = tuple(int(s) for s in datacube.shape)
+        self.nd = len(own_shape)
         self.dtype = datacube.dtype
         self.fista = bool(fista)
         self.device = int(device)
         self.k = max(1, int(k))
-        self.blocks = plan_blocks(self.shape[0], block_rows)
+        self.N0 = int(own_shape[0] if global_rows is None else global_rows)
+        self.row0, self.own = int(row0), own_shape[0]
+        self.world, self.rank, self.group = int(world), int(rank), group
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if self.own < self.k:
+                raise ValueError(f"a slab needs at least k = {self.k} rows (it has {self.own})")
+        self.ext_lo = min(self.k, self.row0) if self.world > 1 else 0
+        self.ext_hi = min(self.k, self.N0 - (self.row0 + self.own)) if self.world > 1 else 0
+        self.base = self.row0 - self.ext_lo                 # global index of host row 0
+        self.shape = (self.ext_lo + self.own + self.ext_hi,) + own_shape[1:]
+        self.blocks = [(self.row0 + a, self.row0 + b) for a, b in plan_blocks(self.own, block_rows)]
         self.max_iters = max(1, int(max_iters))
         tdt = torch.float32 if self.dtype == np.float32 else torch.float64
         plane = self.shape[1:]
+        own_sl = slice(self.ext_lo, self.ext_lo + self.own)
 
         def host(fill=None):
             t = torch.empty(self.shape, dtype=tdt, pin_memory=pin)
-            if fill is None:
-                t.zero_()
-            else:
-                t.copy_(torch.from_numpy(fill))
+            t.zero_()
+            if fill is not None:
+                t[own_sl].copy_(torch.from_numpy(fill))
             return t
 
         # host state: orig, recon old/new, per axis up to two state arrays old/new
         self.orig_h = host(np.ascontiguousarray(datacube))
-        self.recon_h = [self.orig_h.clone().pin_memory() if pin else self.orig_h.clone(), host()]
+        self.recon_h = [host(np.ascontiguousarray(datacube)), host()]
         n_state = 2 if self.fista else 1
         self.state_h = [[[host() for _ in range(n_state)] for _ in range(self.nd)] for _ in range(2)]  # [old/new][axis][j]
         self.ref_h = host(np.ascontiguousarray(reference)) if reference is not None else None
@@ -76,6 +94,9 @@ class StagedRunner:
         self.d_form = self.fista
         self.tk_prev = 0.0
         self.iters_done = 0
+        self._xbuf = None
+        if self.world > 1:
+            self._exchange([self.orig_h], self.k)           # the input's halo rows never change
 
         max_rows = min(self.shape[0], max(g1 - g0 for g0, g1 in self.blocks) + 2 * self.k)
         self.stages = []
@@ -95,10 +116,45 @@ class StagedRunner:
             with torch.cuda.stream(be.stream):
                 for g0, g1 in self.blocks:
                     n = g1 - g0
-                    be.orig[:n].copy_(self.orig_h[g0:g1], non_blocking=True)
-                    be.ref[:n].copy_(self.ref_h[g0:g1], non_blocking=True)
+                    be.orig[:n].copy_(self.orig_h[g0 - self.base:g1 - self.base], non_blocking=True)
+                    be.ref[:n].copy_(self.ref_h[g0 - self.base:g1 - self.base], non_blocking=True)
                     self._sse(be, be.orig[:n], be.ref[:n], 0)
             be.stream.synchronize()
+
+    # ---- slab mode: refresh the halo rows of host arrays from the neighbouring ranks ------------------------
+    def _exchange(self, arrays, depth):
+        """For every host array: my lowest/highest `depth` own rows go to the left/right neighbour's halo
+        rows, theirs come into mine.  gloo moves host memory directly; RCCL stages the rows through HBM."""
+        dist = self.dist
+        lo, hi = self.ext_lo, self.ext_lo + self.own
+        left = self.rank - 1 if self.rank > 0 else None
+        right = self.rank + 1 if self.rank < self.world - 1 else None
+        dl, dh = min(depth, self.ext_lo), min(depth, self.ext_hi)
+        via_dev = dist.get_backend(self.group) != "gloo"
+        peer = (lambda r: r) if self.group is None else (lambda r: dist.get_global_rank(self.group, r))
+        ops, post = [], []
+        for i, t in enumerate(arrays):
+            def snd(view):
+                return view.to(torch.device("cuda", self.device), non_blocking=False) if via_dev else view.contiguous()
+
+            def rcv(view):
+                buf = torch.empty(view.shape, dtype=view.dtype, device=torch.device("cuda", self.device)) if via_dev else view
+                if via_dev:
+                    post.append((view, buf))
+                return buf
+            # the neighbour's halo is as deep as MY own rows allow it to ask for: both sides use min(depth, k)
+            if left is not None:
+                ops.append(dist.P2POp(dist.isend, snd(t[lo:lo + depth]), peer(left), self.group, tag=4 * i + 1))
+            if right is not None:
+                ops.append(dist.P2POp(dist.isend, snd(t[hi - depth:hi]), peer(right), self.group, tag=4 * i + 2))
+                ops.append(dist.P2POp(dist.irecv, rcv(t[hi:hi + dh]), peer(right), self.group, tag=4 * i + 1))
+            if left is not None:
+                ops.append(dist.P2POp(dist.irecv, rcv(t[lo - dl:lo]), peer(left), self.group, tag=4 * i + 2))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for view, buf in post:
+            view.copy_(buf)
 
     def _sse(self, be, a, b, slot):
         _lib.check(_lib.lib().tvdn_sum_square_error(be.ctx, be.code, self.nd, _lib.shape_arr(a.shape), a.data_ptr(),
@@ -108,8 +164,11 @@ class StagedRunner:
     # one super-step: `ratios` holds the tk ratio of each iteration (None = unaccelerated)
     def _superstep(self, ratios, slot0):
         kk = len(ratios)
-        N0 = self.shape[0]
+        N0, base = self.N0, self.base
         old, new = self.h_old, self.h_old ^ 1
+        if self.world > 1:  # neighbours' rows of the current state, kk deep
+            arrays = [self.recon_h[old]] + [t for q in range(self.nd) for t in self.state_h[old][q][: (2 if self.d_form else 1)]]
+            self._exchange(arrays, kk)
         discard = self.max_iters                      # sums row nobody reads
         form_after = tk_after = None
         for bi, (g0, g1) in enumerate(self.blocks):
@@ -122,15 +181,16 @@ class StagedRunner:
                 be.set_block(rows, _lib.EDGE_BC if (whole or not hi_edge) else _lib.EDGE_ZERO)
                 be.set_form(self.d_form, self.tk_prev)
                 # ---- upload the block with its halo rows --------------------------------------------
-                be.orig[:rows].copy_(self.orig_h[s0:s1], non_blocking=True)
-                be.recon[be.cur][:rows].copy_(self.recon_h[old][s0:s1], non_blocking=True)
+                h0, h1 = s0 - base, s1 - base            # the staged rows inside the host arrays
+                be.orig[:rows].copy_(self.orig_h[h0:h1], non_blocking=True)
+                be.recon[be.cur][:rows].copy_(self.recon_h[old][h0:h1], non_blocking=True)
                 n_up = 2
                 for q, arrs in enumerate(be.state_tensors()):
                     for j, t in enumerate(arrs):
-                        t[:rows].copy_(self.state_h[old][q][j][s0:s1], non_blocking=True)
+                        t[:rows].copy_(self.state_h[old][q][j][h0:h1], non_blocking=True)
                         n_up += 1
                 if self.ref_h is not None:
-                    be.ref[:g1 - g0].copy_(self.ref_h[g0:g1], non_blocking=True)
+                    be.ref[:g1 - g0].copy_(self.ref_h[g0 - base:g1 - base], non_blocking=True)
                     self.bytes_h2d += (g1 - g0) * self._row_bytes()
                 self.bytes_h2d += n_up * rows * self._row_bytes()
                 # ---- k iterations on a shrinking range of rows ----------------------------------------
@@ -151,12 +211,12 @@ class StagedRunner:
                     if self.ref_h is not None:
                         self._sse(be, be.ref[:o1 - o0], be.recon_tensor()[o0:o1], slot + 1)
                 # ---- download the own rows ----------------------------------------------------------------
-                self.recon_h[new][g0:g1].copy_(be.recon_tensor()[o0:o1], non_blocking=True)
+                self.recon_h[new][g0 - base:g1 - base].copy_(be.recon_tensor()[o0:o1], non_blocking=True)
                 n_down = 1
                 st = be.state_tensors()
                 for q, arrs in enumerate(st):
                     for j, t in enumerate(arrs):
-                        self.state_h[new][q][j][g0:g1].copy_(t[o0:o1], non_blocking=True)
+                        self.state_h[new][q][j][g0 - base:g1 - base].copy_(t[o0:o1], non_blocking=True)
                         n_down += 1
                 self.bytes_d2h += n_down * (g1 - g0) * self._row_bytes()
                 form_after, tk_after = be.d_form, be.tk_prev
@@ -190,16 +250,24 @@ class StagedRunner:
             if on_superstep is not None and on_superstep(slot + j - n, n):
                 break
 
+    def _allreduce(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world > 1:
+            t = t if self.dist.get_backend(self.group) != "gloo" else t.cpu()
+            self.dist.all_reduce(t, group=self.group)
+        return t
+
     def sums(self) -> np.ndarray:
-        """[max_iters, 3] f64: b_norm, sum|delta|, sum|old| per iteration, summed over the blocks."""
+        """[max_iters, 3] f64: b_norm, sum|delta|, sum|old| per iteration, summed over the blocks (and, in
+        slab mode, over the ranks)."""
         t = sum(be.sums[: self.max_iters] for be in self.stages)
-        return t.cpu().numpy()
+        return self._allreduce(t.clone()).cpu().numpy()
 
     def mse(self) -> np.ndarray:
-        return sum(be.mse for be in self.stages).cpu().numpy()
+        return self._allreduce(sum(be.mse for be in self.stages).clone()).cpu().numpy()
 
     def recon(self) -> np.ndarray:
-        return self.recon_h[self.h_old].numpy().copy()
+        """This rank's own rows of the current reconstruction."""
+        return self.recon_h[self.h_old][self.ext_lo:self.ext_lo + self.own].numpy().copy()
 
 
 __all__ = ["StagedRunner", "plan_blocks"]

@@ -73,7 +73,7 @@ def test_two_rank_processes_on_one_gpu(oracle, world, shape, dtype, bc, n_f, n_p
     np.testing.assert_allclose(parts[0]["sums"][:, 1], ref["delta64"], rtol=1e-12)
 
 
-def _worker_api(rank, world, port, shape, dtype_name, its, fista, stop, outdir):
+def _worker_api(rank, world, port, shape, dtype_name, its, fista, stop, outdir, staged=None):
     import torch
     import torch.distributed as dist
     from cytvdn_amd import synth
@@ -88,7 +88,8 @@ def _worker_api(rank, world, port, shape, dtype_name, its, fista, stop, outdir):
         full = synth.cube(shape, seed=14, dtype=dt)
         g0, g1 = slab_rows(shape, rank, world)
         mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
-        own, bn, dl = denoise_slabs(full[g0:g1], shape, mu, its, FISTA=fista, stopping_relative_change=stop, device=0)
+        own, bn, dl = denoise_slabs(full[g0:g1], shape, mu, its, FISTA=fista, stopping_relative_change=stop, device=0,
+                                    staged=staged)
         np.savez(os.path.join(outdir, f"r{rank}.npz"), own=own, bn=bn, dl=dl)
     finally:
         dist.destroy_process_group()
@@ -115,3 +116,29 @@ def test_denoise_slabs_on_gpu_matches_single_process(oracle, world, shape, dtype
     for p in parts:
         assert np.array_equal(p["dl"] == 0, ref["delta_recon"] == 0)
         np.testing.assert_allclose(p["dl"], ref["delta_recon"], rtol=1e-4 if dt == np.float32 else 1e-12)
+
+
+@pytest.mark.parametrize("world,shape,dtype,its,fista,stop,staged", [
+    (2, (20, 3, 4, 8), "float32", 9, True, None, (4, 3)),        # several blocks per rank, k = 3 halo rows between ranks
+    (3, (19, 6, 16), "float64", [5, 4], True, None, (3, 4)),      # hybrid schedule, uneven slabs
+    (2, (12, 5, 8, 12), "float32", [30, 6], True, 0.03, (5, 8)),  # global stopping rule (forces k = 1)
+], ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_staged_slabs_match_single_process(oracle, world, shape, dtype, its, fista, stop, staged):
+    """BASELINE config 5 in miniature: every rank keeps its slab in host memory and streams it through the
+    GPU with temporal blocking; ranks swap k rows of state per pass.  Bit-identical to one process."""
+    import torch.multiprocessing as mp
+    from cytvdn_amd import synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.start_processes(_worker_api, args=(world, _free_port(), shape, dtype, its, fista, stop, tmp, staged),
+                           nprocs=world, join=True, start_method="spawn")
+        parts = [np.load(os.path.join(tmp, f"r{r}.npz")) for r in range(world)]
+    x = synth.cube(shape, seed=14, dtype=dt)
+    mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
+    ref = oracle.denoise(x, mu, its, fista, stopping_relative_change=stop)
+    assert bits_equal(np.concatenate([p["own"] for p in parts]), ref["recon"])
+    for p in parts:
+        assert np.array_equal(p["dl"] == 0, ref["delta_recon"] == 0)
+        np.testing.assert_allclose(p["dl"], ref["delta_recon"], rtol=1e-4 if dt == np.float32 else 1e-12)
+        np.testing.assert_allclose(p["bn"], ref["b_norm"], rtol=1e-4 if dt == np.float32 else 1e-12)
