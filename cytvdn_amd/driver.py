@@ -160,12 +160,15 @@ def _staging_plan(datacube, FISTA, BC_mode, device, stop):
         fr = _hbm_free(device)
         if fr is None or n_arr * datacube.nbytes < 0.9 * fr[0]:
             return None
-        # two staging buffers of (rows + 2k) rows each must fit in 80 % of the free HBM
-        k = 16
-        rows = int(0.8 * fr[0] / (2 * (n_arr + 1) * plane_bytes)) - 2 * k
-        if rows < 1:
-            k = 1
-            rows = max(1, int(0.8 * fr[0] / (2 * (n_arr + 1) * plane_bytes)) - 2)
+        # three staging buffers of (rows + 2k) rows each must fit in 80 % of the free HBM; deep temporal
+        # blocking is what makes the mode worth using (measured: k 16 -> 9, k 32 -> 21, k 64 -> 29 Gvoxel-iters/s)
+        per_row = 3 * (n_arr + 1) * plane_bytes
+        k = 64
+        rows = int(0.8 * fr[0] / per_row) - 2 * k
+        while rows < k and k > 1:
+            k //= 2
+            rows = int(0.8 * fr[0] / per_row) - 2 * k
+        rows = max(1, rows)
     if stop is not None:
         k = 1      # the stopping test is per iteration (cyTVDN.py:189-194): no temporal blocking then
     if BC_mode != 2:

@@ -41,7 +41,7 @@ def plan_blocks(n_rows: int, block_rows: int):
 
 class StagedRunner:
     """Runs the denoise loop on a host-resident cube (or, with `world` > 1, on this rank's slab of it)
-    through two staging buffers on one GPU.
+    through a few staging buffers on one GPU.
 
     Slab mode: `datacube` holds this rank's own rows [row0, row0+rows) of a cube with `global_rows` rows;
     the host arrays carry up to `k` extra rows per interior side, refreshed from the neighbouring ranks
@@ -50,7 +50,8 @@ class StagedRunner:
 
     def __init__(self, datacube: np.ndarray, fista: bool, clip, lam_mu, bc_mode: int = 2, device: int = 0,
                  block_rows: int = 32, k: int = 8, max_iters: int = 1, reference: np.ndarray = None,
-                 pin: bool = True, global_rows: int = None, row0: int = 0, group=None, world: int = 1, rank: int = 0):
+                 pin: bool = True, global_rows: int = None, row0: int = 0, group=None, world: int = 1, rank: int = 0,
+                 n_stages: int = 3):
         if bc_mode != 2:
             raise NotImplementedError("the staged engine supports the Jia-Zhao boundary condition (BC_mode=2) only")
         own_shape = tuple(int(s) for s in datacube.shape)
@@ -94,13 +95,13 @@ class StagedRunner:
         self.d_form = self.fista
         self.tk_prev = 0.0
         self.iters_done = 0
-        self._xbuf = None
+        self._carry_buf = None
         if self.world > 1:
             self._exchange([self.orig_h], self.k)           # the input's halo rows never change
 
         max_rows = min(self.shape[0], max(g1 - g0 for g0, g1 in self.blocks) + 2 * self.k)
         self.stages = []
-        for _ in range(2):
+        for _ in range(max(2, int(n_stages))):
             be = HipBackend(_BlockLayout(max_rows, plane, bc_mode), self.dtype, self.fista, device=self.device,
                             max_iters=self.max_iters + 1, private_ctx=True)       # last sums row: discard slot
             be.set_params(clip, lam_mu)
@@ -171,8 +172,9 @@ class StagedRunner:
             self._exchange(arrays, kk)
         discard = self.max_iters                      # sums row nobody reads
         form_after = tk_after = None
+        prev = None                                   # (s0, s1, carry-ready event, first carried row) of the previous block
         for bi, (g0, g1) in enumerate(self.blocks):
-            be = self.stages[bi % 2]
+            be = self.stages[bi % len(self.stages)]
             s0, s1 = max(0, g0 - kk), min(N0, g1 + kk)
             rows = s1 - s0
             lo_edge, hi_edge = (s0 == 0), (s1 == N0)
@@ -180,19 +182,35 @@ class StagedRunner:
             with torch.cuda.stream(be.stream):
                 be.set_block(rows, _lib.EDGE_BC if (whole or not hi_edge) else _lib.EDGE_ZERO)
                 be.set_form(self.d_form, self.tk_prev)
-                # ---- upload the block with its halo rows --------------------------------------------
+                # ---- bring in the block with its halo rows ------------------------------------------------
+                # Rows it shares with the previous block (that block's top 2k rows, still at the state of the
+                # pass start there) are forwarded device-to-device through a small carry buffer instead of
+                # crossing PCIe twice; only the rest is uploaded.
                 h0, h1 = s0 - base, s1 - base            # the staged rows inside the host arrays
-                be.orig[:rows].copy_(self.orig_h[h0:h1], non_blocking=True)
-                be.recon[be.cur][:rows].copy_(self.recon_h[old][h0:h1], non_blocking=True)
-                n_up = 2
-                for q, arrs in enumerate(be.state_tensors()):
-                    for j, t in enumerate(arrs):
-                        t[:rows].copy_(self.state_h[old][q][j][h0:h1], non_blocking=True)
-                        n_up += 1
+                ov = 0                                   # leading rows that come from the carry buffer
+                if prev is not None and prev[1] > s0:
+                    ov = min(prev[1], s1) - s0
+                dst = [be.orig, be.recon[be.cur]] + [t for arrs in be.state_tensors() for t in arrs]
+                src_h = [self.orig_h, self.recon_h[old]] + [self.state_h[old][q][j] for q, arrs in
+                                                            enumerate(be.state_tensors()) for j in range(len(arrs))]
+                for t, hsrc in zip(dst, src_h):
+                    t[ov:rows].copy_(hsrc[h0 + ov:h1], non_blocking=True)
+                self.bytes_h2d += len(dst) * (rows - ov) * self._row_bytes()
+                if ov:
+                    be.stream.wait_event(prev[2])
+                    c_off = s0 - prev[3]                 # where row s0 sits inside the carry buffer
+                    for t, c in zip(dst, self._carry(len(dst), be)):
+                        t[:ov].copy_(c[c_off:c_off + ov], non_blocking=True)
                 if self.ref_h is not None:
                     be.ref[:g1 - g0].copy_(self.ref_h[g0 - base:g1 - base], non_blocking=True)
                     self.bytes_h2d += (g1 - g0) * self._row_bytes()
-                self.bytes_h2d += n_up * rows * self._row_bytes()
+                if bi + 1 < len(self.blocks):            # my top rows, untouched yet, for the next block
+                    c0 = max(s0, s1 - 2 * kk)
+                    for t, c in zip(dst, self._carry(len(dst), be)):
+                        c[:s1 - c0].copy_(t[c0 - s0:rows], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(be.stream)
+                    prev = (s0, s1, ev, c0)
                 # ---- k iterations on a shrinking range of rows ----------------------------------------
                 v0, v1 = 0, rows                      # rows whose state is current
                 o0, o1 = g0 - s0, g1 - s0             # own rows, local
@@ -225,6 +243,14 @@ class StagedRunner:
         self.h_old = new
         self.d_form, self.tk_prev = form_after, tk_after
         self.iters_done += kk
+
+    def _carry(self, n_arrays, be):
+        """Device buffer of 2k rows per staged array, handed from one block to the next."""
+        if self._carry_buf is None or len(self._carry_buf) < n_arrays:
+            rows = min(2 * self.k, be.orig.shape[0])
+            self._carry_buf = [torch.empty((rows,) + tuple(be.orig.shape[1:]), dtype=be.orig.dtype, device=be.orig.device)
+                               for _ in range(1 + 1 + 2 * self.nd)]
+        return self._carry_buf[:n_arrays]
 
     def _row_bytes(self):
         return int(np.prod(self.shape[1:])) * self.dtype.itemsize
