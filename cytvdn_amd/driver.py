@@ -80,6 +80,10 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
 
     if device is None:
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    wf = os.environ.get("TVDN_WAVEFRONT")
+    if wf and stopping_relative_change is None and reference_data is None and BC_mode == 2:
+        return _run_wavefront(tuple(int(v) for v in wf.split(",")), datacube, lambdaInv, lam_mu, FISTA, unaccelerated,
+                              n_fista, n_plain, device)
     staged = _staging_plan(datacube, FISTA, BC_mode, device, stopping_relative_change)
     if staged is not None:
         return _run_staged(staged, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain,
@@ -174,6 +178,21 @@ def _staging_plan(datacube, FISTA, BC_mode, device, stop):
     if BC_mode != 2:
         raise NotImplementedError("a cube that needs staging through host memory supports BC_mode=2 only")
     return max(1, rows), max(1, k)
+
+
+def _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device):
+    """Host-resident state, wavefront schedule (cytvdn_amd/wavefront.py): no stopping rule, no reference_data."""
+    from .wavefront import WavefrontRunner
+    dtype = datacube.dtype
+    n_total = n_fista + n_plain
+    rows, k = plan
+    wr = WavefrontRunner(datacube, FISTA, lambdaInv, lam_mu, device=device, chunk_rows=rows, k=k, max_iters=n_total)
+    wr.run(n_fista if FISTA else 0, n_plain if unaccelerated else 0)
+    sums = wr.sums()[:n_total] if n_total else np.zeros((0, 3))
+    b_norm = sums[:, 0].astype(dtype)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        delta_recon = (sums[:, 1].astype(dtype) / sums[:, 2].astype(dtype)).astype(dtype)
+    return wr.recon(), b_norm, delta_recon
 
 
 def _run_staged(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, stop, reference_data,

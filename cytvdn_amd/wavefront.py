@@ -1,0 +1,303 @@
+"""Out-of-core engine, wavefront schedule: k iterations per PCIe round trip with NO redundant sweeps.
+
+`outofcore.StagedRunner` advances a block k iterations by letting the swept range shrink one row per
+iteration on each interior side (a trapezoid in row x iteration space): simple, but at k ~ block height half
+of the sweeps are spent on halo rows.  Here the blocks are parallelograms instead: the cube streams
+through the GPU once per pass, in chunks of R rows, and iteration level j+1 trails level j by one row --
+chunk c computes, for j = 0..k-1, rows [cR-(j+1), (c+1)R-(j+1)) of level j+1 from level j -- so every row of
+every level is computed exactly once and crosses PCIe once per k iterations (10 arrays up, 9 down).
+
+Each level keeps a sliding window of R+3 rows per state array in HBM (recon_j and one accumulator array per
+axis; in the compact FISTA state level j's `d_j` also serves as `d_prev` of level j+1's update), plus one
+window of the input.  The sweeps are the same `tvdn_iterate_fused` launches as everywhere else: windows are
+presented to the kernel as row ranges of virtual arrays by offsetting the base pointers, so the arithmetic
+-- and the bits -- are those of the in-core engine.  Jia-Zhao BC, single GPU, no per-iteration host
+decisions (no stopping rule, no reference_data): `driver._run_staged` falls back to the trapezoid engine
+for those.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import fista_ratios
+
+
+class _Window:
+    """Sliding window of rows [base, top) of one array, stored from buffer row 0."""
+
+    def __init__(self, cap, plane, tdt, dev):
+        self.buf = torch.zeros((cap,) + tuple(plane), dtype=tdt, device=dev)
+        self.base = 0
+        self.top = 0
+
+    def slide(self, new_base):
+        """Drop the rows below new_base (global index), keeping [new_base, top) at the front."""
+        if new_base <= self.base:
+            return
+        keep = max(0, self.top - new_base)
+        shift = new_base - self.base
+        if keep > 0:
+            src = self.buf[shift:shift + keep]
+            self.buf[:keep].copy_(src.clone() if shift < keep else src)
+        self.base = new_base
+        self.top = max(self.top, new_base)
+
+    def rows(self, g0, g1):
+        """View of global rows [g0, g1)."""
+        assert self.base <= g0 and g1 - self.base <= self.buf.shape[0], (self.base, g0, g1, self.buf.shape[0])
+        return self.buf[g0 - self.base:g1 - self.base]
+
+    def ptr(self, ref, row_bytes):
+        """Base pointer of a virtual array whose row 0 is global row `ref` (may lie outside the buffer;
+        only rows inside the window are ever dereferenced)."""
+        return self.buf.data_ptr() + (ref - self.base) * row_bytes
+
+
+class WavefrontRunner:
+    """Host-resident cube, k iterations per streaming pass, no redundant sweeps (see module docstring)."""
+
+    def __init__(self, datacube: np.ndarray, fista: bool, clip, lam_mu, device: int = 0, chunk_rows: int = 16,
+                 k: int = 32, max_iters: int = 1, pin: bool = True):
+        self.shape = tuple(int(s) for s in datacube.shape)
+        self.nd = len(self.shape)
+        self.dtype = datacube.dtype
+        self.code = _lib.dtype_code(self.dtype)
+        self.fista = bool(fista)
+        self.device = int(device)
+        self.k = max(1, int(k))
+        self.R = max(2, int(chunk_rows))
+        self.N0 = self.shape[0]
+        self.max_iters = max(1, int(max_iters))
+        self.ctx = _lib.ctx(self.device)
+        tdt = torch.float32 if self.dtype == np.float32 else torch.float64
+        self.tdt = tdt
+        dev = torch.device("cuda", self.device)
+        self.dev = dev
+        plane = self.shape[1:]
+        self.row_bytes = int(np.prod(plane)) * self.dtype.itemsize
+        self.clip = [float(v) for v in clip]
+        self.lam_mu = [float(v) for v in lam_mu]
+
+        def host(fill=None):
+            t = torch.empty(self.shape, dtype=tdt, pin_memory=pin)
+            if fill is None:
+                t.zero_()
+            else:
+                t.copy_(torch.from_numpy(fill))
+            return t
+
+        self.orig_h = host(np.ascontiguousarray(datacube))
+        self.recon_h = [host(np.ascontiguousarray(datacube)), host()]
+        n_state = 2 if self.fista else 1
+        self.state_h = [[[host() for _ in range(n_state)] for _ in range(self.nd)] for _ in range(2)]
+        self.h_old = 0
+        self.d_form = self.fista
+        self.tk_prev = 0.0
+        self.iters_done = 0
+        self.sums_dev = torch.zeros((self.max_iters, 3), dtype=torch.float64, device=dev)
+        self.bytes_h2d = 0
+        self.bytes_d2h = 0
+
+        cap = self.R + 3
+        K = self.k
+        # levels -1 .. K: recon (levels 0..K) and one accumulator array per axis (levels -1..K)
+        self.Rw = [_Window(cap, plane, tdt, dev) for _ in range(K + 1)]
+        self.Aw = [[_Window(cap, plane, tdt, dev) for _ in range(self.nd)] for _ in range(K + 2)]  # index level + 1
+        self.Ow = _Window(self.R + K + 3, plane, tdt, dev)
+        n_in = 2 + 2 * self.nd
+        n_out = 1 + 2 * self.nd
+        self.inbox = [[torch.empty((self.R,) + tuple(plane), dtype=tdt, device=dev) for _ in range(n_in)] for _ in range(2)]
+        self.outbox = [[torch.empty((self.R,) + tuple(plane), dtype=tdt, device=dev) for _ in range(n_out)] for _ in range(2)]
+        self.up = torch.cuda.Stream(device=dev)
+        self.down = torch.cuda.Stream(device=dev)
+        self._args = _lib.IterArgs()
+
+    def device_bytes(self) -> int:
+        n = (len(self.Rw) + len(self.Aw) * self.nd) * self.Rw[0].buf.numel() + self.Ow.buf.numel()
+        n += sum(t.numel() for b in self.inbox + self.outbox for t in b)
+        return n * self.dtype.itemsize
+
+    # ---- one launch: level j -> j+1 for global rows [a, b) ---------------------------------------------------
+    def _launch(self, j, a, b, tk, tk_prev, mode, slot):
+        N0, rb = self.N0, self.row_bytes
+        ref = 0 if a == 0 else a - 1
+        at_top = (b == N0)
+        row_hi = (b - ref) if at_top else (b - ref + 1)
+        A = self._args
+        A.dtype, A.ndim = self.code, self.nd
+        A.shape[0] = row_hi
+        for i, s in enumerate(self.shape[1:]):
+            A.shape[i + 1] = s
+        A.row_lo, A.row_hi = 0, row_hi
+        A.sweep_lo, A.sweep_hi = a - ref, b - ref
+        A.lo_mode = _lib.EDGE_BC
+        A.hi_mode = _lib.EDGE_ZERO if at_top else _lib.EDGE_BC
+        A.bc_mode = 2
+        A.mode = mode
+        A.tk, A.tk_prev = float(tk or 0.0), float(tk_prev)
+        A.accumulate = 1
+        A.orig = self.Ow.ptr(ref, rb)
+        A.recon_in = self.Rw[j].ptr(ref, rb)
+        A.recon_out = self.Rw[j + 1].ptr(ref, rb)
+        for q in range(self.nd):
+            cur, prv, nxt = self.Aw[j + 1][q], self.Aw[j][q], self.Aw[j + 2][q]
+            A.b_in[q] = A.b_out[q] = A.d_in[q] = A.d_out[q] = A.dprev_in[q] = None
+            A.clip[q], A.lambda_mu[q] = self.clip[q], self.lam_mu[q]
+            if mode == _lib.ITER_FISTA_D:
+                A.d_in[q], A.dprev_in[q], A.d_out[q] = cur.ptr(ref, rb), prv.ptr(ref, rb), nxt.ptr(ref, rb)
+            elif mode == _lib.ITER_FISTA_D_TO_PLAIN:
+                A.d_in[q], A.dprev_in[q], A.b_out[q] = cur.ptr(ref, rb), prv.ptr(ref, rb), nxt.ptr(ref, rb)
+            else:
+                A.b_in[q], A.b_out[q] = cur.ptr(ref, rb), nxt.ptr(ref, rb)
+        _lib.check(_lib.lib().tvdn_iterate_fused(self.ctx, C.byref(A), C.c_void_p(self.sums_dev[slot].data_ptr()),
+                                                 _lib.current_stream(self.device)))
+
+    # ---- one pass of len(ratios) iterations over the whole cube ------------------------------------------------
+    def _pass(self, ratios, slot0):
+        kk, R, N0, nd = len(ratios), self.R, self.N0, self.nd
+        old, new = self.h_old, self.h_old ^ 1
+        main = torch.cuda.current_stream(self.dev)
+        # form and mode of every level of this pass
+        forms = [self.d_form]
+        modes, tkp = [], []
+        prev_ratio = self.tk_prev
+        for j, tk in enumerate(ratios):
+            if tk is not None:
+                if not forms[j]:
+                    raise ValueError("a FISTA iteration cannot follow an unaccelerated one")
+                modes.append(_lib.ITER_FISTA_D)
+                forms.append(True)
+            else:
+                modes.append(_lib.ITER_FISTA_D_TO_PLAIN if forms[j] else _lib.ITER_PLAIN)
+                forms.append(False)
+            tkp.append(prev_ratio)
+            if tk is not None:
+                prev_ratio = tk
+        n_in_state = 2 if forms[0] else 1
+        n_out_state = 2 if forms[kk] else 1
+        for w in self.Rw[:kk + 1] + [x for lvl in self.Aw[:kk + 2] for x in lvl] + [self.Ow]:
+            w.base = w.top = 0
+        n_chunks = (N0 + kk + R - 1) // R
+        in_ready, in_free = [None, None], [None, None]
+        out_ready, out_free = [None, None], [None, None]
+
+        def upload(c):
+            u0, u1 = c * R, min((c + 1) * R, N0)
+            if u0 >= u1:
+                return
+            box = self.inbox[c % 2]
+            with torch.cuda.stream(self.up):
+                if in_free[c % 2] is not None:
+                    self.up.wait_event(in_free[c % 2])
+                n = u1 - u0
+                box[0][:n].copy_(self.orig_h[u0:u1], non_blocking=True)
+                box[1][:n].copy_(self.recon_h[old][u0:u1], non_blocking=True)
+                i = 2
+                for q in range(nd):
+                    for s in range(n_in_state):
+                        box[i][:n].copy_(self.state_h[old][q][s][u0:u1], non_blocking=True)
+                        i += 1
+                self.bytes_h2d += i * n * self.row_bytes
+                ev = torch.cuda.Event()
+                ev.record(self.up)
+                in_ready[c % 2] = ev
+
+        upload(0)
+        for c in range(n_chunks):
+            upload(c + 1)                                   # next chunk crosses PCIe while this one is swept
+            u0, u1 = c * R, min((c + 1) * R, N0)
+            # slide every window to what chunk c still needs: level j keeps rows >= cR - j - 2
+            for j in range(-1, kk + 1):
+                nb = max(0, c * R - j - 2)
+                if j >= 0:
+                    self.Rw[j].slide(nb)
+                for q in range(nd):
+                    self.Aw[j + 1][q].slide(nb)
+            self.Ow.slide(max(0, c * R - kk - 1))
+            if u0 < u1:
+                n = u1 - u0
+                box = self.inbox[c % 2]
+                main.wait_event(in_ready[c % 2])
+                self.Ow.rows(u0, u1).copy_(box[0][:n])
+                self.Rw[0].rows(u0, u1).copy_(box[1][:n])
+                i = 2
+                for q in range(nd):
+                    self.Aw[1][q].rows(u0, u1).copy_(box[i][:n])          # level 0: d_k (or b)
+                    i += 1
+                    if n_in_state == 2:
+                        self.Aw[0][q].rows(u0, u1).copy_(box[i][:n])      # level -1: d_k-1
+                        i += 1
+                ev = torch.cuda.Event()
+                ev.record(main)
+                in_free[c % 2] = ev
+                self.Ow.top = self.Rw[0].top = u1
+                for q in range(nd):
+                    self.Aw[1][q].top = self.Aw[0][q].top = u1
+            # the wavefront: level j+1 trails level j by one row
+            for j in range(kk):
+                a = max(0, c * R - (j + 1))
+                b = min(N0, (c + 1) * R - (j + 1))
+                if a >= b:
+                    continue
+                self._launch(j, a, b, ratios[j], tkp[j], modes[j], slot0 + j)
+                self.Rw[j + 1].top = b
+                for q in range(nd):
+                    self.Aw[j + 2][q].top = b
+            # rows that have reached the last level go home
+            a = max(0, c * R - kk)
+            b = min(N0, (c + 1) * R - kk)
+            if a < b:
+                n = b - a
+                box = self.outbox[c % 2]
+                if out_free[c % 2] is not None:
+                    main.wait_event(out_free[c % 2])
+                box[0][:n].copy_(self.Rw[kk].rows(a, b))
+                i = 1
+                for q in range(nd):
+                    box[i][:n].copy_(self.Aw[kk + 1][q].rows(a, b))
+                    i += 1
+                    if n_out_state == 2:
+                        box[i][:n].copy_(self.Aw[kk][q].rows(a, b))
+                        i += 1
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(self.down):
+                    self.down.wait_event(ev)
+                    self.recon_h[new][a:b].copy_(box[0][:n], non_blocking=True)
+                    i = 1
+                    for q in range(nd):
+                        for s in range(n_out_state):
+                            self.state_h[new][q][s][a:b].copy_(box[i][:n], non_blocking=True)
+                            i += 1
+                    self.bytes_d2h += i * n * self.row_bytes
+                    ev2 = torch.cuda.Event()
+                    ev2.record(self.down)
+                    out_free[c % 2] = ev2
+        self.down.synchronize()
+        main.synchronize()
+        self.h_old = new
+        self.d_form = forms[kk]
+        self.tk_prev = prev_ratio
+        self.iters_done += kk
+
+    def run(self, n_fista: int, n_plain: int):
+        slot = self.iters_done
+        ratios = [float(r) for r in fista_ratios(n_fista)] + [None] * int(n_plain)
+        i = 0
+        while i < len(ratios):
+            grp = ratios[i:i + self.k]
+            self._pass(grp, slot + i)
+            i += len(grp)
+
+    def sums(self) -> np.ndarray:
+        return self.sums_dev.cpu().numpy()
+
+    def recon(self) -> np.ndarray:
+        return self.recon_h[self.h_old].numpy().copy()
+
+
+__all__ = ["WavefrontRunner"]

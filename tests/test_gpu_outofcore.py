@@ -48,3 +48,33 @@ def test_staged_early_stop_matches(monkeypatch):
     assert bits_equal(got[0], want[0])
     assert np.array_equal(got[2] == 0, want[2] == 0)
     np.testing.assert_allclose(got[2], want[2], rtol=1e-6)
+
+
+@pytest.mark.parametrize("shape,dtype,its,fista,rows,k", [
+    ((23, 3, 4, 8), "float32", 9, True, 5, 3),
+    ((23, 3, 4, 8), "float32", 9, True, 2, 9),               # deeper than a chunk: many levels per row
+    ((23, 3, 4, 8), "float32", [5, 4], True, 4, 4),           # hybrid: the d -> b transition inside a pass
+    ((23, 3, 4, 8), "float32", [5, 4], True, 3, 9),           # ... and inside a single pass
+    ((17, 6, 16), "float64", 7, False, 3, 5),
+    ((17, 6, 16), "float64", 7, True, 17, 2),
+    ((9, 2, 5, 7), "float32", 6, True, 2, 8),                 # more levels than rows in the cube
+    ((40, 3, 4, 8), "float32", 11, True, 7, 4),
+    ((5, 3, 4, 8), "float32", 12, True, 16, 5),               # chunk taller than the cube
+])
+def test_wavefront_equals_in_core(oracle, monkeypatch, shape, dtype, its, fista, rows, k):
+    """The wavefront (parallelogram) schedule: every row of every iteration level computed once, still bit-identical."""
+    import cytvdn_amd as tv
+    from cytvdn_amd import synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=57, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    fn = tv.denoise4D if nd == 4 else tv.denoise3D
+    want = fn(x, mu, its, FISTA=fista, quiet=True)
+    monkeypatch.setenv("TVDN_WAVEFRONT", f"{rows},{k}")
+    got = fn(x, mu, its, FISTA=fista, quiet=True)
+    assert bits_equal(got[0], want[0])
+    ref = oracle.denoise(x, mu, its, fista)
+    assert bits_equal(got[0], ref["recon"])
+    for a, b in zip(got[1:], want[1:]):
+        np.testing.assert_allclose(a, b, rtol=1e-6 if dt == np.float32 else 1e-12)
