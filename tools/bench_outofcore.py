@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--iters", type=int, default=32)
     ap.add_argument("--stages", type=int, default=3)
+    ap.add_argument("--engine", default="trapezoid", choices=["trapezoid", "wavefront"])
     ap.add_argument("--check", action="store_true", help="also run in-core and compare bit for bit")
     a = ap.parse_args()
     import numpy as np
@@ -45,7 +46,11 @@ def main():
     mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
     lam = mu / dt.type(32.0 if nd == 4 else 16.0)
     t0 = time.perf_counter()
-    sr = StagedRunner(x, True, 1.0 / lam, (lam / mu).astype(dt), device=0, block_rows=a.rows, k=a.k, max_iters=a.iters, n_stages=a.stages)
+    if a.engine == "wavefront":
+        from cytvdn_amd.wavefront import WavefrontRunner
+        sr = WavefrontRunner(x, True, 1.0 / lam, (lam / mu).astype(dt), device=0, chunk_rows=a.rows, k=a.k, max_iters=a.iters)
+    else:
+        sr = StagedRunner(x, True, 1.0 / lam, (lam / mu).astype(dt), device=0, block_rows=a.rows, k=a.k, max_iters=a.iters, n_stages=a.stages)
     t_alloc = time.perf_counter() - t0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -54,7 +59,7 @@ def main():
     dt_run = time.perf_counter() - t0
     vox = float(np.prod(shape))
     out = {"metric": "Gvoxel-iters/s (4D aniso FISTA, out-of-core single GPU)", "value": round(vox * a.iters / dt_run / 1e9, 3),
-           "unit": "Gvoxel-iters/s", "shape": list(shape), "block_rows": a.rows, "iters_per_pass": a.k, "iters": a.iters, "stages": a.stages,
+           "unit": "Gvoxel-iters/s", "shape": list(shape), "block_rows": a.rows, "iters_per_pass": a.k, "iters": a.iters, "stages": a.stages, "engine": a.engine,
            "seconds": round(dt_run, 3), "h2d_GBps": round(sr.bytes_h2d / dt_run / 1e9, 1),
            "d2h_GBps": round(sr.bytes_d2h / dt_run / 1e9, 1), "h2d_GB": round(sr.bytes_h2d / 1e9, 1),
            "d2h_GB": round(sr.bytes_d2h / 1e9, 1), "synth_s": round(t_syn, 1), "pin_alloc_s": round(t_alloc, 1),
