@@ -28,9 +28,10 @@ def denoise_slabs(my_rows, global_shape, mu, iterations=10, FISTA=True, stopping
     are global (all-reduced) and identical on every rank.  Semantics of `iterations` ([nF, nU] hybrid),
     `lam` defaults and the stopping rule follow cyTVDN/cyTVDN.py:67-68 / :294-295, :99-108, :189-195.
 
-    `staged=(block_rows, k)` keeps each rank's slab in pinned host memory and streams it through the GPU in
-    blocks, k iterations per visit (cytvdn_amd/outofcore.py): for cubes whose state exceeds the HBM of the
-    GPUs at hand (BASELINE config 5).  Without it the slab must fit in HBM."""
+    `staged=(rows, k)` keeps each rank's slab in pinned host memory and streams it through the GPU, k iterations
+    per PCIe round trip (cytvdn_amd/wavefront.py; cytvdn_amd/outofcore.py when a stopping rule needs a decision
+    every iteration, or with `staged=(rows, k, "trapezoid")`): for cubes whose state exceeds the HBM of the GPUs
+    at hand (BASELINE config 5).  Without it the slab must fit in HBM."""
     import torch.distributed as dist
     if not dist.is_initialized():
         raise RuntimeError("initialise torch.distributed first (backend 'nccl' = RCCL on ROCm)")
@@ -101,11 +102,21 @@ def denoise_slabs(my_rows, global_shape, mu, iterations=10, FISTA=True, stopping
 
 def _denoise_slabs_staged(my_rows, lay, dtype, mu, lam, FISTA, unacc, n_f, n_p, stop, group, device, staged, rank, world):
     from .outofcore import StagedRunner
+    from .wavefront import WavefrontRunner
     rows, k = int(staged[0]), int(staged[1])
-    if stop is not None:
-        k = 1
     n = n_f + n_p
     own = my_rows.cpu().numpy() if isinstance(my_rows, torch.Tensor) else np.ascontiguousarray(my_rows)
+    if stop is None and lay.bc_mode == 2 and not (len(staged) > 2 and staged[2] == "trapezoid"):
+        # no per-iteration host decision: the wavefront schedule (every row of every level swept once)
+        wr = WavefrontRunner(own, FISTA, 1.0 / lam, (lam / mu).astype(dtype), device=device, chunk_rows=rows,
+                             k=min(k, lay.own_rows), max_iters=n, global_rows=lay.shape[0], row0=lay.g0, group=group,
+                             world=world, rank=rank)
+        wr.run(n_f if FISTA else 0, n_p if unacc else 0)
+        sums = wr.sums()[:n]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return wr.recon(), sums[:, 0].astype(dtype), (sums[:, 1].astype(dtype) / sums[:, 2].astype(dtype)).astype(dtype)
+    if stop is not None:
+        k = 1
     sr = StagedRunner(own, FISTA, 1.0 / lam, (lam / mu).astype(dtype), bc_mode=lay.bc_mode, device=device,
                       block_rows=rows, k=min(k, lay.own_rows), max_iters=n, global_rows=lay.shape[0], row0=lay.g0,
                       group=group, world=world, rank=rank)

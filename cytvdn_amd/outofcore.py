@@ -39,6 +39,40 @@ def plan_blocks(n_rows: int, block_rows: int):
     return [(g, min(g + block_rows, n_rows)) for g in range(0, n_rows, block_rows)]
 
 
+def exchange_halo_rows(dist, group, rank, world, device, arrays, lo, hi, ext_lo, ext_hi, depth):
+    """Slab mode: for every host array (own rows [lo, hi), halo rows around them) send my lowest / highest
+    `depth` own rows to the left / right neighbour's halo rows and receive theirs into mine.
+    gloo moves host memory directly; RCCL stages the rows through HBM."""
+    left = rank - 1 if rank > 0 else None
+    right = rank + 1 if rank < world - 1 else None
+    dl, dh = min(depth, ext_lo), min(depth, ext_hi)
+    via_dev = dist.get_backend(group) != "gloo"
+    peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+    cuda = torch.device("cuda", device)
+    ops, post = [], []
+    for i, t in enumerate(arrays):
+        def snd(view):
+            return view.to(cuda, non_blocking=False) if via_dev else view.contiguous()
+
+        def rcv(view):
+            buf = torch.empty(view.shape, dtype=view.dtype, device=cuda) if via_dev else view
+            if via_dev:
+                post.append((view, buf))
+            return buf
+        if left is not None:
+            ops.append(dist.P2POp(dist.isend, snd(t[lo:lo + depth]), peer(left), group, tag=4 * i + 1))
+        if right is not None:
+            ops.append(dist.P2POp(dist.isend, snd(t[hi - depth:hi]), peer(right), group, tag=4 * i + 2))
+            ops.append(dist.P2POp(dist.irecv, rcv(t[hi:hi + dh]), peer(right), group, tag=4 * i + 1))
+        if left is not None:
+            ops.append(dist.P2POp(dist.irecv, rcv(t[lo - dl:lo]), peer(left), group, tag=4 * i + 2))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for view, buf in post:
+        view.copy_(buf)
+
+
 class StagedRunner:
     """Runs the denoise loop on a host-resident cube (or, with `world` > 1, on this rank's slab of it)
     through a few staging buffers on one GPU.
@@ -122,40 +156,9 @@ class StagedRunner:
                     self._sse(be, be.orig[:n], be.ref[:n], 0)
             be.stream.synchronize()
 
-    # ---- slab mode: refresh the halo rows of host arrays from the neighbouring ranks ------------------------
     def _exchange(self, arrays, depth):
-        """For every host array: my lowest/highest `depth` own rows go to the left/right neighbour's halo
-        rows, theirs come into mine.  gloo moves host memory directly; RCCL stages the rows through HBM."""
-        dist = self.dist
-        lo, hi = self.ext_lo, self.ext_lo + self.own
-        left = self.rank - 1 if self.rank > 0 else None
-        right = self.rank + 1 if self.rank < self.world - 1 else None
-        dl, dh = min(depth, self.ext_lo), min(depth, self.ext_hi)
-        via_dev = dist.get_backend(self.group) != "gloo"
-        peer = (lambda r: r) if self.group is None else (lambda r: dist.get_global_rank(self.group, r))
-        ops, post = [], []
-        for i, t in enumerate(arrays):
-            def snd(view):
-                return view.to(torch.device("cuda", self.device), non_blocking=False) if via_dev else view.contiguous()
-
-            def rcv(view):
-                buf = torch.empty(view.shape, dtype=view.dtype, device=torch.device("cuda", self.device)) if via_dev else view
-                if via_dev:
-                    post.append((view, buf))
-                return buf
-            # the neighbour's halo is as deep as MY own rows allow it to ask for: both sides use min(depth, k)
-            if left is not None:
-                ops.append(dist.P2POp(dist.isend, snd(t[lo:lo + depth]), peer(left), self.group, tag=4 * i + 1))
-            if right is not None:
-                ops.append(dist.P2POp(dist.isend, snd(t[hi - depth:hi]), peer(right), self.group, tag=4 * i + 2))
-                ops.append(dist.P2POp(dist.irecv, rcv(t[hi:hi + dh]), peer(right), self.group, tag=4 * i + 1))
-            if left is not None:
-                ops.append(dist.P2POp(dist.irecv, rcv(t[lo - dl:lo]), peer(left), self.group, tag=4 * i + 2))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        for view, buf in post:
-            view.copy_(buf)
+        exchange_halo_rows(self.dist, self.group, self.rank, self.world, self.device, arrays, self.ext_lo,
+                           self.ext_lo + self.own, self.ext_lo, self.ext_hi, depth)
 
     def _sse(self, be, a, b, slot):
         _lib.check(_lib.lib().tvdn_sum_square_error(be.ctx, be.code, self.nd, _lib.shape_arr(a.shape), a.data_ptr(),

@@ -61,16 +61,32 @@ class WavefrontRunner:
     """Host-resident cube, k iterations per streaming pass, no redundant sweeps (see module docstring)."""
 
     def __init__(self, datacube: np.ndarray, fista: bool, clip, lam_mu, device: int = 0, chunk_rows: int = 16,
-                 k: int = 32, max_iters: int = 1, pin: bool = True):
-        self.shape = tuple(int(s) for s in datacube.shape)
-        self.nd = len(self.shape)
+                 k: int = 32, max_iters: int = 1, pin: bool = True, global_rows: int = None, row0: int = 0,
+                 group=None, world: int = 1, rank: int = 0):
+        """Slab mode (`world` > 1): `datacube` holds this rank's own rows [row0, row0+rows) of a cube with
+        `global_rows` rows.  The host arrays then carry up to k extra rows per interior side, refreshed from the
+        neighbouring ranks before every pass; at those artificial faces the wavefront gives up one row per
+        level (a trapezoid k rows wide), everywhere else it stays redundancy-free."""
+        own_shape = tuple(int(s) for s in datacube.shape)
+        self.nd = len(own_shape)
         self.dtype = datacube.dtype
         self.code = _lib.dtype_code(self.dtype)
         self.fista = bool(fista)
         self.device = int(device)
         self.k = max(1, int(k))
         self.R = max(2, int(chunk_rows))
-        self.N0 = self.shape[0]
+        self.N0 = int(own_shape[0] if global_rows is None else global_rows)
+        self.g0, self.g1 = int(row0), int(row0) + own_shape[0]
+        self.world, self.rank, self.group = int(world), int(rank), group
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if own_shape[0] < self.k:
+                raise ValueError(f"a slab needs at least k = {self.k} rows (it has {own_shape[0]})")
+        self.ext_lo = min(self.k, self.g0) if self.world > 1 else 0
+        self.ext_hi = min(self.k, self.N0 - self.g1) if self.world > 1 else 0
+        self.base = self.g0 - self.ext_lo                    # global index of host row 0
+        self.shape = (self.ext_lo + own_shape[0] + self.ext_hi,) + own_shape[1:]
         self.max_iters = max(1, int(max_iters))
         self.ctx = _lib.ctx(self.device)
         tdt = torch.float32 if self.dtype == np.float32 else torch.float64
@@ -82,12 +98,13 @@ class WavefrontRunner:
         self.clip = [float(v) for v in clip]
         self.lam_mu = [float(v) for v in lam_mu]
 
+        own_sl = slice(self.ext_lo, self.ext_lo + own_shape[0])
+
         def host(fill=None):
             t = torch.empty(self.shape, dtype=tdt, pin_memory=pin)
-            if fill is None:
-                t.zero_()
-            else:
-                t.copy_(torch.from_numpy(fill))
+            t.zero_()
+            if fill is not None:
+                t[own_sl].copy_(torch.from_numpy(fill))
             return t
 
         self.orig_h = host(np.ascontiguousarray(datacube))
@@ -98,7 +115,13 @@ class WavefrontRunner:
         self.d_form = self.fista
         self.tk_prev = 0.0
         self.iters_done = 0
-        self.sums_dev = torch.zeros((self.max_iters, 3), dtype=torch.float64, device=dev)
+        self.sums_dev = torch.zeros((self.max_iters + 1, 3), dtype=torch.float64, device=dev)   # last row: discard slot
+        if self.world > 1:
+            from .outofcore import exchange_halo_rows
+            self._exchange = lambda arrays, depth: exchange_halo_rows(
+                self.dist, self.group, self.rank, self.world, self.device, arrays, self.ext_lo,
+                self.ext_lo + own_shape[0], self.ext_lo, self.ext_hi, depth)
+            self._exchange([self.orig_h], self.k)
         self.bytes_h2d = 0
         self.bytes_d2h = 0
 
@@ -161,6 +184,15 @@ class WavefrontRunner:
         kk, R, N0, nd = len(ratios), self.R, self.N0, self.nd
         old, new = self.h_old, self.h_old ^ 1
         main = torch.cuda.current_stream(self.dev)
+        hb = self.base                                      # host row index = global row - hb
+        g0, g1 = self.g0, self.g1
+        # rows this pass works on: own rows plus kk rows of the neighbours' state at each artificial face
+        E0, E1 = max(0, g0 - kk) if self.world > 1 else 0, min(N0, g1 + kk) if self.world > 1 else N0
+        art_lo, art_hi = (E0 > 0), (E1 < N0)                # faces that are not the cube's own boundary
+        if self.world > 1:
+            arrays = [self.recon_h[old]] + [t for q in range(nd) for t in self.state_h[old][q][: (2 if self.d_form else 1)]]
+            self._exchange(arrays, kk)
+        discard = self.max_iters
         # form and mode of every level of this pass
         forms = [self.d_form]
         modes, tkp = [], []
@@ -181,12 +213,18 @@ class WavefrontRunner:
         n_out_state = 2 if forms[kk] else 1
         for w in self.Rw[:kk + 1] + [x for lvl in self.Aw[:kk + 2] for x in lvl] + [self.Ow]:
             w.base = w.top = 0
-        n_chunks = (N0 + kk + R - 1) // R
+        n_chunks = (E1 - E0 + kk + R - 1) // R
+
+        def lo_bound(level):    # lowest row that can be brought to `level` (an artificial face loses a row per level)
+            return E0 + level if art_lo else 0
+
+        def hi_bound(level):
+            return E1 - level if art_hi else N0
         in_ready, in_free = [None, None], [None, None]
         out_ready, out_free = [None, None], [None, None]
 
         def upload(c):
-            u0, u1 = c * R, min((c + 1) * R, N0)
+            u0, u1 = E0 + c * R, min(E0 + (c + 1) * R, E1)
             if u0 >= u1:
                 return
             box = self.inbox[c % 2]
@@ -194,12 +232,12 @@ class WavefrontRunner:
                 if in_free[c % 2] is not None:
                     self.up.wait_event(in_free[c % 2])
                 n = u1 - u0
-                box[0][:n].copy_(self.orig_h[u0:u1], non_blocking=True)
-                box[1][:n].copy_(self.recon_h[old][u0:u1], non_blocking=True)
+                box[0][:n].copy_(self.orig_h[u0 - hb:u1 - hb], non_blocking=True)
+                box[1][:n].copy_(self.recon_h[old][u0 - hb:u1 - hb], non_blocking=True)
                 i = 2
                 for q in range(nd):
                     for s in range(n_in_state):
-                        box[i][:n].copy_(self.state_h[old][q][s][u0:u1], non_blocking=True)
+                        box[i][:n].copy_(self.state_h[old][q][s][u0 - hb:u1 - hb], non_blocking=True)
                         i += 1
                 self.bytes_h2d += i * n * self.row_bytes
                 ev = torch.cuda.Event()
@@ -209,15 +247,15 @@ class WavefrontRunner:
         upload(0)
         for c in range(n_chunks):
             upload(c + 1)                                   # next chunk crosses PCIe while this one is swept
-            u0, u1 = c * R, min((c + 1) * R, N0)
-            # slide every window to what chunk c still needs: level j keeps rows >= cR - j - 2
+            u0, u1 = E0 + c * R, min(E0 + (c + 1) * R, E1)
+            # slide every window to what chunk c still needs: level j keeps rows >= E0 + cR - j - 2
             for j in range(-1, kk + 1):
-                nb = max(0, c * R - j - 2)
+                nb = max(0, E0 + c * R - j - 2)
                 if j >= 0:
                     self.Rw[j].slide(nb)
                 for q in range(nd):
                     self.Aw[j + 1][q].slide(nb)
-            self.Ow.slide(max(0, c * R - kk - 1))
+            self.Ow.slide(max(0, E0 + c * R - kk - 1))
             if u0 < u1:
                 n = u1 - u0
                 box = self.inbox[c % 2]
@@ -239,17 +277,20 @@ class WavefrontRunner:
                     self.Aw[1][q].top = self.Aw[0][q].top = u1
             # the wavefront: level j+1 trails level j by one row
             for j in range(kk):
-                a = max(0, c * R - (j + 1))
-                b = min(N0, (c + 1) * R - (j + 1))
+                a = max(lo_bound(j + 1), E0 + c * R - (j + 1))
+                b = min(hi_bound(j + 1), E0 + (c + 1) * R - (j + 1))
                 if a >= b:
                     continue
-                self._launch(j, a, b, ratios[j], tkp[j], modes[j], slot0 + j)
+                # the sums count own rows only: rows of the neighbours' halo go to a discard slot
+                for x0, x1, slot in ((a, min(b, g0), discard), (max(a, g0), min(b, g1), slot0 + j), (max(a, g1), b, discard)):
+                    if x0 < x1:
+                        self._launch(j, x0, x1, ratios[j], tkp[j], modes[j], slot)
                 self.Rw[j + 1].top = b
                 for q in range(nd):
                     self.Aw[j + 2][q].top = b
-            # rows that have reached the last level go home
-            a = max(0, c * R - kk)
-            b = min(N0, (c + 1) * R - kk)
+            # own rows that have reached the last level go home
+            a = max(g0, E0 + c * R - kk)
+            b = min(g1, E0 + (c + 1) * R - kk)
             if a < b:
                 n = b - a
                 box = self.outbox[c % 2]
@@ -267,11 +308,11 @@ class WavefrontRunner:
                 ev.record(main)
                 with torch.cuda.stream(self.down):
                     self.down.wait_event(ev)
-                    self.recon_h[new][a:b].copy_(box[0][:n], non_blocking=True)
+                    self.recon_h[new][a - hb:b - hb].copy_(box[0][:n], non_blocking=True)
                     i = 1
                     for q in range(nd):
                         for s in range(n_out_state):
-                            self.state_h[new][q][s][a:b].copy_(box[i][:n], non_blocking=True)
+                            self.state_h[new][q][s][a - hb:b - hb].copy_(box[i][:n], non_blocking=True)
                             i += 1
                     self.bytes_d2h += i * n * self.row_bytes
                     ev2 = torch.cuda.Event()
@@ -294,10 +335,16 @@ class WavefrontRunner:
             i += len(grp)
 
     def sums(self) -> np.ndarray:
-        return self.sums_dev.cpu().numpy()
+        """[max_iters, 3] f64 sums over the own rows (all-reduced over the ranks in slab mode)."""
+        t = self.sums_dev[: self.max_iters].clone()
+        if self.world > 1:
+            t = t if self.dist.get_backend(self.group) != "gloo" else t.cpu()
+            self.dist.all_reduce(t, group=self.group)
+        return t.cpu().numpy()
 
     def recon(self) -> np.ndarray:
-        return self.recon_h[self.h_old].numpy().copy()
+        """This rank's own rows of the current reconstruction."""
+        return self.recon_h[self.h_old][self.ext_lo:self.ext_lo + (self.g1 - self.g0)].numpy().copy()
 
 
 __all__ = ["WavefrontRunner"]

@@ -119,8 +119,12 @@ def test_denoise_slabs_on_gpu_matches_single_process(oracle, world, shape, dtype
 
 
 @pytest.mark.parametrize("world,shape,dtype,its,fista,stop,staged", [
-    (2, (20, 3, 4, 8), "float32", 9, True, None, (4, 3)),        # several blocks per rank, k = 3 halo rows between ranks
-    (3, (19, 6, 16), "float64", [5, 4], True, None, (3, 4)),      # hybrid schedule, uneven slabs
+    (2, (20, 3, 4, 8), "float32", 9, True, None, (4, 3, "trapezoid")),   # several blocks per rank, 3 halo rows between ranks
+    (3, (19, 6, 16), "float64", [5, 4], True, None, (3, 4, "trapezoid")), # hybrid schedule, uneven slabs
+    (2, (20, 3, 4, 8), "float32", 9, True, None, (4, 3)),        # wavefront inside each slab, trapezoid at the slab faces
+    (3, (19, 6, 16), "float64", [5, 4], True, None, (3, 4)),
+    (2, (24, 2, 5, 7), "float32", 14, True, None, (2, 8)),       # more levels than chunk rows, scalar path
+    (4, (21, 4, 8), "float32", 7, False, None, (5, 5)),
     (2, (12, 5, 8, 12), "float32", [30, 6], True, 0.03, (5, 8)),  # global stopping rule (forces k = 1)
 ], ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
 def test_staged_slabs_match_single_process(oracle, world, shape, dtype, its, fista, stop, staged):
