@@ -147,6 +147,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        dist.barrier()      # first collective with every rank taking part (batched P2P must not be the first one)
 
     dtype = np.float32 if a.dtype == "f32" else np.float64
     if a.shape:

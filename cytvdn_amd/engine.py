@@ -338,6 +338,8 @@ class SlabRunner:
             if not dist.is_initialized():
                 raise RuntimeError("world > 1 needs an initialised torch.distributed process group")
             self.dist = dist
+            # batched P2P must not be the first collective of a group (torch.distributed.batch_isend_irecv note)
+            dist.barrier(group=group)
 
     def _device_p2p(self) -> bool:
         """True when the process group can send device memory directly (RCCL); a gloo group moves the
