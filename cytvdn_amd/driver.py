@@ -72,6 +72,10 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
                                   "(utils.pyx:117-120); not reproduced")
     if BC_mode not in (0, 2):
         raise ValueError(f"BC_mode must be 0 or 2, got {BC_mode}")
+    if datacube.size == 0:
+        # nothing to sweep: upstream's loops fall through, every norm is 0 and delta_recon is 0/0 (utils.pyx:125)
+        out = (datacube.copy(), np.zeros(n_total, dtype), np.full(n_total, np.nan, dtype))
+        return out + (np.zeros(n_total + 1, dtype),) if reference_data is not None else out
 
     if not quiet:
         plan = hbm_plan(datacube.shape, dtype, FISTA)

@@ -137,3 +137,14 @@ def test_hbm_plan_counts_arrays():
     assert hbm_plan((256, 256, 128, 128), np.float32, True)["bytes"] == 15 * 4 * 2 ** 30
     assert hbm_plan((256, 256, 128, 128), np.float64, False)["arrays"] == 11
     assert hbm_plan((128, 128, 512), np.float32, True)["arrays"] == 12
+
+
+def test_empty_cube_needs_no_gpu():
+    """A zero-size axis: upstream's loops fall through (norms 0, delta_recon 0/0 = NaN, recon an empty copy)."""
+    x = np.zeros((3, 0, 4, 4), np.float32)
+    recon, bn, dl = tv.denoise4D(x, np.ones(4, np.float32), 3, quiet=True)
+    assert recon.shape == x.shape and recon is not x
+    assert bn.dtype == np.float32 and np.array_equal(bn, np.zeros(3, np.float32)) and np.isnan(dl).all()
+    y = np.zeros((0, 5, 6), np.float64)
+    out = tv.denoise3D(y, np.ones(3), [2, 1], reference_data=y.copy(), quiet=True)
+    assert len(out) == 4 and out[3].shape == (4,) and out[0].shape == y.shape
