@@ -133,3 +133,38 @@ def test_config3_f64_plain_locality(oracle):
     assert bits_equal(got, ref[inner])
     del be
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("shape,fista", [
+    ((520, 256, 128, 128), True),      # 2.18e9 elements per array: past the signed 32-bit range (8.1 GiB x 15 arrays)
+    ((1056, 256, 128, 128), False),    # 4.43e9 elements per array: past the unsigned 32-bit range (16.5 GiB x 11 arrays)
+], ids=["past-2^31-FISTA", "past-2^32-plain"])
+def test_large_offsets_locality(oracle, shape, fista):
+    """Maximum-size regime: element offsets beyond 32 bits.  Windows at the far end of the cube against the oracle."""
+    import torch
+    from cytvdn_amd import _lib, synth
+    from cytvdn_amd.engine import HipBackend, SlabLayout, SlabRunner
+    dt = np.dtype(np.float32)
+    k = 2
+    mu = np.array([1.0, 1.0, 0.5, 0.5], dt)
+    lam = mu / dt.type(32.0)
+    be = HipBackend(SlabLayout(shape, 0, 1, 2), dt, fista, device=0, max_iters=k)
+    be.set_params(1.0 / lam, (lam / mu).astype(dt))
+    _lib.check(_lib.lib().tvdn_synth_fill(be.code, 4, _lib.shape_arr(shape), synth.SEED_4D, 0, shape[0],
+                                          be.orig.data_ptr(), _lib.current_stream(0)))
+    be.recon[be.cur].copy_(be.orig)
+    SlabRunner(be).run(k if fista else 0, 0 if fista else k)
+    halo = 2 * k
+    for start, ext in (((shape[0] - 9, 250, 119, 96), (9, 6, 9, 16)), ((shape[0] // 2 + 3, 0, 0, 0), (6, 7, 8, 12))):
+        lo = [max(0, s - halo) for s in start]
+        hi = [min(n, s + e + halo) for s, e, n in zip(start, ext, shape)]
+        x = be.orig[tuple(slice(a, b) for a, b in zip(lo, hi))].cpu().numpy().copy()
+        ref = oracle.denoise(x, mu, k, fista)["recon"]
+        inner = tuple(slice(s - a, s - a + e) for s, a, e in zip(start, lo, ext))
+        got = be.recon_tensor()[tuple(slice(s, s + e) for s, e in zip(start, ext))].cpu().numpy()
+        assert bits_equal(got, ref[inner])
+    # the sums of a cube this size are still finite and positive
+    s = be.sums.cpu().numpy()
+    assert np.all(np.isfinite(s)) and np.all(s[:, 2] > 0)
+    del be
+    torch.cuda.empty_cache()
