@@ -144,10 +144,23 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.barrier()  # first collective with every rank taking part (batched P2P must not be the first one)
+                torch.cuda.synchronize()
+            except Exception as e:  # RCCL unusable on this node: still produce a (slower) number over gloo
+                print(f"[bench] RCCL initialisation failed ({e!r}); falling back to gloo with host-staged halo rows",
+                      file=sys.stderr, flush=True)
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                backend = "gloo"
+                dist.init_process_group("gloo")
+                dist.barrier()
         else:
             dist.init_process_group(backend)
-        dist.barrier()      # first collective with every rank taking part (batched P2P must not be the first one)
+            dist.barrier()
 
     dtype = np.float32 if a.dtype == "f32" else np.float64
     if a.shape:
@@ -203,7 +216,7 @@ def main():
     # mean sweep-kernel time per iteration (with N > 1 an iteration is three launches: two edge rows + interior)
     kern_ms = tot_ms.value / max(a.steps, 1)
 
-    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kern_ms = float(t[0]), float(t[1])
@@ -231,6 +244,7 @@ def main():
             "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_shape": list(shape), "bc_mode": 2,
+                       "transport": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
                        "state_arrays": be.n_arrays(), "state": a.state,
                        "parallelism": f"slab{world}" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,

@@ -152,6 +152,7 @@ class HipBackend:
             raise TypeError("No matching signature found")
         # raises without a GPU: no CPU fallback.  A private context = own reduction scratch, needed when two
         # backends are driven from two streams at once (cytvdn_amd/outofcore.py)
+        self._private_ctx = bool(private_ctx)
         self.ctx = _lib.new_ctx(self.device) if private_ctx else _lib.ctx(self.device)
         tdt = torch.float32 if self.dtype == np.float32 else torch.float64
         dev = torch.device("cuda", self.device)
@@ -183,6 +184,14 @@ class HipBackend:
         a.row_lo, a.row_hi = layout.row_lo, layout.row_hi
         a.lo_mode, a.hi_mode, a.bc_mode = layout.lo_mode, layout.hi_mode, layout.bc_mode
         a.orig = self.orig.data_ptr()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_private_ctx", False) and self.ctx:
+                _lib.lib().tvdn_ctx_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
 
     # -- the five methods SlabRunner needs ------------------------------------------------------
     def set_params(self, clip, lam_mu):
@@ -484,6 +493,8 @@ class SlabRunner:
         self.finish()
         s = self.be.sums_tensor().clone()
         if self.layout.world > 1:
+            if s.is_cuda and self.dist.get_backend(self.group) == "gloo":
+                s = s.cpu()                      # gloo reduces host memory
             self.dist.all_reduce(s, group=self.group)
         return s
 
