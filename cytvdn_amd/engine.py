@@ -397,21 +397,13 @@ class SlabRunner:
         if not self._device_p2p():
             self._exchange_staged(r)
             return
-        # Order matters where RCCL matches messages per peer in issue order and one peer is both
-        # neighbours (periodic ring of two): sends go (first row -> left, last row -> right), so the
-        # receives are posted (from right, from left).
-        ops = []
-        if lay.left is not None:
-            ops.append(dist.P2POp(dist.isend, r[lay.row_lo], self._peer(lay.left), self.group, tag=1))
-        if lay.right is not None:
-            ops.append(dist.P2POp(dist.isend, r[lay.row_hi - 1], self._peer(lay.right), self.group, tag=2))
-            ops.append(dist.P2POp(dist.irecv, r[lay.row_hi], self._peer(lay.right), self.group, tag=1))
-        if lay.left is not None:
-            ops.append(dist.P2POp(dist.irecv, r[lay.row_lo - 1], self._peer(lay.left), self.group, tag=2))
-        for w in dist.batch_isend_irecv(ops):
+        for w in dist.batch_isend_irecv(self._ops(r)):
             w.wait()
 
     def _ops(self, r):
+        """The four row messages of one exchange.  Order matters where RCCL matches messages per peer in issue
+        order and one peer is both neighbours (periodic ring of two): sends go (first row -> left, last row ->
+        right), so the receives are posted (from right, from left)."""
         lay, dist = self.layout, self.dist
         ops = []
         if lay.left is not None:
