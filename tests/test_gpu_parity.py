@@ -226,3 +226,30 @@ def test_tvdn_run_host_entry(tv, shape, dtype, its, fista, stop, with_ref):
     assert bits_equal(dl, want[2])
     if with_ref:
         assert bits_equal(mse.astype(dt), want[3])
+
+
+def test_subnormals_signed_zeros_and_infinities(tv, oracle):
+    """f32 subnormals are kept (no flush-to-zero), -0.0 survives, +-inf/NaN propagate as on the CPU:
+    the arithmetic contract of SURVEY Appendix A, on the one-pass kernels and on the fused sweep."""
+    rng = np.random.default_rng(11)
+    shape = (6, 5, 4, 8)
+    tiny = np.float32(1e-41)                       # subnormal
+    a = (rng.standard_normal(shape) * tiny * 50).astype(np.float32)
+    b = (rng.standard_normal(shape) * tiny * 20).astype(np.float32)
+    d = (rng.standard_normal(shape) * tiny * 20).astype(np.float32)
+    a[0, 0, 0, 0], b[0, 0, 0, 0] = np.float32(-0.0), np.float32(-0.0)
+    assert np.any((a != 0) & (np.abs(a) < np.finfo(np.float32).tiny))
+    b2, d2 = b.copy(), d.copy()
+    tv.accumulator_update_4D_FISTA(a, b, d, np.float32(0.3), 3, np.float32(tiny * 7))
+    oracle.acc_update(a, b2, d2, np.float32(0.3), 3, np.float32(tiny * 7), 2)
+    assert bits_equal(b, b2) and bits_equal(d, d2)
+    assert np.any((b != 0) & (np.abs(b) < np.finfo(np.float32).tiny)), "subnormal results must not be flushed"
+    # fused loop on subnormal-scale data with infinities sprinkled in
+    x = (rng.standard_normal(shape) * tiny * 1000).astype(np.float32)
+    x[2, 3, 1, 5] = np.inf
+    x[4, 1, 2, 0] = -np.inf
+    mu = np.array([1, 1, .5, .5], np.float32)
+    got = tv.denoise4D(x, mu, 4, quiet=True)
+    ref = oracle.denoise(x, mu, 4, True)
+    assert bits_equal(got[0], ref["recon"])
+    assert np.isnan(got[0]).any() and np.isfinite(got[0]).any()
