@@ -87,14 +87,15 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
     staged = _staging_plan(datacube, FISTA, BC_mode, device, stopping_relative_change)
     # a host-resident run without per-iteration host decisions takes the wavefront schedule (no redundant sweeps)
     wf = os.environ.get("TVDN_WAVEFRONT")
-    if stopping_relative_change is None and reference_data is None and BC_mode == 2 and \
+    if stopping_relative_change is None and reference_data is None and \
             (wf or (staged is not None and not os.environ.get("TVDN_STAGED"))):
         plan = tuple(int(v) for v in wf.split(",")) if wf else _wavefront_plan(datacube, device)
         if plan is not None:
             if not quiet:
                 print(f"State exceeds HBM: streaming the cube from pinned host memory, {plan[1]} iterations per pass "
                       f"(wavefront schedule, {plan[0]}-row chunks)", flush=True)
-            return _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device)
+            return _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device,
+                                  BC_mode)
     if staged is not None:
         return _run_staged(staged, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain,
                            stopping_relative_change, reference_data, BC_mode, quiet, device)
@@ -185,8 +186,6 @@ def _staging_plan(datacube, FISTA, BC_mode, device, stop):
         rows = max(1, rows)
     if stop is not None:
         k = 1      # the stopping test is per iteration (cyTVDN.py:189-194): no temporal blocking then
-    if BC_mode != 2:
-        raise NotImplementedError("a cube that needs staging through host memory supports BC_mode=2 only")
     return max(1, rows), max(1, k)
 
 
@@ -206,13 +205,14 @@ def _wavefront_plan(datacube, device):
     return None
 
 
-def _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device):
+def _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device, BC_mode=2):
     """Host-resident state, wavefront schedule (cytvdn_amd/wavefront.py): no stopping rule, no reference_data."""
     from .wavefront import WavefrontRunner
     dtype = datacube.dtype
     n_total = n_fista + n_plain
     rows, k = plan
-    wr = WavefrontRunner(datacube, FISTA, lambdaInv, lam_mu, device=device, chunk_rows=rows, k=k, max_iters=n_total)
+    wr = WavefrontRunner(datacube, FISTA, lambdaInv, lam_mu, device=device, chunk_rows=rows, k=k, max_iters=n_total,
+                         bc_mode=int(BC_mode))
     wr.run(n_fista if FISTA else 0, n_plain if unaccelerated else 0)
     sums = wr.sums()[:n_total] if n_total else np.zeros((0, 3))
     b_norm = sums[:, 0].astype(dtype)
@@ -224,6 +224,8 @@ def _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fi
 def _run_staged(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, stop, reference_data,
                 BC_mode, quiet, device):
     from .outofcore import StagedRunner
+    if BC_mode != 2:
+        raise NotImplementedError("a host-staged run with a stopping rule or reference_data supports BC_mode=2 only")
     dtype = datacube.dtype
     n_total = n_fista + n_plain
     rows, k = plan

@@ -11,9 +11,9 @@ Each level keeps a sliding window of R+3 rows per state array in HBM (recon_j an
 axis; in the compact FISTA state level j's `d_j` also serves as `d_prev` of level j+1's update), plus one
 window of the input.  The sweeps are the same `tvdn_iterate_fused` launches as everywhere else: windows are
 presented to the kernel as row ranges of virtual arrays by offsetting the base pointers, so the arithmetic
--- and the bits -- are those of the in-core engine.  Jia-Zhao BC, single GPU, no per-iteration host
-decisions (no stopping rule, no reference_data): `driver._run_staged` falls back to the trapezoid engine
-for those.
+-- and the bits -- are those of the in-core engine.  Jia-Zhao and (single process) periodic BC; slabs across
+ranks; no per-iteration host decisions (no stopping rule, no reference_data): `driver._run_staged` falls back
+to the trapezoid engine for those.
 """
 from __future__ import annotations
 
@@ -62,12 +62,20 @@ class WavefrontRunner:
 
     def __init__(self, datacube: np.ndarray, fista: bool, clip, lam_mu, device: int = 0, chunk_rows: int = 16,
                  k: int = 32, max_iters: int = 1, pin: bool = True, global_rows: int = None, row0: int = 0,
-                 group=None, world: int = 1, rank: int = 0):
+                 group=None, world: int = 1, rank: int = 0, bc_mode: int = 2):
         """Slab mode (`world` > 1): `datacube` holds this rank's own rows [row0, row0+rows) of a cube with
         `global_rows` rows.  The host arrays then carry up to k extra rows per interior side, refreshed from the
         neighbouring ranks before every pass; at those artificial faces the wavefront gives up one row per
         level (a trapezoid k rows wide), everywhere else it stays redundancy-free."""
         own_shape = tuple(int(s) for s in datacube.shape)
+        if bc_mode not in (0, 2):
+            raise NotImplementedError("BC_mode must be 0 (periodic) or 2 (Jia-Zhao)")
+        if bc_mode == 0 and world > 1:
+            raise NotImplementedError("periodic BC across staged slabs is not built; use the in-core slab engine")
+        # Periodic BC along axis 0 (single process): the cube is extended by k wrapped rows at both ends, which
+        # makes both faces "artificial" exactly like slab faces whose neighbour is the cube's own other end.
+        self.bc = int(bc_mode)
+        self.periodic = (self.bc == 0)
         self.nd = len(own_shape)
         self.dtype = datacube.dtype
         self.code = _lib.dtype_code(self.dtype)
@@ -75,16 +83,21 @@ class WavefrontRunner:
         self.device = int(device)
         self.k = max(1, int(k))
         self.R = max(2, int(chunk_rows))
-        self.N0 = int(own_shape[0] if global_rows is None else global_rows)
-        self.g0, self.g1 = int(row0), int(row0) + own_shape[0]
+        if self.periodic:
+            k = min(int(k), own_shape[0])
+        self.k = max(1, int(k))
+        self.N0 = int(own_shape[0] if global_rows is None else global_rows) + (2 * self.k if self.periodic else 0)
+        self.g0 = int(row0) + (self.k if self.periodic else 0)
+        self.g1 = self.g0 + own_shape[0]
         self.world, self.rank, self.group = int(world), int(rank), group
         if self.world > 1:
             import torch.distributed as dist
             self.dist = dist
             if own_shape[0] < self.k:
                 raise ValueError(f"a slab needs at least k = {self.k} rows (it has {own_shape[0]})")
-        self.ext_lo = min(self.k, self.g0) if self.world > 1 else 0
-        self.ext_hi = min(self.k, self.N0 - self.g1) if self.world > 1 else 0
+        halo = self.world > 1 or self.periodic
+        self.ext_lo = min(self.k, self.g0) if halo else 0
+        self.ext_hi = min(self.k, self.N0 - self.g1) if halo else 0
         self.base = self.g0 - self.ext_lo                    # global index of host row 0
         self.shape = (self.ext_lo + own_shape[0] + self.ext_hi,) + own_shape[1:]
         self.max_iters = max(1, int(max_iters))
@@ -122,6 +135,9 @@ class WavefrontRunner:
                 self.dist, self.group, self.rank, self.world, self.device, arrays, self.ext_lo,
                 self.ext_lo + own_shape[0], self.ext_lo, self.ext_hi, depth)
             self._exchange([self.orig_h], self.k)
+        elif self.periodic:
+            self._exchange = self._wrap_rows
+            self._exchange([self.orig_h], self.k)
         self.bytes_h2d = 0
         self.bytes_d2h = 0
 
@@ -138,6 +154,13 @@ class WavefrontRunner:
         self.up = torch.cuda.Stream(device=dev)
         self.down = torch.cuda.Stream(device=dev)
         self._args = _lib.IterArgs()
+
+    def _wrap_rows(self, arrays, depth):
+        """Periodic BC: the halo rows below the first / above the last own row are the cube's own other end."""
+        lo, hi = self.ext_lo, self.ext_lo + (self.g1 - self.g0)
+        for t in arrays:
+            t[lo - depth:lo].copy_(t[hi - depth:hi])
+            t[hi:hi + depth].copy_(t[lo:lo + depth])
 
     def device_bytes(self) -> int:
         n = (len(self.Rw) + len(self.Aw) * self.nd) * self.Rw[0].buf.numel() + self.Ow.buf.numel()
@@ -159,7 +182,7 @@ class WavefrontRunner:
         A.sweep_lo, A.sweep_hi = a - ref, b - ref
         A.lo_mode = _lib.EDGE_BC
         A.hi_mode = _lib.EDGE_ZERO if at_top else _lib.EDGE_BC
-        A.bc_mode = 2
+        A.bc_mode = self.bc
         A.mode = mode
         A.tk, A.tk_prev = float(tk or 0.0), float(tk_prev)
         A.accumulate = 1
@@ -187,9 +210,11 @@ class WavefrontRunner:
         hb = self.base                                      # host row index = global row - hb
         g0, g1 = self.g0, self.g1
         # rows this pass works on: own rows plus kk rows of the neighbours' state at each artificial face
-        E0, E1 = max(0, g0 - kk) if self.world > 1 else 0, min(N0, g1 + kk) if self.world > 1 else N0
-        art_lo, art_hi = (E0 > 0), (E1 < N0)                # faces that are not the cube's own boundary
-        if self.world > 1:
+        halo = self.world > 1 or self.periodic
+        E0, E1 = max(0, g0 - kk) if halo else 0, min(N0, g1 + kk) if halo else N0
+        art_lo = (E0 > 0) or self.periodic                  # faces that are not the cube's own boundary
+        art_hi = (E1 < N0) or self.periodic
+        if halo:
             arrays = [self.recon_h[old]] + [t for q in range(nd) for t in self.state_h[old][q][: (2 if self.d_form else 1)]]
             self._exchange(arrays, kk)
         discard = self.max_iters

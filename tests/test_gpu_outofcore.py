@@ -50,6 +50,27 @@ def test_staged_early_stop_matches(monkeypatch):
     np.testing.assert_allclose(got[2], want[2], rtol=1e-6)
 
 
+@pytest.mark.parametrize("shape,dtype,its,fista,rows,k,bc", [
+    ((23, 3, 4, 8), "float32", 9, True, 5, 3, 0),             # periodic BC: the cube's two ends are each other's halo
+    ((17, 6, 16), "float64", [4, 3], True, 4, 6, 0),
+    ((6, 3, 4, 8), "float32", 7, True, 2, 9, 0),              # k capped at the cube height
+])
+def test_wavefront_periodic(oracle, monkeypatch, shape, dtype, its, fista, rows, k, bc):
+    import cytvdn_amd as tv
+    from cytvdn_amd import synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=57, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    fn = tv.denoise4D if nd == 4 else tv.denoise3D
+    monkeypatch.setenv("TVDN_WAVEFRONT", f"{rows},{k}")
+    got = fn(x, mu, its, FISTA=fista, BC_mode=bc, quiet=True)
+    ref = oracle.denoise(x, mu, its, fista, BC_mode=bc)
+    assert bits_equal(got[0], ref["recon"])
+    np.testing.assert_allclose(got[1].astype(np.float64), ref["b_norm64"].astype(dt).astype(np.float64),
+                               rtol=1e-6 if dt == np.float32 else 1e-12)
+
+
 @pytest.mark.parametrize("shape,dtype,its,fista,rows,k", [
     ((23, 3, 4, 8), "float32", 9, True, 5, 3),
     ((23, 3, 4, 8), "float32", 9, True, 2, 9),               # deeper than a chunk: many levels per row
