@@ -12,6 +12,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built libraries (they are git-ignored): compile them once (hipcc cross-compiles
+    # for gfx950 without a GPU; the oracle needs gcc only)
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "cytvdn_amd", "libtvdn_hip.so")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "cytvdn_amd", "csrc")])
+    if not os.path.exists(os.path.join(ROOT, "oracle", "libtvdn_oracle.so")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle"])
 
 
 @pytest.fixture(scope="session")
