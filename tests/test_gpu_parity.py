@@ -253,3 +253,32 @@ def test_subnormals_signed_zeros_and_infinities(tv, oracle):
     ref = oracle.denoise(x, mu, 4, True)
     assert bits_equal(got[0], ref["recon"])
     assert np.isnan(got[0]).any() and np.isfinite(got[0]).any()
+
+
+def test_plain_c_caller_of_the_abi(tv, tmp_path):
+    """examples/tvdn_run_demo.c: a C program linked against libtvdn_hip.so (no Python in the data path) must
+    produce the recon the Python driver produces for the same input."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "tvdn_run_demo")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "tvdn_run_demo.c"),
+                           "-L" + os.path.join(root, "cytvdn_amd"), "-ltvdn_hip",
+                           "-Wl,-rpath," + os.path.join(root, "cytvdn_amd"), "-lm", "-o", exe])
+    shape, iters = (7, 6, 8, 16), 6
+    out = subprocess.check_output([exe] + [str(s) for s in shape] + [str(iters)], text=True)
+    got = dict(l.split(" ", 1) for l in out.strip().splitlines() if l.startswith(("recon_fnv1a", "iters_run")))
+    # the same input, generated the same way
+    n = int(np.prod(shape))
+    z = np.uint64(88172645463325252)
+    x = np.empty(n, np.float32)
+    with np.errstate(over="ignore"):
+        for i in range(n):
+            z ^= z << np.uint64(13); z ^= z >> np.uint64(7); z ^= z << np.uint64(17)
+            x[i] = np.float32(int(z >> np.uint64(60))) + np.float32(0.001) * np.float32(i % 977)
+    recon = tv.denoise4D(x.reshape(shape), np.array([1, 1, .5, .5], np.float32), iters, quiet=True)[0]
+    h = 1469598103934665603
+    for byte in recon.tobytes():
+        h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert int(got["iters_run"]) == iters
+    assert got["recon_fnv1a"] == f"{h:016x}"
