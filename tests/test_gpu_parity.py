@@ -120,6 +120,9 @@ SHAPES = [
     ((40, 3, 5, 8), np.float32),   # several marching chunks
     ((70, 4, 4), np.float32), ((3, 5, 7, 9), np.float32), ((2, 1, 1, 4), np.float64), ((1, 1, 1, 1), np.float32),
     ((1, 6, 8), np.float64),
+    # C-rows of 8 / 16 / 32 lanes with A divisible by the rows a wavefront holds (wave-level sharing of the A neighbours)
+    ((5, 8, 3, 32), np.float32), ((4, 4, 5, 64), np.float32), ((3, 6, 4, 128), np.float32), ((3, 4, 3, 64), np.float64),
+    ((11, 16, 2, 32), np.float32),
 ]
 
 
