@@ -392,6 +392,9 @@ def check_memory(datacube, device: int = 0):
     print(f"Datacube size is {_fmt_bytes(datacube.nbytes)} with dtype {dtype}")
     if avail is not None:
         print(f"Free HBM on device {device}: {_fmt_bytes(avail)}")
+        fits = hbm_plan(shape, dtype, True)["bytes"] < 0.9 * avail
+        print("Engine denoise3D/4D will use (FISTA): " + ("in-core fused sweep" if fits else
+              "cube streamed from pinned host memory (wavefront schedule; trapezoid blocks with a stopping rule)"))
     try:
         from tabulate import tabulate
         print(tabulate(rows, ["Algorithm", "HBM Needed", "State", "OK?"]))
