@@ -87,7 +87,7 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
     staged = _staging_plan(datacube, FISTA, BC_mode, device, stopping_relative_change)
     # a host-resident run without per-iteration host decisions takes the wavefront schedule (no redundant sweeps)
     wf = os.environ.get("TVDN_WAVEFRONT")
-    if stopping_relative_change is None and reference_data is None and \
+    if stopping_relative_change is None and \
             (wf or (staged is not None and not os.environ.get("TVDN_STAGED"))):
         plan = tuple(int(v) for v in wf.split(",")) if wf else _wavefront_plan(datacube, device)
         if plan is not None:
@@ -95,7 +95,7 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
                 print(f"State exceeds HBM: streaming the cube from pinned host memory, {plan[1]} iterations per pass "
                       f"(wavefront schedule, {plan[0]}-row chunks)", flush=True)
             return _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device,
-                                  BC_mode)
+                                  BC_mode, reference_data)
     if staged is not None:
         return _run_staged(staged, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain,
                            stopping_relative_change, reference_data, BC_mode, quiet, device)
@@ -205,19 +205,22 @@ def _wavefront_plan(datacube, device):
     return None
 
 
-def _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device, BC_mode=2):
-    """Host-resident state, wavefront schedule (cytvdn_amd/wavefront.py): no stopping rule, no reference_data."""
+def _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device, BC_mode=2,
+                   reference_data=None):
+    """Host-resident state, wavefront schedule (cytvdn_amd/wavefront.py): anything but a stopping rule."""
     from .wavefront import WavefrontRunner
     dtype = datacube.dtype
     n_total = n_fista + n_plain
     rows, k = plan
     wr = WavefrontRunner(datacube, FISTA, lambdaInv, lam_mu, device=device, chunk_rows=rows, k=k, max_iters=n_total,
-                         bc_mode=int(BC_mode))
+                         bc_mode=int(BC_mode), reference=reference_data)
     wr.run(n_fista if FISTA else 0, n_plain if unaccelerated else 0)
     sums = wr.sums()[:n_total] if n_total else np.zeros((0, 3))
     b_norm = sums[:, 0].astype(dtype)
     with np.errstate(divide="ignore", invalid="ignore"):
         delta_recon = (sums[:, 1].astype(dtype) / sums[:, 2].astype(dtype)).astype(dtype)
+    if reference_data is not None:
+        return wr.recon(), b_norm, delta_recon, wr.mse().astype(dtype)
     return wr.recon(), b_norm, delta_recon
 
 

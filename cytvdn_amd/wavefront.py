@@ -12,8 +12,8 @@ axis; in the compact FISTA state level j's `d_j` also serves as `d_prev` of leve
 window of the input.  The sweeps are the same `tvdn_iterate_fused` launches as everywhere else: windows are
 presented to the kernel as row ranges of virtual arrays by offsetting the base pointers, so the arithmetic
 -- and the bits -- are those of the in-core engine.  Jia-Zhao and (single process) periodic BC; slabs across
-ranks; no per-iteration host decisions (no stopping rule, no reference_data): `driver._run_staged` falls back
-to the trapezoid engine for those.
+ranks; `reference_data` traces; no per-iteration host decisions (a stopping rule makes `driver._run_staged`
+fall back to the trapezoid engine with k = 1).
 """
 from __future__ import annotations
 
@@ -62,7 +62,7 @@ class WavefrontRunner:
 
     def __init__(self, datacube: np.ndarray, fista: bool, clip, lam_mu, device: int = 0, chunk_rows: int = 16,
                  k: int = 32, max_iters: int = 1, pin: bool = True, global_rows: int = None, row0: int = 0,
-                 group=None, world: int = 1, rank: int = 0, bc_mode: int = 2):
+                 group=None, world: int = 1, rank: int = 0, bc_mode: int = 2, reference: np.ndarray = None):
         """Slab mode (`world` > 1): `datacube` holds this rank's own rows [row0, row0+rows) of a cube with
         `global_rows` rows.  The host arrays then carry up to k extra rows per interior side, refreshed from the
         neighbouring ranks before every pass; at those artificial faces the wavefront gives up one row per
@@ -124,6 +124,9 @@ class WavefrontRunner:
         self.recon_h = [host(np.ascontiguousarray(datacube)), host()]
         n_state = 2 if self.fista else 1
         self.state_h = [[[host() for _ in range(n_state)] for _ in range(self.nd)] for _ in range(2)]
+        self.ref_h = host(np.ascontiguousarray(reference)) if reference is not None else None
+        self.mse_dev = torch.zeros(self.max_iters + 1, dtype=torch.float64, device=dev) if reference is not None else None
+        self._sse_tmp = torch.zeros(1, dtype=torch.float64, device=dev)
         self.h_old = 0
         self.d_form = self.fista
         self.tk_prev = 0.0
@@ -147,7 +150,8 @@ class WavefrontRunner:
         self.Rw = [_Window(cap, plane, tdt, dev) for _ in range(K + 1)]
         self.Aw = [[_Window(cap, plane, tdt, dev) for _ in range(self.nd)] for _ in range(K + 2)]  # index level + 1
         self.Ow = _Window(self.R + K + 3, plane, tdt, dev)
-        n_in = 2 + 2 * self.nd
+        self.Fw = _Window(self.R + K + 3, plane, tdt, dev) if reference is not None else None   # reference_data rows
+        n_in = 3 + 2 * self.nd
         n_out = 1 + 2 * self.nd
         self.inbox = [[torch.empty((self.R,) + tuple(plane), dtype=tdt, device=dev) for _ in range(n_in)] for _ in range(2)]
         self.outbox = [[torch.empty((self.R,) + tuple(plane), dtype=tdt, device=dev) for _ in range(n_out)] for _ in range(2)]
@@ -161,6 +165,12 @@ class WavefrontRunner:
         for t in arrays:
             t[lo - depth:lo].copy_(t[hi - depth:hi])
             t[hi:hi + depth].copy_(t[lo:lo + depth])
+
+    def _sse(self, a: torch.Tensor, b: torch.Tensor, slot: int):
+        """mse[slot] += sum((a - b)^2) over two equally shaped row blocks (sum_square_error, utils.pyx:14-49)."""
+        _lib.check(_lib.lib().tvdn_sum_square_error(self.ctx, self.code, self.nd, _lib.shape_arr(a.shape), a.data_ptr(),
+                                                    b.data_ptr(), self._sse_tmp.data_ptr(), _lib.current_stream(self.device)))
+        self.mse_dev[slot:slot + 1] += self._sse_tmp
 
     def device_bytes(self) -> int:
         n = (len(self.Rw) + len(self.Aw) * self.nd) * self.Rw[0].buf.numel() + self.Ow.buf.numel()
@@ -236,7 +246,7 @@ class WavefrontRunner:
                 prev_ratio = tk
         n_in_state = 2 if forms[0] else 1
         n_out_state = 2 if forms[kk] else 1
-        for w in self.Rw[:kk + 1] + [x for lvl in self.Aw[:kk + 2] for x in lvl] + [self.Ow]:
+        for w in self.Rw[:kk + 1] + [x for lvl in self.Aw[:kk + 2] for x in lvl] + [self.Ow] + ([self.Fw] if self.Fw else []):
             w.base = w.top = 0
         n_chunks = (E1 - E0 + kk + R - 1) // R
 
@@ -264,6 +274,9 @@ class WavefrontRunner:
                     for s in range(n_in_state):
                         box[i][:n].copy_(self.state_h[old][q][s][u0 - hb:u1 - hb], non_blocking=True)
                         i += 1
+                if self.ref_h is not None:
+                    box[-1][:n].copy_(self.ref_h[u0 - hb:u1 - hb], non_blocking=True)
+                    i += 1
                 self.bytes_h2d += i * n * self.row_bytes
                 ev = torch.cuda.Event()
                 ev.record(self.up)
@@ -281,6 +294,8 @@ class WavefrontRunner:
                 for q in range(nd):
                     self.Aw[j + 1][q].slide(nb)
             self.Ow.slide(max(0, E0 + c * R - kk - 1))
+            if self.Fw is not None:
+                self.Fw.slide(max(0, E0 + c * R - kk - 1))
             if u0 < u1:
                 n = u1 - u0
                 box = self.inbox[c % 2]
@@ -294,6 +309,13 @@ class WavefrontRunner:
                     if n_in_state == 2:
                         self.Aw[0][q].rows(u0, u1).copy_(box[i][:n])      # level -1: d_k-1
                         i += 1
+                if self.Fw is not None:
+                    self.Fw.rows(u0, u1).copy_(box[-1][:n])
+                    self.Fw.top = u1
+                    if self.iters_done == 0:   # MSE[0]: the input against the reference (cyTVDN.py:124-125), own rows
+                        o0, o1 = max(u0, g0), min(u1, g1)
+                        if o0 < o1:
+                            self._sse(self.Rw[0].rows(o0, o1), self.Fw.rows(o0, o1), 0)
                 ev = torch.cuda.Event()
                 ev.record(main)
                 in_free[c % 2] = ev
@@ -310,6 +332,8 @@ class WavefrontRunner:
                 for x0, x1, slot in ((a, min(b, g0), discard), (max(a, g0), min(b, g1), slot0 + j), (max(a, g1), b, discard)):
                     if x0 < x1:
                         self._launch(j, x0, x1, ratios[j], tkp[j], modes[j], slot)
+                        if self.Fw is not None and slot != discard:
+                            self._sse(self.Fw.rows(x0, x1), self.Rw[j + 1].rows(x0, x1), slot + 1)
                 self.Rw[j + 1].top = b
                 for q in range(nd):
                     self.Aw[j + 2][q].top = b
@@ -362,6 +386,13 @@ class WavefrontRunner:
     def sums(self) -> np.ndarray:
         """[max_iters, 3] f64 sums over the own rows (all-reduced over the ranks in slab mode)."""
         t = self.sums_dev[: self.max_iters].clone()
+        if self.world > 1:
+            t = t if self.dist.get_backend(self.group) != "gloo" else t.cpu()
+            self.dist.all_reduce(t, group=self.group)
+        return t.cpu().numpy()
+
+    def mse(self) -> np.ndarray:
+        t = self.mse_dev.clone()
         if self.world > 1:
             t = t if self.dist.get_backend(self.group) != "gloo" else t.cpu()
             self.dist.all_reduce(t, group=self.group)

@@ -83,17 +83,20 @@ def test_wavefront_periodic(oracle, monkeypatch, shape, dtype, its, fista, rows,
     ((5, 3, 4, 8), "float32", 12, True, 16, 5),               # chunk taller than the cube
 ])
 def test_wavefront_equals_in_core(oracle, monkeypatch, shape, dtype, its, fista, rows, k):
-    """The wavefront (parallelogram) schedule: every row of every iteration level computed once, still bit-identical."""
+    """The wavefront (parallelogram) schedule: every row of every iteration level computed once, still bit-identical
+    (recon and the b_norm / delta_recon / MSE traces)."""
     import cytvdn_amd as tv
     from cytvdn_amd import synth
     dt = np.dtype(dtype)
     nd = len(shape)
     x = synth.cube(shape, seed=57, dtype=dt) + dt.type(0.25)
+    refd = synth.cube(shape, seed=57, dtype=dt, kind="mean") if (rows + k) % 2 else None
     mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
     fn = tv.denoise4D if nd == 4 else tv.denoise3D
-    want = fn(x, mu, its, FISTA=fista, quiet=True)
+    want = fn(x, mu, its, FISTA=fista, reference_data=refd, quiet=True)
     monkeypatch.setenv("TVDN_WAVEFRONT", f"{rows},{k}")
-    got = fn(x, mu, its, FISTA=fista, quiet=True)
+    got = fn(x, mu, its, FISTA=fista, reference_data=refd, quiet=True)
+    assert len(got) == len(want)
     assert bits_equal(got[0], want[0])
     ref = oracle.denoise(x, mu, its, fista)
     assert bits_equal(got[0], ref["recon"])
