@@ -285,3 +285,49 @@ def test_plain_c_caller_of_the_abi(tv, tmp_path):
         h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert int(got["iters_run"]) == iters
     assert got["recon_fnv1a"] == f"{h:016x}"
+
+
+def test_c_abi_error_paths_and_timing(tv):
+    """Status codes and messages of the C ABI for bad arguments (nothing is launched), and the HIP-event timing aid."""
+    import ctypes as C
+    import torch
+    from cytvdn_amd import _lib
+    L, ctx = _lib.lib(), _lib.ctx(0)
+    t = [torch.zeros((4, 3, 2, 8), dtype=torch.float32, device="cuda") for _ in range(12)]
+    out = torch.zeros(4, dtype=torch.float64, device="cuda")
+    sh = _lib.shape_arr((4, 3, 2, 8))
+
+    def err():
+        return L.tvdn_last_error().decode()
+
+    assert L.tvdn_accumulator_update(ctx, 0, 4, sh, t[0].data_ptr(), t[1].data_ptr(), None, 0.0, 7, 1.0, 2, out.data_ptr(), None) == -1
+    assert "ax = 7" in err()
+    assert L.tvdn_accumulator_update(ctx, 0, 4, sh, t[0].data_ptr(), t[1].data_ptr(), None, 0.0, 0, 1.0, 5, out.data_ptr(), None) == -1
+    assert L.tvdn_accumulator_update(ctx, 3, 4, sh, t[0].data_ptr(), t[1].data_ptr(), None, 0.0, 0, 1.0, 2, out.data_ptr(), None) == -1
+    bp = (C.c_void_p * 4)(*[x.data_ptr() for x in t[2:6]])
+    lm = (C.c_double * 4)(0.03, 0.03, 0.03, 0.03)
+    assert L.tvdn_datacube_update(ctx, 0, 4, sh, t[0].data_ptr(), t[1].data_ptr(), bp, lm, 1, out.data_ptr(), None) == -2
+    assert "mirror" in err()
+    a = _lib.IterArgs(dtype=0, ndim=4, row_lo=0, row_hi=4, lo_mode=0, hi_mode=0, bc_mode=2, mode=_lib.ITER_FISTA_D)
+    for i, s in enumerate((4, 3, 2, 8)):
+        a.shape[i] = s
+    a.orig, a.recon_in, a.recon_out = t[0].data_ptr(), t[1].data_ptr(), t[1].data_ptr()
+    assert L.tvdn_iterate_fused(ctx, C.byref(a), out.data_ptr(), None) == -1 and "not in-place" in err()
+    a.recon_out = t[2].data_ptr()
+    assert L.tvdn_iterate_fused(ctx, C.byref(a), out.data_ptr(), None) == -1 and "d_in" in err()       # missing state
+    a.row_hi = 9
+    assert L.tvdn_iterate_fused(ctx, C.byref(a), out.data_ptr(), None) == -1 and "own rows" in err()
+    a.row_hi, a.hi_mode, a.bc_mode = 4, _lib.EDGE_ZERO, 0
+    assert L.tvdn_iterate_fused(ctx, C.byref(a), out.data_ptr(), None) == -1 and "Jia-Zhao" in err()
+    a.hi_mode, a.bc_mode, a.mode = 0, 2, 9
+    assert L.tvdn_iterate_fused(ctx, C.byref(a), out.data_ptr(), None) == -1 and "bad mode" in err()
+    # timing aid: one valid call bracketed by events
+    a.mode = _lib.ITER_PLAIN
+    for q in range(4):
+        a.b_in[q], a.b_out[q] = t[3 + q].data_ptr(), t[7 + q].data_ptr()
+        a.clip[q], a.lambda_mu[q] = 32.0, 1 / 32
+    assert L.tvdn_ctx_timing_enable(ctx, 1) == 0
+    assert L.tvdn_iterate_fused(ctx, C.byref(a), out.data_ptr(), _lib.current_stream(0)) == 0
+    ms, n = C.c_double(), C.c_int64()
+    assert L.tvdn_ctx_timing_read(ctx, C.byref(ms), C.byref(n)) == 0 and n.value == 1 and ms.value > 0
+    assert L.tvdn_ctx_timing_enable(ctx, 0) == 0
