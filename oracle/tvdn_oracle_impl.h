@@ -52,27 +52,47 @@ void FN(orc_accumulator_update)(const T *a, T *b, T *d, T tk, int ax, T clip, in
     T norm = (T)0;
     double norm64 = 0.0;
 
+    const T *restrict ar = a;
+    T *restrict br = b;
+    T *restrict dr = d;
+    if (d) {
 #if defined(_OPENMP)
 #pragma omp parallel for reduction(+ : norm, norm64) schedule(static) num_threads(nthreads)
 #endif
-    for (int64_t ij = 0; ij < outer; ++ij) {
-        const int64_t i = start[0] + ij / outer1;
-        const int64_t j = start[1] + ij % outer1;
-        for (int64_t k = start[2]; k < N2; ++k) {
-            for (int64_t l = start[3]; l < N3; ++l) {
-                const int64_t x = i * st[0] + j * st[1] + k * st[2] + l;
-                T v = (a[x] - a[x - back]) + b[x];
-                T dn = FN(orc_clip)(v, clip);
-                T bn;
-                if (d) {
-                    bn = dn + tk * (dn - d[x]);
-                    d[x] = dn;
-                } else {
-                    bn = dn;
+        for (int64_t ij = 0; ij < outer; ++ij) {
+            const int64_t i = start[0] + ij / outer1;
+            const int64_t j = start[1] + ij % outer1;
+            for (int64_t k = start[2]; k < N2; ++k) {
+                const int64_t x0 = i * st[0] + j * st[1] + k * st[2];
+                for (int64_t l = start[3]; l < N3; ++l) {
+                    const int64_t x = x0 + l;
+                    const T v = (ar[x] - ar[x - back]) + br[x];
+                    const T dn = FN(orc_clip)(v, clip);
+                    const T bn = dn + tk * (dn - dr[x]);
+                    dr[x] = dn;
+                    br[x] = bn;
+                    norm += (T)fabs((double)bn);
+                    norm64 += fabs((double)bn);
                 }
-                b[x] = bn;
-                norm += (T)fabs((double)bn);
-                norm64 += fabs((double)bn);
+            }
+        }
+    } else {
+#if defined(_OPENMP)
+#pragma omp parallel for reduction(+ : norm, norm64) schedule(static) num_threads(nthreads)
+#endif
+        for (int64_t ij = 0; ij < outer; ++ij) {
+            const int64_t i = start[0] + ij / outer1;
+            const int64_t j = start[1] + ij % outer1;
+            for (int64_t k = start[2]; k < N2; ++k) {
+                const int64_t x0 = i * st[0] + j * st[1] + k * st[2];
+                for (int64_t l = start[3]; l < N3; ++l) {
+                    const int64_t x = x0 + l;
+                    const T v = (ar[x] - ar[x - back]) + br[x];
+                    const T bn = FN(orc_clip)(v, clip);
+                    br[x] = bn;
+                    norm += (T)fabs((double)bn);
+                    norm64 += fabs((double)bn);
+                }
             }
         }
     }
