@@ -161,3 +161,43 @@ def test_denoise_slabs_api_matches_single_process(oracle, world, shape, dtype, i
         assert np.array_equal(p["dl"] == 0, ref["delta_recon"] == 0)          # same iteration count on every rank
         np.testing.assert_allclose(p["dl"], ref["delta_recon"], rtol=1e-4 if dt == np.float32 else 1e-12)
         np.testing.assert_allclose(p["bn"], ref["b_norm"], rtol=1e-4 if dt == np.float32 else 1e-12)
+
+
+from hypothesis import given, settings, strategies as st
+
+
+@settings(max_examples=200, deadline=None, derandomize=True)
+@given(n0=st.integers(1, 300), world=st.integers(1, 16), bc=st.sampled_from([0, 2]))
+def test_layout_invariants(n0, world, bc):
+    """Slabs tile axis 0 exactly, neighbours are mutual, halo rows hold the neighbour's edge rows."""
+    if n0 < world:
+        with pytest.raises(ValueError):
+            SlabLayout((n0, 2, 3), 0, world, bc)
+        return
+    lays = [SlabLayout((n0, 2, 3), r, world, bc) for r in range(world)]
+    assert lays[0].g0 == 0 and lays[-1].g1 == n0
+    for a, b in zip(lays, lays[1:]):
+        assert a.g1 == b.g0 and a.own_rows >= 1
+    assert sum(l.own_rows for l in lays) == n0
+    for l in lays:
+        rows = l.local_rows_global()
+        assert len(rows) == l.local_shape[0] == l.halo_lo + l.own_rows + l.halo_hi
+        assert list(rows[l.row_lo:l.row_hi]) == list(range(l.g0, l.g1))
+        if l.left is not None:
+            assert lays[l.left].right == l.rank and rows[0] == (l.g0 - 1) % n0 == lays[l.left].g1 - 1
+        if l.right is not None:
+            assert lays[l.right].left == l.rank and rows[-1] == l.g1 % n0 == lays[l.right].g0
+        if world == 1:
+            assert l.halo_lo == l.halo_hi == 0 and l.lo_mode == _lib.EDGE_BC and l.hi_mode == _lib.EDGE_BC
+        elif bc == 2:
+            assert (l.lo_mode == _lib.EDGE_BC) == (l.rank == 0)
+            assert l.hi_mode == (_lib.EDGE_ZERO if l.rank == world - 1 else _lib.EDGE_HALO)
+        else:
+            assert l.lo_mode == l.hi_mode == _lib.EDGE_HALO
+
+
+def test_block_and_wavefront_plans():
+    from cytvdn_amd.outofcore import plan_blocks
+    assert plan_blocks(10, 4) == [(0, 4), (4, 8), (8, 10)]
+    assert plan_blocks(3, 8) == [(0, 3)]
+    assert plan_blocks(5, 0) == [(i, i + 1) for i in range(5)]
