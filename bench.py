@@ -7,19 +7,35 @@ A "step" is one full TV iteration (all four accumulator updates + the reconstruc
 its convergence reductions) over the device-resident synthetic 4D-STEM cube.
   N = 1   BASELINE.json configs[1]: denoise4D FISTA, float32, 256x256x128x128 (2^30 voxels).
   N > 1   the configs[3] family, weak scaling: float32, (64*N)x512x256x256, one 64-row slab
-          (2^31 voxels) per GPU, RCCL halo exchange each step (driver launches one rank per GPU).
+          (2^31 voxels) per GPU, RCCL halo exchange each step under the interior sweep.  The driver
+          launches one rank per GPU with torch.distributed.run; a plain `python bench.py --gpus N`
+          starts those N ranks itself (as child processes, before anything touches a GPU).
 Inputs are synthesised in HBM before the timed region (cytvdn_amd.synth on the device).
-Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (19 array passes
-x 4 B = 76 B per voxel) / mean duration of the fused sweep kernel, taken from HIP
-events recorded around that kernel on its own stream during the timed steps.
-`cpu_baseline` (N = 1 only) times the reference's own compiled kernels (oracle/_ref, kind
-"reference") -- or, when they are absent, this repo's C restatement (kind "port") -- on the
-host cores of the same box over a bounded sample of the same workload.
+Rank 0 prints ONE JSON line.
+
+roofline.achieved = ALGORITHMIC bytes per launch (every array of the reference's state read
+once and written once = 19 passes x 4 B = 76 B per voxel for 4-D FISTA f32) / mean duration of the fused
+sweep kernel, from HIP events recorded around that kernel on its own stream during the timed steps.
+The compact state of this engine moves fewer bytes than that yardstick (15 passes = 60 B per voxel); what the
+kernel really streams is reported next to it as roofline.moved_GBps / roofline.moved_frac.
+
+At N = 1 the line also carries
+  also          the other single-GPU configurations on the same clock: BASELINE configs[2] (float64,
+                unaccelerated), the configs[0] shape on the GPU (3-D FISTA 128x128x512), and ONE slab of
+                configs[3] (66x512x256x256 local block, halo edges, edge rows first, halo rows refreshed by
+                device copies of the same size as the RCCL messages) = the per-GPU term of the weak-scaling curve
+  cpu_baseline  the reference-structured CPU restatement (oracle/libtvdn_oracle_timed.so, kind "port": the
+                reference's five passes per iteration, its visiting order, dtype-width sums and serial
+                boundary hyperslab) on the host cores of the same box, on config 2 itself when the host has
+                the memory for it; when oracle/_ref (the reference's own compiled kernels) is present they are
+                timed on the same arrays and reported beside it.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,8 +44,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-BYTES_PER_VOXEL_ITER = {("f32", True, 4): 76, ("f64", True, 4): 152, ("f32", False, 4): 44, ("f64", False, 4): 88,
-                        ("f32", True, 3): 60, ("f32", False, 3): 36}
 
 
 def parse():
@@ -43,8 +57,13 @@ def parse():
     ap.add_argument("--state", type=str, default="compact", choices=["compact", "reference"],
                     help="accumulator state in HBM: compact = rotating d arrays (15 passes per 4-D FISTA iteration), "
                          "reference = the reference's (b, d) pairs (19 passes)")
+    ap.add_argument("--slab-of", type=int, default=0, metavar="N",
+                    help="single GPU: run ONE interior slab of an N-slab job (halo edges, edge rows first, halo rows "
+                         "refreshed by device copies) instead of the whole cube; --shape is then the GLOBAL shape")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra single-GPU configurations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of each timed CPU leg")
+    ap.add_argument("--no-preflight", action="store_true", help="N > 1: skip the bit-exactness check of the exchange")
     return ap.parse_args()
 
 
@@ -60,205 +79,379 @@ def host_cores():
     return n
 
 
-def cpu_baseline(target_s):
-    """Reference OpenMP kernels (or the port) on a bounded sample: 32x128x128x128 f32 FISTA."""
+def mem_available_gib():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) / 2 ** 20
+                break
+        else:
+            return 0.0
+        try:  # a cgroup limit may be tighter than the machine
+            lim = open("/sys/fs/cgroup/memory.max").read().strip()
+            if lim != "max":
+                cur = int(open("/sys/fs/cgroup/memory.current").read())
+                avail = min(avail, (int(lim) - cur) / 2 ** 30)
+        except Exception:
+            pass
+        return avail
+    except Exception:
+        return 0.0
+
+
+# --------------------------------------------------------------------------------------------------
+# CPU baseline
+# --------------------------------------------------------------------------------------------------
+def cpu_baseline(target_s, x_host=None):
+    """The reference's loop body (cyTVDN/cyTVDN.py:153-184) on the host cores: config 2 itself (2^30 voxels, 40 GiB
+    of state in the reference's representation) when `x_host` is given, else a 1/16 sample of it."""
     import numpy as np
-    cores = host_cores()
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    os.environ.setdefault("OMP_PROC_BIND", "spread")
-    os.environ.setdefault("OMP_PLACES", "cores")
     from oracle import oracle
     from cytvdn_amd import synth
-    shape = (32, 128, 128, 128)               # 2^26 voxels, 2.5 GiB of state: far beyond the host caches
-    x = synth.stem4d(shape, dtype=np.float32)
+    cores = int(os.environ["OMP_NUM_THREADS"])
+    oracle.build()
+    oracle.set_threads(cores)
+    if x_host is not None:
+        x, what = x_host, "BASELINE config 2 in full"
+    else:
+        x, what = synth.stem4d((16, 256, 128, 128), dtype=np.float32), "a 16-row slice (1/16) of config 2: host memory is short"
+    shape = x.shape
     mu = np.array([1.0, 1.0, 0.5, 0.5], np.float32)
     lam = mu / np.float32(32.0)
     lam_inv, lam_mu = 1.0 / lam, (lam / mu).astype(np.float32)
-    kind = "port"
-    k = None
-    if oracle.have_reference_kernels():
-        try:
-            k = oracle.load_reference_kernels()
-            kind = "reference"
-        except Exception:
-            k = None
-    if k is None:
-        oracle.build()
-        oracle.set_threads(int(os.environ["OMP_NUM_THREADS"]))
-        k = oracle
-    acc = [np.zeros_like(x) for _ in range(4)]
-    dd = [np.zeros_like(x) for _ in range(4)]
-    recon = x.copy()
-    ratios = oracle.fista_schedule(256)
-
-    def one(i):  # the reference's loop body, cyTVDN/cyTVDN.py:153-184
-        for ax in range(4):
-            k.accumulator_update_4D_FISTA(recon, acc[ax], dd[ax], ratios[i], ax, lam_inv[ax], BC_mode=2)
-        k.datacube_update_4D(x, recon, acc[0], acc[1], acc[2], acc[3], lam_mu, BC_mode=2)
-
-    one(0)                                   # first touch of the state arrays (page faults), untimed
-    t0 = time.perf_counter()
-    one(1)
-    one(2)
-    t1 = (time.perf_counter() - t0) / 2
-    n = int(max(5, min(250, target_s / max(t1, 1e-3))))
-    t0 = time.perf_counter()
-    for i in range(3, n + 3):
-        one(i)
-    dt = time.perf_counter() - t0
+    ratios = oracle.fista_schedule(4096)
     vox = float(np.prod(shape))
-    return dict(value=vox * n / dt / 1e9, unit="Gvoxel-iters/s", cores=int(os.environ["OMP_NUM_THREADS"]), kind=kind,
-                sample=f"denoise4D FISTA f32 {'x'.join(map(str, shape))} synthetic 4D-STEM, {n} iterations, "
-                       f"{dt:.1f} s, OMP_NUM_THREADS={os.environ['OMP_NUM_THREADS']}")
+
+    def leg(k, budget_s):
+        acc = [np.zeros_like(x) for _ in range(4)]
+        dd = [np.zeros_like(x) for _ in range(4)]
+        recon = x.copy()
+
+        def one(i):
+            for ax in range(4):
+                k.accumulator_update_4D_FISTA(recon, acc[ax], dd[ax], ratios[i], ax, lam_inv[ax], BC_mode=2)
+            k.datacube_update_4D(x, recon, acc[0], acc[1], acc[2], acc[3], lam_mu, BC_mode=2)
+
+        one(0)                                   # first touch of the state arrays (page faults), untimed
+        t0 = time.perf_counter()
+        one(1)
+        t1 = time.perf_counter() - t0
+        n = int(max(5, min(500, budget_s / max(t1, 1e-3))))
+        t0 = time.perf_counter()
+        for i in range(2, n + 2):
+            one(i)
+        dt = time.perf_counter() - t0
+        return vox * n / dt / 1e9, n, dt
+
+    v, n, dt = leg(oracle.timed_kernels(), target_s)
+    out = dict(value=v, unit="Gvoxel-iters/s", cores=cores, kind="port",
+               sample=f"denoise4D FISTA f32 {'x'.join(map(str, shape))} synthetic 4D-STEM ({what}), {n} iterations, "
+                      f"{dt:.1f} s, OMP_NUM_THREADS={cores}; oracle/libtvdn_oracle_timed.so = the reference's five "
+                      f"passes, visiting order, dtype-width sums and serial boundary hyperslab")
+    if oracle.have_reference_kernels():
+        try:  # the reference's own compiled kernels, when they travelled: same arrays, same loop
+            rv, rn, rdt = leg(oracle.load_reference_kernels(), min(target_s, 8.0))
+            out["reference_kernels"] = dict(value=rv, iterations=rn, seconds=round(rdt, 1),
+                                            port_over_reference=round(v / rv, 3))
+        except Exception as e:
+            out["reference_kernels"] = dict(error=repr(e))
+    return out
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# --------------------------------------------------------------------------------------------------
+# GPU measurement of one workload
+# --------------------------------------------------------------------------------------------------
+def passes_algorithmic(nd, fista):
+    """arrays of the reference's state, each read once and written once."""
+    return (2 + 2 * nd) + (1 + 2 * nd) if fista else (2 + nd) + (1 + nd)
 
-    cpu = None
-    if world == 1 and rank == 0 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.cpu_seconds)   # before the GPU is touched: libgomp reads OMP_* at load
 
+def passes_moved(nd, fista, state):
+    return 3 + nd * ((3 if state == "compact" else 4) if fista else 2)
+
+
+def workload_name(shape, dtype_name, fista, world=1, slab_of=0):
+    nd = len(shape)
+    s = (f"denoise{nd}D anisotropic {'FISTA' if fista else 'unaccelerated'} {dtype_name} "
+         f"{'x'.join(map(str, shape))} synthetic {'4D-STEM' if nd == 4 else 'EELS'}")
+    if world > 1:
+        s += f", {world} slabs along axis 0"
+    if slab_of:
+        s += f", ONE interior slab of {slab_of} on a single GPU"
+    return s
+
+
+class EmulatedNeighbours:
+    """Single GPU, one interior slab of a larger job: the same three launches per iteration as `step_overlapped`
+    (two edge rows, then the interior) with the two halo rows refreshed on a side stream by device copies of the
+    size of the RCCL messages (content: the slab's own edge rows; only the timing is meaningful)."""
+
+    def __init__(self, be):
+        import torch
+        self.be, self.torch = be, torch
+        self.side = torch.cuda.Stream(device=be.device)
+
+    def _step(self, tk, slot):
+        torch, be = self.torch, self.be
+        lay = be.layout
+        lo, hi = lay.row_lo, lay.row_hi
+        main = torch.cuda.current_stream(be.device)
+        main.wait_stream(self.side)
+        be.step(tk, slot, rows=(lo, lo + 1), accumulate=False)
+        be.step(tk, slot, rows=(hi - 1, hi), accumulate=True)
+        done = torch.cuda.Event()
+        done.record(main)
+        r = be.recon_next()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(done)
+            r[hi].copy_(r[lo], non_blocking=True)
+            r[lo - 1].copy_(r[hi - 1], non_blocking=True)
+        be.step(tk, slot, rows=(lo + 1, hi - 1), accumulate=True)
+        be.flip()
+
+    def finish(self):
+        self.torch.cuda.current_stream(self.be.device).wait_stream(self.side)
+
+    def global_sums(self):
+        self.finish()
+        return self.be.sums_tensor().clone()
+
+
+def measure(shape, dtype_name, fista, state, steps, warmup, device, rank=0, world=1, group=None, ctl=None,
+            slab_of=0, overlap=True, traffic_table=None):
+    """Runs warmup + steps iterations of one workload on this rank's slab; returns the result dict (same on all ranks)."""
     import numpy as np
     import torch
     import torch.distributed as dist
     from cytvdn_amd import _lib, synth
-    if not os.path.exists(_lib.LIB_PATH):       # fresh checkout: compile the HIP library in-tree (hipcc, ~20 s)
-        if rank == 0:
-            _lib.build()
-        while not os.path.exists(_lib.LIB_PATH):
-            time.sleep(1.0)
     from cytvdn_amd.engine import HipBackend, SlabLayout, SlabRunner, fista_ratios
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: cytvdn_amd has no CPU fallback")
-    backend = os.environ.get("TVDN_DIST_BACKEND", "nccl")   # "gloo": rehearsal with host-staged halo rows
-    if backend != "nccl":
-        local_rank %= torch.cuda.device_count()             # several ranks may then share one GPU
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        if backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-                dist.barrier()  # first collective with every rank taking part (batched P2P must not be the first one)
-                torch.cuda.synchronize()
-            except Exception as e:  # RCCL unusable on this node: still produce a (slower) number over gloo
-                print(f"[bench] RCCL initialisation failed ({e!r}); falling back to gloo with host-staged halo rows",
-                      file=sys.stderr, flush=True)
-                try:
-                    dist.destroy_process_group()
-                except Exception:
-                    pass
-                backend = "gloo"
-                dist.init_process_group("gloo")
-                dist.barrier()
-        else:
-            dist.init_process_group(backend)
-            dist.barrier()
-
-    dtype = np.float32 if a.dtype == "f32" else np.float64
-    if a.shape:
-        shape = tuple(int(v) for v in a.shape.lower().split("x"))
-    elif world == 1:
-        shape = (256, 256, 128, 128)
-    else:
-        shape = (64 * world, 512, 256, 256)
+    dtype = np.float32 if dtype_name == "f32" else np.float64
     nd = len(shape)
-    fista = not a.plain
-    workload = (f"denoise{nd}D anisotropic {'FISTA' if fista else 'unaccelerated'} {a.dtype} "
-                f"{'x'.join(map(str, shape))} synthetic {'4D-STEM' if nd == 4 else 'EELS'}"
-                + (f", {world} slabs along axis 0" if world > 1 else ""))
-
-    lay = SlabLayout(shape, rank, world, 2)
-    be = HipBackend(lay, dtype, fista, device=local_rank, max_iters=a.steps + a.warmup, state=a.state)
-    mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dtype)
+    if slab_of:
+        lay = SlabLayout(shape, slab_of // 2, slab_of, 2)
+    else:
+        lay = SlabLayout(shape, rank, world, 2)
+    be = HipBackend(lay, dtype, fista, device=device, max_iters=steps + warmup, state=state)
+    mu = np.array([1.0, 1.0, 0.5, 0.5] if nd == 4 else [1.0, 1.0, 0.5], dtype)
     lam = mu / dtype(32.0 if nd == 4 else 16.0)
     be.set_params(1.0 / lam, (lam / mu).astype(dtype))
     # synthesise this slab (halo rows included) directly in HBM: global rows g0-halo .. g1+halo
-    g_first = lay.g0 - lay.halo_lo
-    rows = lay.local_shape[0]
     seed = synth.SEED_4D if nd == 4 else synth.SEED_3D
-    _lib.check(_lib.lib().tvdn_synth_fill(be.code, nd, _lib.shape_arr(shape), seed, g_first, rows,
-                                          be.orig.data_ptr(), _lib.current_stream(local_rank)))
+    _lib.check(_lib.lib().tvdn_synth_fill(be.code, nd, _lib.shape_arr(shape), seed, lay.g0 - lay.halo_lo,
+                                          lay.local_shape[0], be.orig.data_ptr(), _lib.current_stream(device)))
     be.recon[be.cur].copy_(be.orig)
-    runner = SlabRunner(be)
-    ratios = fista_ratios(a.steps + a.warmup)
+    if slab_of:
+        runner = EmulatedNeighbours(be)
+    else:
+        runner = SlabRunner(be, group)
+        runner.overlap = overlap
+    ratios = fista_ratios(steps + warmup)
 
     def step(i):
-        # world > 1: edge rows first, their RCCL transfer on a side stream under the interior sweep
         runner._step(float(ratios[i]) if fista else None, i)
 
     def fence():
         runner.finish()
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=ctl)
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
+    for i in range(warmup):
         step(i)
     fence()
     _lib.check(_lib.lib().tvdn_ctx_timing_enable(be.ctx, 1))
     t0 = time.perf_counter()
-    for i in range(a.warmup, a.warmup + a.steps):
+    for i in range(warmup, warmup + steps):
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
     tot_ms, nl = C.c_double(), C.c_int64()
     _lib.check(_lib.lib().tvdn_ctx_timing_read(be.ctx, C.byref(tot_ms), C.byref(nl)))
     _lib.check(_lib.lib().tvdn_ctx_timing_enable(be.ctx, 0))
-    # mean sweep-kernel time per iteration (with N > 1 an iteration is three launches: two edge rows + interior)
-    kern_ms = tot_ms.value / max(a.steps, 1)
-
-    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    # sweep-kernel time per iteration (a slab iteration is three launches: two edge rows + interior)
+    kern_ms = tot_ms.value / max(steps, 1)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kern_ms = float(t[0]), float(t[1])
-
-    sums = runner.global_sums().cpu().numpy()
-    total_vox = float(np.prod(shape))
+        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)      # control-plane group (gloo, host memory)
+        elapsed, kern_ms = float(t[0]), float(t[1])
+    sums = runner.global_sums().cpu().numpy()      # all-reduced over the data-plane group when world > 1
     own_vox = float(lay.own_rows) * float(np.prod(shape[1:]))
-    value = total_vox * a.steps / elapsed / 1e9
-    bpv = BYTES_PER_VOXEL_ITER.get((a.dtype, fista, nd))
-    achieved = own_vox * bpv / (kern_ms * 1e-3) / 1e9 if bpv else None
-    # bytes the sweep really has to move per voxel-iteration with the chosen state representation
-    item = 4 if a.dtype == "f32" else 8
-    passes = 3 + nd * ((3 if a.state == "compact" else 4) if fista else 2)
-    moved_bpv = passes * item
+    total_vox = own_vox if slab_of else float(np.prod(shape))
+    item = 4 if dtype_name == "f32" else 8
+    bpv = passes_algorithmic(nd, fista) * item
+    moved_bpv = passes_moved(nd, fista, state) * item
+    achieved = own_vox * bpv / (kern_ms * 1e-3) / 1e9
+    moved = own_vox * moved_bpv / (kern_ms * 1e-3) / 1e9
+    name = workload_name(shape, dtype_name, fista, world, slab_of)
     traffic = None
-    try:  # PMC-derived HBM bytes per launch, committed next to the rocprof CSVs they come from
-        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        traffic = tr.get(f"{workload}|{a.state}", {}).get("traffic_bytes")
+    if traffic_table:
+        traffic = traffic_table.get(f"{name}|{state}", {}).get("traffic_bytes")
+    last = warmup + steps - 1
+    res = {
+        "value": round(total_vox * steps / elapsed / 1e9, 3), "unit": "Gvoxel-iters/s",
+        "ms_per_step": round(elapsed / steps * 1e3, 4), "dtype": dtype_name,
+        "config": {"workload": name, "global_shape": list(shape), "local_block": list(lay.local_shape), "bc_mode": 2,
+                   "state_arrays": be.n_arrays(), "state": state,
+                   "parallelism": f"slab{world}" if world > 1 else ("one slab of %d" % slab_of if slab_of else "single")},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "kernel": "fused_iter_kernel", "kernel_ms": round(kern_ms, 4),
+                     "launches_per_step": int(nl.value // max(steps, 1)),
+                     "basis": f"SURVEY 8d algorithmic bytes: {passes_algorithmic(nd, fista)} array passes x {item} B = "
+                              f"{bpv} B per voxel-iteration (the reference's state, each array read once and written once)",
+                     "algorithmic_bytes_per_launch": own_vox * bpv,
+                     "moved_bytes_per_voxel": moved_bpv, "moved_bytes_per_launch": own_vox * moved_bpv,
+                     "moved_GBps": round(moved, 1), "moved_frac": round(moved / HBM_PEAK_GBS, 4)},
+        "check": {"b_norm_last": float(sums[last, 0]), "delta_last": float(sums[last, 1] / sums[last, 2])},
+    }
+    del runner, be
+    torch.cuda.empty_cache()
+    return res
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (nothing here has touched a GPU)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without a launcher: starting the ranks with: %s" % (a.gpus, " ".join(cmd)),
+          file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
+def init_groups(local_rank):
+    """Control plane over gloo (decisions, timing reductions, barriers); data plane over RCCL when EVERY rank can
+    bring it up -- the decision is taken collectively, so no rank is left behind in another backend.
+    Returns (data_group_or_None, transport, fallback_flag)."""
+    import torch
+    import torch.distributed as dist
+    want = os.environ.get("TVDN_DIST_BACKEND", "nccl")
+    dist.init_process_group("gloo")
+    dist.barrier()
+    if want != "nccl":
+        return None, "gloo", False
+    ok, g, err = 1, None, ""
+    try:
+        g = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier(group=g)   # first collective with every rank taking part (batched P2P must not be the first one)
+        torch.cuda.synchronize()
+    except Exception as e:
+        ok, err = 0, repr(e)
+    t = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if int(t[0]) == 1:
+        return g, "rccl", False
+    print(f"[bench] RCCL unusable on at least one rank ({err or 'another rank failed'}); ALL ranks fall back to gloo "
+          "with host-staged halo rows", file=sys.stderr, flush=True)
+    return None, "gloo", True
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(a))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # libgomp reads these when it is first loaded (numpy/torch pull it in): set them before any import
+    os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from cytvdn_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):       # fresh checkout: compile the HIP library in-tree (hipcc, ~30 s)
+        if local_rank == 0:
+            _lib.build()
+        while not os.path.exists(_lib.LIB_PATH):
+            time.sleep(1.0)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: cytvdn_amd has no CPU fallback")
+
+    want_backend = os.environ.get("TVDN_DIST_BACKEND", "nccl")
+    if want_backend != "nccl":
+        local_rank %= torch.cuda.device_count()             # rehearsal: several ranks may then share one GPU
+    torch.cuda.set_device(local_rank)
+    group, transport, fallback, preflight = None, None, False, None
+    overlap = True
+    if world > 1:
+        group, transport, fallback = init_groups(local_rank)
+        if not a.no_preflight:
+            from cytvdn_amd.distributed import selfcheck_exchange
+            preflight = selfcheck_exchange(group=group, device=local_rank)
+            if not preflight["overlap"]:
+                overlap = False                  # keep measuring, visibly, with the blocking exchange
+            if not preflight["blocking"] and rank == 0:
+                print(f"[bench] exchange self-check FAILED on {transport}: {preflight}", file=sys.stderr, flush=True)
+
+    dtype_name = a.dtype
+    if a.shape:
+        shape = tuple(int(v) for v in a.shape.lower().split("x"))
+    elif world == 1 and not a.slab_of:
+        shape = (256, 256, 128, 128)
+    else:
+        shape = (64 * max(world, a.slab_of), 512, 256, 256)
+    fista = not a.plain
+    try:
+        traffic_table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except Exception:
-        pass
+        traffic_table = None
+
+    main_res = measure(shape, dtype_name, fista, a.state, a.steps, a.warmup, local_rank, rank, world, group,
+                       None, a.slab_of, overlap, traffic_table)
+
+    also = None
+    headline = world == 1 and not a.slab_of and not a.shape and dtype_name == "f32" and fista
+    if headline and not a.no_also:
+        also = []
+        for shp, dn, fi, st_, wu, slab in (((256, 256, 128, 128), "f64", False, 20, 3, 0),     # BASELINE configs[2]
+                                           ((128, 128, 512), "f32", True, 200, 20, 0),         # configs[0] shape on the GPU
+                                           ((512, 512, 256, 256), "f32", True, 10, 2, 8)):     # one slab of configs[3]
+            try:
+                r = measure(shp, dn, fi, a.state, st_, wu, local_rank, slab_of=slab, traffic_table=traffic_table)
+                r["steps"], r["warmup"] = st_, wu
+                also.append(r)
+            except Exception as e:   # e.g. a smaller GPU: say so instead of failing the headline
+                also.append({"config": {"workload": workload_name(shp, dn, fi, 1, slab)}, "error": repr(e)})
+
+    cpu = None
+    if headline and rank == 0 and not a.no_cpu_baseline:
+        x_host = None
+        if mem_available_gib() >= 56.0:         # 10 arrays x 4 GiB + the input + slack
+            buf = torch.empty(shape, dtype=torch.float32, device="cuda")
+            from cytvdn_amd import synth
+            _lib.check(_lib.lib().tvdn_synth_fill(0, 4, _lib.shape_arr(shape), synth.SEED_4D, 0, shape[0],
+                                                  buf.data_ptr(), _lib.current_stream(local_rank)))
+            x_host = buf.cpu().numpy()
+            del buf
+            torch.cuda.empty_cache()
+        cpu = cpu_baseline(a.cpu_seconds, x_host)
+
     if rank == 0:
-        out = {
-            "metric": "Gvoxel-iters/s (4D aniso FISTA)", "value": round(value, 3), "unit": "Gvoxel-iters/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": workload, "global_shape": list(shape), "bc_mode": 2,
-                       "transport": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
-                       "state_arrays": be.n_arrays(), "state": a.state,
-                       "parallelism": f"slab{world}" if world > 1 else "single"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                         "traffic": traffic, "kernel": "fused_iter_kernel", "kernel_ms": round(kern_ms, 4),
-                         "algorithmic_bytes_per_launch": own_vox * bpv if bpv else None,
-                         "moved_bytes_per_voxel": moved_bpv,
-                         "moved_GBps": round(own_vox * moved_bpv / (kern_ms * 1e-3) / 1e9, 1)},
-            "cpu_baseline": cpu,
-            "check": {"b_norm_last": float(sums[a.warmup + a.steps - 1, 0]),
-                      "delta_last": float(sums[a.warmup + a.steps - 1, 1] / sums[a.warmup + a.steps - 1, 2])},
-        }
+        out = {"metric": "Gvoxel-iters/s (4D aniso FISTA)", "value": main_res["value"], "unit": "Gvoxel-iters/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": main_res["ms_per_step"],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name,
+               "data": "synthetic", "config": main_res["config"], "roofline": main_res["roofline"],
+               "cpu_baseline": cpu, "check": main_res["check"]}
+        if world > 1:
+            out["config"]["transport"] = transport
+            out["config"]["overlap"] = bool(overlap)
+            out["transport_fallback"] = bool(fallback)
+            out["preflight"] = preflight
+        if also is not None:
+            out["also"] = also
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

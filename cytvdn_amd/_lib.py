@@ -27,7 +27,7 @@ EXPORTS = (
     "tvdn_abi_version", "tvdn_last_error", "tvdn_device_count", "tvdn_ctx_create", "tvdn_ctx_destroy",
     "tvdn_ctx_timing_enable", "tvdn_ctx_timing_read",
     "tvdn_accumulator_update", "tvdn_datacube_update", "tvdn_sum_square_error", "tvdn_iterate_fused",
-    "tvdn_synth_fill", "tvdn_run",
+    "tvdn_synth_fill", "tvdn_run", "tvdn_copy_to_device", "tvdn_copy_to_host",
 )
 
 
@@ -99,6 +99,8 @@ def lib():
                                         C.c_void_p]
     L.tvdn_iterate_fused.argtypes = [C.c_void_p, C.POINTER(IterArgs), C.c_void_p, C.c_void_p]
     L.tvdn_run.argtypes = [C.POINTER(RunArgs)]
+    L.tvdn_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.tvdn_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     L.tvdn_synth_fill.argtypes = [C.c_int, C.c_int, i64p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header and library out of step
@@ -155,6 +157,24 @@ def new_ctx(device: int) -> C.c_void_p:
     with torch.cuda.device(device):
         check(lib().tvdn_ctx_create(C.byref(h), int(device)))
     return h
+
+
+def copy_to_device(src: np.ndarray, dst) -> None:
+    """C-contiguous NumPy array -> contiguous device tensor of the same byte size, through the library's pinned,
+    multi-lane staging (csrc/tvdn_hostio.hip).  Synchronous; the caller orders it against its own streams."""
+    if not src.flags["C_CONTIGUOUS"] or not dst.is_contiguous() or src.nbytes != dst.numel() * dst.element_size():
+        raise ValueError("copy_to_device needs contiguous buffers of equal size")
+    check(lib().tvdn_copy_to_device(C.c_void_p(dst.data_ptr()), C.c_void_p(src.ctypes.data), src.nbytes, dst.device.index))
+
+
+def copy_to_host(src, dtype) -> np.ndarray:
+    """Contiguous device tensor -> fresh NumPy array (first touch of the new pages spread over the staging lanes).
+    Synchronous; the producing stream must have been synchronised by the caller."""
+    if not src.is_contiguous():
+        raise ValueError("copy_to_host needs a contiguous tensor")
+    out = np.empty(tuple(src.shape), dtype=dtype)
+    check(lib().tvdn_copy_to_host(C.c_void_p(out.ctypes.data), C.c_void_p(src.data_ptr()), out.nbytes, src.device.index))
+    return out
 
 
 def current_stream(device: int) -> C.c_void_p:

@@ -1,11 +1,8 @@
-// libtvdn_hip.so: C ABI plumbing, the one-pass ("kernel-level") HIP kernels and the synthetic
-// input generator.  The fused iteration lives in tvdn_fused.hip.
+// libtvdn_hip.so: C ABI plumbing (errors, contexts, the second reduction stage) and the synthetic
+// input generator.  The one-pass kernels live in tvdn_passes.hip, the fused iteration in tvdn_fused.hip.
 //
-// Arithmetic contract: every operation in the array dtype, left to right
-// as the reference writes it, no fused multiply-add (this file is compiled with
-// -ffp-contract=off), f32 denormals kept (hipcc default for gfx950).  Reductions are kept in
-// f64 by a fixed tree, so they are deterministic and, unlike the reference's OpenMP sums,
-// independent of any thread count.
+// Reductions are kept in f64 by a fixed tree (lanes -> waves -> one partial per workgroup -> the fold below),
+// so they are deterministic and, unlike the reference's OpenMP sums, independent of any thread count.
 #include <cstdarg>
 
 #include "tvdn_common.hpp"
@@ -24,6 +21,27 @@ void set_error(const char *fmt, ...)
 }
 
 // ---- second reduction stage ------------------------------------------------------------------
+// Up to kFoldDirect partial rows: one workgroup folds them in index order.  More: a first stage of
+// ceil(n / kFoldSegment) workgroups folds one contiguous segment each, then the single workgroup folds those.
+// The tree depends on the number of partial rows only.
+__global__ void __launch_bounds__(256) fold_kernel(const double *partials, int nblocks, int nv, double *out)
+{
+    __shared__ double red[kPartialWidth][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lo = blockIdx.x * kFoldSegment;
+    const int hi = (lo + kFoldSegment < nblocks) ? lo + kFoldSegment : nblocks;
+    for (int q = 0; q < nv; ++q) {
+        double s = 0.0;
+        for (int i = lo + (int)threadIdx.x; i < hi; i += 256) s += partials[(size_t)i * kPartialWidth + q];
+        s = wave_sum(s);
+        if (lane == 0) red[q][w] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nv)
+        out[(size_t)blockIdx.x * kPartialWidth + threadIdx.x] =
+            ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
+}
+
 __global__ void __launch_bounds__(1024) finalize_kernel(const double *partials, int nblocks, int nv,
                                                          double *out, int accumulate)
 {
@@ -43,110 +61,38 @@ __global__ void __launch_bounds__(1024) finalize_kernel(const double *partials, 
     }
 }
 
+int ensure_partials(tvdn_ctx *ctx, long long nblocks)
+{
+    TVDN_REQUIRE(nblocks >= 1 && nblocks <= kMaxPartialBlocks, "launch of %lld workgroups exceeds the reduction scratch",
+                 nblocks);
+    if (nblocks <= ctx->partial_cap) return TVDN_OK;
+    long long cap = ctx->partial_cap > 0 ? ctx->partial_cap : kInitPartialBlocks;
+    while (cap < nblocks) cap *= 2;
+    double *fresh = nullptr;
+    TVDN_HIP(hipMalloc((void **)&fresh, sizeof(double) * (size_t)cap * kPartialWidth));
+    TVDN_HIP(hipDeviceSynchronize());  // earlier launches may still be writing the old scratch
+    if (ctx->partials) TVDN_HIP(hipFree(ctx->partials));
+    ctx->partials = fresh;
+    ctx->partial_cap = cap;
+    return TVDN_OK;
+}
+
 int launch_finalize(tvdn_ctx *ctx, int nblocks, int nv, double *out, hipStream_t s, bool accumulate)
 {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, s, ctx->partials, nblocks, nv, out, accumulate ? 1 : 0);
+    const double *src = ctx->partials;
+    if (nblocks > kFoldDirect) {
+        const int g1 = (nblocks + kFoldSegment - 1) / kFoldSegment;
+        hipLaunchKernelGGL(fold_kernel, dim3(g1), dim3(256), 0, s, ctx->partials, nblocks, nv, ctx->partials2);
+        TVDN_HIP(hipGetLastError());
+        src = ctx->partials2;
+        nblocks = g1;
+    }
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, s, src, nblocks, nv, out, accumulate ? 1 : 0);
     TVDN_HIP(hipGetLastError());
     return TVDN_OK;
 }
 
-// ---- one-pass kernels ------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ T clipval(T a, T val)
-{
-    // two ternaries exactly as the reference's generated C (anisotropic.c:2423-2437): NaN passes
-    const T lo = -val;
-    const T t = (lo > a) ? lo : a;
-    return (val < t) ? val : t;
-}
-
 constexpr int kBlock = 256;
-
-// accumulator_update_{3D,4D}[_FISTA]: cyTVDN/anisotropic.pyx:17-84, :89-164, :169-237, :243-317.
-// The reference's serial boundary hyperslab (:56-82) is folded in as a predicated `prev` offset.
-template <typename T, bool FISTA>
-__global__ void __launch_bounds__(kBlock) acc_update_kernel(const T *__restrict__ a, T *__restrict__ b,
-                                                             T *__restrict__ d, T tk, T clip,
-                                                             long long total, long long stride,
-                                                             long long n_ax, long long edge_delta,
-                                                             double *partials)
-{
-    double acc[1] = {0.0};
-    const long long step = (long long)gridDim.x * kBlock;
-    for (long long x = (long long)blockIdx.x * kBlock + threadIdx.x; x < total; x += step) {
-        const long long c = (x / stride) % n_ax;
-        const long long p = (c > 0) ? x - stride : x + edge_delta;
-        const T v = (a[x] - a[p]) + b[x];
-        const T dn = clipval(v, clip);
-        T bn = dn;
-        if (FISTA) {
-            bn = dn + tk * (dn - d[x]);
-            d[x] = dn;
-        }
-        b[x] = bn;
-        acc[0] += fabs((double)bn);
-    }
-    block_store_partials<1, kBlock>(acc, partials);
-}
-
-template <typename T>
-struct ReconArgs {
-    const T *orig;
-    T *recon;
-    const T *b[4];
-    T lm[4];
-    long long n[4], st[4];
-    int nax;
-    long long total;
-};
-
-// datacube_update_{3D,4D}: cyTVDN/utils.pyx:54-125, :131-199 (periodic-wrap branch, BC 0 and 2);
-// association of the sum from the generated C, utils.c:5641.
-template <typename T, int NAX>
-__global__ void __launch_bounds__(kBlock) recon_update_kernel(ReconArgs<T> p, double *partials)
-{
-    double acc[2] = {0.0, 0.0};
-    const long long step = (long long)gridDim.x * kBlock;
-    for (long long x = (long long)blockIdx.x * kBlock + threadIdx.x; x < p.total; x += step) {
-        long long idx[4];
-        long long rem = x;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            idx[q] = rem / p.st[q];
-            rem -= idx[q] * p.st[q];
-        }
-        T s = (T)0;
-#pragma unroll
-        for (int q = 0; q < NAX; ++q) {
-            const int axq = (NAX == 4) ? q : (q == 0 ? 0 : q + 1);
-            const long long nx = (idx[axq] + 1 < p.n[axq]) ? x + p.st[axq] : x - idx[axq] * p.st[axq];
-            const T term = p.lm[q] * (p.b[q][x] - p.b[q][nx]);
-            s = (q == 0) ? term : (s + term);
-        }
-        const T old = p.recon[x];
-        const T nw = p.orig[x] - s;
-        p.recon[x] = nw;
-        const T df = nw - old;
-        acc[0] += fabs((double)df);
-        acc[1] += fabs((double)old);
-    }
-    block_store_partials<2, kBlock>(acc, partials);
-}
-
-// sum_square_error_{3D,4D}: cyTVDN/utils.pyx:14-30, :35-49.
-template <typename T>
-__global__ void __launch_bounds__(kBlock) sse_kernel(const T *__restrict__ a, const T *__restrict__ b,
-                                                      long long total, double *partials)
-{
-    double acc[1] = {0.0};
-    const long long step = (long long)gridDim.x * kBlock;
-    for (long long x = (long long)blockIdx.x * kBlock + threadIdx.x; x < total; x += step) {
-        const T t = a[x] - b[x];
-        const T sq = t * t;
-        acc[0] += (double)sq;
-    }
-    block_store_partials<1, kBlock>(acc, partials);
-}
 
 static int grid_for(long long total)
 {
@@ -155,59 +101,6 @@ static int grid_for(long long total)
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;
-}
-
-static int check_common(tvdn_ctx *ctx, int dtype, int ndim, const int64_t *shape)
-{
-    TVDN_REQUIRE(ctx != nullptr, "ctx is NULL");
-    TVDN_REQUIRE(dtype == TVDN_F32 || dtype == TVDN_F64, "dtype must be TVDN_F32 or TVDN_F64, got %d", dtype);
-    TVDN_REQUIRE(ndim == 3 || ndim == 4, "ndim must be 3 or 4, got %d", ndim);
-    TVDN_REQUIRE(shape != nullptr, "shape is NULL");
-    for (int i = 0; i < ndim; ++i) TVDN_REQUIRE(shape[i] >= 1, "shape[%d] = %lld must be >= 1", i, (long long)shape[i]);
-    return TVDN_OK;
-}
-
-template <typename T>
-static int acc_update_impl(tvdn_ctx *ctx, const Geom &g, const void *a, void *b, void *d, double tk, int cax,
-                           double clip, int bc_mode, double *norm_out, hipStream_t s)
-{
-    const long long n_ax = g.n[cax], stride = g.st[cax];
-    long long edge = 0;
-    if (bc_mode == TVDN_BC_PERIODIC) edge = (n_ax - 1) * stride;
-    if (bc_mode == TVDN_BC_MIRROR) edge = stride;
-    const int grid = grid_for(g.total);
-    if (d)
-        hipLaunchKernelGGL((acc_update_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, (const T *)a, (T *)b,
-                           (T *)d, (T)tk, (T)clip, g.total, stride, n_ax, edge, ctx->partials);
-    else
-        hipLaunchKernelGGL((acc_update_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, (const T *)a, (T *)b,
-                           (T *)nullptr, (T)tk, (T)clip, g.total, stride, n_ax, edge, ctx->partials);
-    TVDN_HIP(hipGetLastError());
-    return launch_finalize(ctx, grid, 1, norm_out, s);
-}
-
-template <typename T>
-static int recon_update_impl(tvdn_ctx *ctx, const Geom &g, const void *orig, void *recon, const void *const *b,
-                             const double *lm, double *sums_out, hipStream_t s)
-{
-    ReconArgs<T> p;
-    p.orig = (const T *)orig;
-    p.recon = (T *)recon;
-    for (int q = 0; q < 4; ++q) {
-        p.b[q] = q < g.nax ? (const T *)b[q] : nullptr;
-        p.lm[q] = q < g.nax ? (T)lm[q] : (T)0;
-        p.n[q] = g.n[q];
-        p.st[q] = g.st[q];
-    }
-    p.nax = g.nax;
-    p.total = g.total;
-    const int grid = grid_for(g.total);
-    if (g.nax == 4)
-        hipLaunchKernelGGL((recon_update_kernel<T, 4>), dim3(grid), dim3(kBlock), 0, s, p, ctx->partials);
-    else
-        hipLaunchKernelGGL((recon_update_kernel<T, 3>), dim3(grid), dim3(kBlock), 0, s, p, ctx->partials);
-    TVDN_HIP(hipGetLastError());
-    return launch_finalize(ctx, grid, 2, sums_out, s);
 }
 
 // ---- synthetic input (cytvdn_amd/synth.py, same integer arithmetic) ---------------------------
@@ -319,9 +212,14 @@ int tvdn_ctx_create(tvdn_ctx **out, int device)
     tvdn_ctx *c = new tvdn_ctx;
     c->device = device;
     c->partials = nullptr;
+    c->partials2 = nullptr;
+    c->partial_cap = kInitPartialBlocks;
     c->timing = false;
-    hipError_t e = hipMalloc((void **)&c->partials, sizeof(double) * (size_t)kMaxPartialBlocks * kPartialWidth);
+    hipError_t e = hipMalloc((void **)&c->partials, sizeof(double) * (size_t)kInitPartialBlocks * kPartialWidth);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&c->partials2, sizeof(double) * (size_t)(kMaxPartialBlocks / kFoldSegment) * kPartialWidth);
     if (e != hipSuccess) {
+        if (c->partials) (void)hipFree(c->partials);
         delete c;
         set_error("hipMalloc(partials) failed: %s", hipGetErrorString(e));
         return TVDN_ERR_HIP;
@@ -365,66 +263,13 @@ int tvdn_ctx_destroy(tvdn_ctx *ctx)
         (void)hipEventDestroy(ev.second);
     }
     hipError_t e = hipFree(ctx->partials);
+    (void)hipFree(ctx->partials2);
     delete ctx;
     if (e != hipSuccess) {
         set_error("hipFree failed: %s", hipGetErrorString(e));
         return TVDN_ERR_HIP;
     }
     return TVDN_OK;
-}
-
-int tvdn_accumulator_update(tvdn_ctx *ctx, int dtype, int ndim, const int64_t *shape, const void *a, void *b,
-                            void *d, double tk, int ax, double clip, int bc_mode, double *norm_out, void *stream)
-{
-    int rc = check_common(ctx, dtype, ndim, shape);
-    if (rc) return rc;
-    TVDN_REQUIRE(a && b && norm_out, "a, b and norm_out must be non-NULL");
-    TVDN_REQUIRE(ax >= 0 && ax < ndim, "ax = %d out of range for ndim = %d", ax, ndim);
-    TVDN_REQUIRE(bc_mode >= 0 && bc_mode <= 2, "bc_mode must be 0, 1 or 2, got %d", bc_mode);
-    TVDN_REQUIRE(!(bc_mode == TVDN_BC_MIRROR && shape[ax] < 2), "mirror BC needs shape[ax] >= 2");
-    const Geom g = make_geom(ndim, shape);
-    const int cax = canon_axis(ndim, ax);
-    return dtype == TVDN_F32
-               ? acc_update_impl<float>(ctx, g, a, b, d, tk, cax, clip, bc_mode, norm_out, (hipStream_t)stream)
-               : acc_update_impl<double>(ctx, g, a, b, d, tk, cax, clip, bc_mode, norm_out, (hipStream_t)stream);
-}
-
-int tvdn_datacube_update(tvdn_ctx *ctx, int dtype, int ndim, const int64_t *shape, const void *orig, void *recon,
-                         const void *const *b, const double *lambda_mu, int bc_mode, double *sums_out,
-                         void *stream)
-{
-    int rc = check_common(ctx, dtype, ndim, shape);
-    if (rc) return rc;
-    TVDN_REQUIRE(orig && recon && b && lambda_mu && sums_out, "NULL argument");
-    for (int q = 0; q < ndim; ++q) TVDN_REQUIRE(b[q] != nullptr, "b[%d] is NULL", q);
-    if (bc_mode == TVDN_BC_MIRROR) {
-        set_error("bc_mode 1 (mirror) reconstruction update reads out of bounds upstream (utils.pyx:117-120): unsupported");
-        return TVDN_ERR_UNSUPPORTED;
-    }
-    TVDN_REQUIRE(bc_mode == 0 || bc_mode == 2, "bc_mode must be 0 or 2, got %d", bc_mode);
-    const Geom g = make_geom(ndim, shape);
-    return dtype == TVDN_F32
-               ? recon_update_impl<float>(ctx, g, orig, recon, b, lambda_mu, sums_out, (hipStream_t)stream)
-               : recon_update_impl<double>(ctx, g, orig, recon, b, lambda_mu, sums_out, (hipStream_t)stream);
-}
-
-int tvdn_sum_square_error(tvdn_ctx *ctx, int dtype, int ndim, const int64_t *shape, const void *a, const void *b,
-                          double *out, void *stream)
-{
-    int rc = check_common(ctx, dtype, ndim, shape);
-    if (rc) return rc;
-    TVDN_REQUIRE(a && b && out, "NULL argument");
-    const Geom g = make_geom(ndim, shape);
-    const int grid = grid_for(g.total);
-    hipStream_t s = (hipStream_t)stream;
-    if (dtype == TVDN_F32)
-        hipLaunchKernelGGL((sse_kernel<float>), dim3(grid), dim3(kBlock), 0, s, (const float *)a, (const float *)b,
-                           g.total, ctx->partials);
-    else
-        hipLaunchKernelGGL((sse_kernel<double>), dim3(grid), dim3(kBlock), 0, s, (const double *)a,
-                           (const double *)b, g.total, ctx->partials);
-    TVDN_HIP(hipGetLastError());
-    return launch_finalize(ctx, grid, 1, out, s);
 }
 
 int tvdn_synth_fill(int dtype, int ndim, const int64_t *shape, uint64_t seed, int64_t row0, int64_t rows,

@@ -68,14 +68,22 @@ inline Geom make_geom(int ndim, const int64_t *shape)
 inline int canon_axis(int ndim, int ax) { return (ndim == 4 || ax == 0) ? ax : ax + 1; }
 
 // ---- context ---------------------------------------------------------------------------------
-constexpr int kMaxPartialBlocks = 1 << 18;  // per launch
+// Per-workgroup partial sums of one launch: `partial_cap` rows of kPartialWidth doubles.  The buffer starts at
+// kInitPartialBlocks rows and grows on demand (ensure_partials) up to kMaxPartialBlocks, so that even a
+// 1024x256x256 plane keeps its short 8-row marches (2^16 tiles x 17 chunks = 1.1 M workgroups).
+constexpr int kInitPartialBlocks = 1 << 18;
+constexpr int kMaxPartialBlocks = 1 << 22;  // per launch
 constexpr int kPartialWidth = 4;            // doubles per block
+constexpr int kFoldSegment = 1024;          // partial rows folded by one workgroup of the first finalize stage
+constexpr int kFoldDirect = 4096;           // up to this many rows the single-workgroup stage folds them itself
 
 }  // namespace tvdn
 
 struct tvdn_ctx {
     int device;
-    double *partials;  // [kMaxPartialBlocks][kPartialWidth]
+    double *partials;   // [partial_cap][kPartialWidth]
+    double *partials2;  // [kMaxPartialBlocks / kFoldSegment][kPartialWidth]: output of the first finalize stage
+    long long partial_cap;
     bool timing;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // pending (start, stop) pairs
 };
@@ -112,6 +120,79 @@ __device__ __forceinline__ void block_store_partials(const double (&v)[NV], doub
     }
 }
 
+// Makes room for `nblocks` partial rows (grows the scratch buffer; a growth synchronises the device once).
+int ensure_partials(tvdn_ctx *ctx, long long nblocks);
 int launch_finalize(tvdn_ctx *ctx, int nblocks, int nv, double *out, hipStream_t s, bool accumulate = false);
+
+// ---- 16-byte packs ---------------------------------------------------------------------------
+// A thread owns VEC consecutive elements of the contiguous axis (16 bytes: 4 floats / 2 doubles), or one
+// element when the extent or the alignment forbids it.
+template <typename T, int VEC>
+struct alignas(sizeof(T) * VEC) Pack {
+    T v[VEC];
+};
+
+template <typename T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> ldv(const T *p)
+{
+    return *reinterpret_cast<const Pack<T, VEC> *>(p);
+}
+
+#ifndef TVDN_NT_STORES
+#define TVDN_NT_STORES 1
+#endif
+#ifndef TVDN_NT_LOADS
+#define TVDN_NT_LOADS 1
+#endif
+constexpr bool kNtStores = TVDN_NT_STORES != 0;
+constexpr bool kNtLoads = TVDN_NT_LOADS != 0;
+
+// Outputs are written once and not read again by the same sweep: non-temporal (streaming) stores keep them
+// from displacing the input lines that neighbouring threads are about to re-read from L2.  Measured on
+// config 2, interleaved runs on one device: plain 11.77 ms, nt stores 11.66 ms, nt stores + nt loads of
+// the own-position-only arrays 11.44 ms (a pure 10R/5W float4 stream: 11.03 ms plain, 10.76 ms nt).
+template <typename T, int VEC>
+__device__ __forceinline__ void stv(T *p, const Pack<T, VEC> &x)
+{
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    vec_t v;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = x.v[j];
+    if (kNtStores)
+        __builtin_nontemporal_store(v, reinterpret_cast<vec_t *>(p));
+    else
+        *reinterpret_cast<vec_t *>(p) = v;
+}
+
+// Arrays read at the thread's own position only: streaming loads.
+template <typename T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> ldv_nt(const T *p)
+{
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    Pack<T, VEC> x;
+    const vec_t v = kNtLoads ? __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(p)) : *reinterpret_cast<const vec_t *>(p);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) x.v[j] = v[j];
+    return x;
+}
+
+// two ternaries as in the reference's generated C (anisotropic.c:2423-2437): NaN passes through
+template <typename T>
+__device__ __forceinline__ T clipv(T a, T val)
+{
+    const T lo = -val;
+    const T t = (lo > a) ? lo : a;
+    return (val < t) ? val : t;
+}
+
+inline bool aligned16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
+
+// XCD-aware remap of workgroup ids (bijective for any grid size): blocks b and b+8 share an XCD and its L2,
+// so each XCD gets a contiguous run of logical ids.
+__device__ __forceinline__ long long xcd_remap(long long bid, long long G)
+{
+    const long long q8 = G / 8, r8 = G % 8, xcd = bid % 8;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
+}
 
 }  // namespace tvdn

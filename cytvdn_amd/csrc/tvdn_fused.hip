@@ -33,64 +33,6 @@
 
 namespace tvdn {
 
-#ifndef TVDN_NT_STORES
-#define TVDN_NT_STORES 1
-#endif
-#ifndef TVDN_NT_LOADS
-#define TVDN_NT_LOADS 1
-#endif
-constexpr bool kNtStores = TVDN_NT_STORES != 0;
-constexpr bool kNtLoads = TVDN_NT_LOADS != 0;
-
-template <typename T>
-__device__ __forceinline__ T clipv(T a, T val)
-{
-    // two ternaries as in the reference's generated C (anisotropic.c:2423-2437): NaN passes through
-    const T lo = -val;
-    const T t = (lo > a) ? lo : a;
-    return (val < t) ? val : t;
-}
-
-template <typename T, int VEC>
-struct alignas(sizeof(T) * VEC) Pack {
-    T v[VEC];
-};
-
-template <typename T, int VEC>
-__device__ __forceinline__ Pack<T, VEC> ldv(const T *p)
-{
-    return *reinterpret_cast<const Pack<T, VEC> *>(p);
-}
-
-// Outputs are written once and not read again by this sweep: non-temporal (streaming) stores keep them
-// from displacing the input lines that neighbouring threads are about to re-read from L2.  Measured on
-// config 2, interleaved runs on one device: plain 11.77 ms, nt stores 11.66 ms, nt stores + nt loads of
-// the own-position-only arrays 11.44 ms (a pure 10R/5W float4 stream: 11.03 ms plain, 10.76 ms nt).
-template <typename T, int VEC>
-__device__ __forceinline__ void stv(T *p, const Pack<T, VEC> &x)
-{
-    typedef T vec_t __attribute__((ext_vector_type(VEC)));
-    vec_t v;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) v[j] = x.v[j];
-    if (kNtStores)
-        __builtin_nontemporal_store(v, reinterpret_cast<vec_t *>(p));
-    else
-        *reinterpret_cast<vec_t *>(p) = v;
-}
-
-// Arrays read at the thread's own position only (orig, the M-axis state): streaming loads.
-template <typename T, int VEC>
-__device__ __forceinline__ Pack<T, VEC> ldv_nt(const T *p)
-{
-    typedef T vec_t __attribute__((ext_vector_type(VEC)));
-    Pack<T, VEC> x;
-    const vec_t v = kNtLoads ? __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(p)) : *reinterpret_cast<const vec_t *>(p);
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) x.v[j] = v[j];
-    return x;
-}
-
 // Per-axis accumulator state as the kernel sees it.  Which arrays exist depends on the mode:
 //   in1: b (PLAIN, FISTA) or d_k-1 (FISTA_D*);  in2: d_k (all FISTA modes)
 //   out1: b' (PLAIN, FISTA, FISTA_D_TO_PLAIN);  out2: d' (FISTA, FISTA_D)
@@ -235,11 +177,7 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
     constexpr int iM = 0, iA = 1, iB = NAX - 2, iC = NAX - 1;  // accumulator slot per canonical axis
     constexpr bool HAS_A = (NAX == 4);
 
-    // XCD-aware remap (bijective for any grid size): blocks b and b+8 share an XCD and its L2, so
-    // each XCD gets a contiguous run of logical ids.
-    const long long G = gridDim.x, bid = blockIdx.x;
-    const long long q8 = G / 8, r8 = G % 8, xcd = bid % 8;
-    const long long L = p.xcd ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8 : bid;
+    const long long L = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (long long)blockIdx.x;
     const long long chunk_id = L / p.tiles, tile = L % p.tiles;
 
     const long long u = tile * kFusedBlock + threadIdx.x;
@@ -381,8 +319,6 @@ static int launch_fused_m(const FusedParams<T> &p, int mode, int grid, hipStream
     }
 }
 
-static bool aligned16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
-
 template <typename T>
 static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *sums_out, hipStream_t s)
 {
@@ -440,11 +376,18 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
     long long chunk = e_chunk ? atoll(e_chunk) : 8;
     if (chunk < 1) chunk = 1;
     while (chunk > 4 && p.tiles * ((rows + chunk - 1) / chunk) < 256 * 8) chunk /= 2;
+    // the reduction scratch grows with the grid (ensure_partials), so big planes keep their short marches;
+    // only beyond kMaxPartialBlocks workgroups do the marches get longer
     while (p.tiles * ((rows + chunk - 1) / chunk) > kMaxPartialBlocks && chunk < rows) chunk *= 2;
     p.chunk = (int)chunk;
     const long long nchunks = (rows + chunk - 1) / chunk;
     const long long grid = p.tiles * nchunks;
     TVDN_REQUIRE(grid >= 1 && grid <= kMaxPartialBlocks, "fused grid %lld out of range (max %d)", grid, kMaxPartialBlocks);
+    {
+        const int rce = ensure_partials(ctx, grid);
+        if (rce) return rce;
+        p.partials = ctx->partials;
+    }
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ctx->timing) {

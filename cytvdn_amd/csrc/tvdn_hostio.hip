@@ -1,0 +1,147 @@
+// Host <-> HBM transfers of whole datacubes at PCIe speed from ordinary (pageable) host arrays.
+//
+// denoise3D/4D take and return NumPy arrays (cyTVDN/cyTVDN.py:19-31, :244-247: `recon = datacube.copy()` on the way
+// in, a fresh array on the way out), i.e. pageable memory.  hipMemcpy from/to pageable memory stages through one
+// bounce buffer with one host thread doing the copy, and a freshly allocated destination is page-faulted by that same
+// thread: 10-25 GB/s where the link does 50+.  Here `kLanes` host threads each own two pinned bounce buffers and a
+// HIP stream and move every kLanes-th chunk of the array on their own: memcpy into (or out of) the pinned buffer
+// overlaps the DMA of the lane's other buffer and the work of the other lanes, and the first touch of a fresh
+// destination is spread over all lanes.  The pinned buffers are allocated once per process and device.
+//
+// Both entry points are synchronous (they return when the bytes have arrived) and order themselves only against
+// their own streams: the caller synchronises the stream that produced / will consume the device buffer.
+#include <algorithm>
+#include <mutex>
+#include <thread>
+
+#include "tvdn_common.hpp"
+
+namespace tvdn {
+
+constexpr int kLanes = 8;
+constexpr size_t kChunk = size_t(16) << 20;  // per bounce buffer
+
+struct Lane {
+    void *pin[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+struct HostIo {
+    int device = -1;
+    bool ready = false;
+    Lane lane[kLanes];
+};
+
+static std::mutex g_io_mutex;       // one transfer at a time per process: the bounce buffers are shared
+static HostIo g_io[16];
+
+static int lanes_wanted()
+{
+    unsigned hc = std::thread::hardware_concurrency();
+    int n = hc ? (int)hc : 4;
+    const char *e = getenv("TVDN_IO_LANES");
+    if (e && atoi(e) > 0) n = atoi(e);
+    return std::max(1, std::min(n, kLanes));
+}
+
+static int io_init(HostIo &io, int device)
+{
+    if (io.ready) return TVDN_OK;
+    TVDN_HIP(hipSetDevice(device));
+    for (int l = 0; l < kLanes; ++l) {
+        Lane &L = io.lane[l];
+        for (int b = 0; b < 2; ++b) {
+            TVDN_HIP(hipHostMalloc(&L.pin[b], kChunk, hipHostMallocDefault));
+            TVDN_HIP(hipEventCreateWithFlags(&L.ev[b], hipEventDisableTiming));
+        }
+        TVDN_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    }
+    io.device = device;
+    io.ready = true;
+    return TVDN_OK;
+}
+
+// One lane of an upload: chunks l, l+n, l+2n, ... of the array.
+static void lane_upload(HostIo *io, int l, int n, char *dst, const char *src, size_t bytes, int *status)
+{
+    Lane &L = io->lane[l];
+    if (hipSetDevice(io->device) != hipSuccess) { *status = TVDN_ERR_HIP; return; }
+    const size_t nchunks = (bytes + kChunk - 1) / kChunk;
+    int buf = 0;
+    bool used[2] = {false, false};
+    for (size_t c = (size_t)l; c < nchunks; c += (size_t)n, buf ^= 1) {
+        const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
+        if (used[buf] && hipEventSynchronize(L.ev[buf]) != hipSuccess) { *status = TVDN_ERR_HIP; return; }
+        std::memcpy(L.pin[buf], src + off, len);
+        if (hipMemcpyAsync(dst + off, L.pin[buf], len, hipMemcpyHostToDevice, L.stream) != hipSuccess ||
+            hipEventRecord(L.ev[buf], L.stream) != hipSuccess) { *status = TVDN_ERR_HIP; return; }
+        used[buf] = true;
+    }
+    if (hipStreamSynchronize(L.stream) != hipSuccess) *status = TVDN_ERR_HIP;
+}
+
+// One lane of a download: the DMA of the lane's next chunk runs while it copies the current one out.
+static void lane_download(HostIo *io, int l, int n, char *dst, const char *src, size_t bytes, int *status)
+{
+    Lane &L = io->lane[l];
+    if (hipSetDevice(io->device) != hipSuccess) { *status = TVDN_ERR_HIP; return; }
+    const size_t nchunks = (bytes + kChunk - 1) / kChunk;
+    auto issue = [&](size_t c, int buf) -> bool {
+        const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
+        return hipMemcpyAsync(L.pin[buf], src + off, len, hipMemcpyDeviceToHost, L.stream) == hipSuccess &&
+               hipEventRecord(L.ev[buf], L.stream) == hipSuccess;
+    };
+    int buf = 0;
+    size_t c = (size_t)l;
+    if (c < nchunks && !issue(c, buf)) { *status = TVDN_ERR_HIP; return; }
+    for (; c < nchunks; c += (size_t)n, buf ^= 1) {
+        const size_t next = c + (size_t)n;
+        if (next < nchunks && !issue(next, buf ^ 1)) { *status = TVDN_ERR_HIP; return; }
+        if (hipEventSynchronize(L.ev[buf]) != hipSuccess) { *status = TVDN_ERR_HIP; return; }
+        const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
+        std::memcpy(dst + off, L.pin[buf], len);
+    }
+}
+
+static int transfer(bool up, void *dst, const void *src, size_t bytes, int device)
+{
+    TVDN_REQUIRE(device >= 0 && device < 16, "device %d out of range", device);
+    TVDN_REQUIRE(bytes == 0 || (dst && src), "NULL buffer");
+    if (bytes == 0) return TVDN_OK;
+    std::lock_guard<std::mutex> lock(g_io_mutex);
+    if (bytes < (size_t(4) << 20)) {  // small: the runtime's own path is as good
+        TVDN_HIP(hipSetDevice(device));
+        TVDN_HIP(hipMemcpy(dst, src, bytes, up ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+        return TVDN_OK;
+    }
+    HostIo &io = g_io[device];
+    int rc = io_init(io, device);
+    if (rc) return rc;
+    const size_t nchunks = (bytes + kChunk - 1) / kChunk;
+    const int n = (int)std::min<size_t>((size_t)lanes_wanted(), nchunks);
+    int status[kLanes] = {0};
+    std::thread th[kLanes];
+    for (int l = 1; l < n; ++l)
+        th[l] = std::thread(up ? lane_upload : lane_download, &io, l, n, (char *)dst, (const char *)src, bytes, &status[l]);
+    (up ? lane_upload : lane_download)(&io, 0, n, (char *)dst, (const char *)src, bytes, &status[0]);
+    for (int l = 1; l < n; ++l) th[l].join();
+    for (int l = 0; l < n; ++l)
+        if (status[l]) {
+            set_error("host transfer lane %d failed: %s", l, hipGetErrorString(hipGetLastError()));
+            return TVDN_ERR_HIP;
+        }
+    return TVDN_OK;
+}
+
+}  // namespace tvdn
+
+extern "C" int tvdn_copy_to_device(void *dst_device, const void *src_host, size_t bytes, int device)
+{
+    return tvdn::transfer(true, dst_device, src_host, bytes, device);
+}
+
+extern "C" int tvdn_copy_to_host(void *dst_host, const void *src_device, size_t bytes, int device)
+{
+    return tvdn::transfer(false, dst_host, src_device, bytes, device);
+}

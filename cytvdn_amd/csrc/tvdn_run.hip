@@ -45,12 +45,14 @@ static int run_impl(const tvdn_run_args *a)
         }
     TVDN_HIP(hipMalloc(&sums.p, sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1)));
     TVDN_HIP(hipMemsetAsync(sums.p, 0, sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1), nullptr));
-    TVDN_HIP(hipMemcpy(orig.p, a->data, bytes, hipMemcpyHostToDevice));
+    rc = tvdn_copy_to_device(orig.p, a->data, bytes, a->device);
+    if (rc) return rc;
     TVDN_HIP(hipMemcpyAsync(recon[0].p, orig.p, bytes, hipMemcpyDeviceToDevice, nullptr));
     const bool want_mse = a->mse_out != nullptr && a->reference != nullptr;
     if (want_mse) {
         TVDN_HIP(hipMalloc(&ref.p, bytes));
-        TVDN_HIP(hipMemcpy(ref.p, a->reference, bytes, hipMemcpyHostToDevice));
+        rc = tvdn_copy_to_device(ref.p, a->reference, bytes, a->device);
+        if (rc) return rc;
         TVDN_HIP(hipMalloc(&mse.p, sizeof(double) * (size_t)(n_total + 1)));
         TVDN_HIP(hipMemsetAsync(mse.p, 0, sizeof(double) * (size_t)(n_total + 1), nullptr));
         rc = tvdn_sum_square_error(ctx, a->dtype, nd, a->shape, orig.p, ref.p, (double *)mse.p, nullptr);
@@ -146,7 +148,9 @@ static int run_impl(const tvdn_run_args *a)
         if (st) break;
     }
 
-    TVDN_HIP(hipMemcpy(a->recon_out, recon[cur].p, bytes, hipMemcpyDeviceToHost));
+    TVDN_HIP(hipDeviceSynchronize());
+    rc = tvdn_copy_to_host(a->recon_out, recon[cur].p, bytes, a->device);
+    if (rc) return rc;
     if (n_total > 0) TVDN_HIP(hipMemcpy(a->sums_out, sums.p, sizeof(double) * 3 * (size_t)n_total, hipMemcpyDeviceToHost));
     if (want_mse) TVDN_HIP(hipMemcpy(a->mse_out, mse.p, sizeof(double) * (size_t)(n_total + 1), hipMemcpyDeviceToHost));
     if (a->iters_run) *a->iters_run = ran;

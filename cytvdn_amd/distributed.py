@@ -143,4 +143,53 @@ def _denoise_slabs_staged(my_rows, lay, dtype, mu, lam, FISTA, unacc, n_f, n_p, 
     return sr.recon(), b_norm, delta
 
 
-__all__ = ["denoise_slabs", "slab_rows"]
+def selfcheck_exchange(group=None, device=None, iterations: int = 6, dtype=np.float32, plane=(6, 16, 32)):
+    """Pre-flight check of the multi-GPU exchange on THIS process group: a small cube (4 rows per rank) is
+    denoised three ways -- one slab on this rank's own GPU (no communication), the slab runner with the halo
+    exchange overlapped under the interior sweep (`step_overlapped`), and the slab runner with a blocking
+    exchange after every sweep -- and this rank's rows must come out bit-identical in all three.  The verdicts are
+    combined over all ranks (minimum), so every rank returns the same dict:
+        {"overlap": bool, "blocking": bool, "transport": "rccl" | "gloo", "error": str | None}
+    A failing transport shows up as False (an exception is caught and reported), never as a silent fallback."""
+    import torch.distributed as dist
+    from . import synth
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if device is None:
+        device = torch.cuda.current_device()
+    dt = np.dtype(dtype)
+    shape = (4 * world,) + tuple(plane)
+    nd = len(shape)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    lam = mu / dt.type(32.0 if nd == 4 else 16.0)
+    x = synth.cube(shape, seed=4242, dtype=dt) + dt.type(0.25)
+
+    def run(lay, overlap, grp):
+        be = HipBackend(lay, dt, True, device=device, max_iters=iterations)
+        be.set_params(1.0 / lam, (lam / mu).astype(dt))
+        be.set_input(x[lay.local_rows_global()])
+        r = SlabRunner(be, grp)
+        r.overlap = overlap
+        r.run(iterations, 0)
+        torch.cuda.synchronize(device)
+        return be.recon_tensor()[lay.row_lo:lay.row_hi].clone(), r.transport
+
+    res = {"overlap": False, "blocking": False, "transport": None, "error": None}
+    lay = SlabLayout(shape, rank, world, 2)
+    want, _ = run(SlabLayout(shape, 0, 1, 2), False, None)
+    want = want[lay.g0:lay.g1]
+    for key, overlap in (("blocking", False), ("overlap", True)):
+        try:
+            got, res["transport"] = run(lay, overlap, group)
+            res[key] = bool(torch.equal(got.view(torch.int32 if dt == np.float32 else torch.int64),
+                                        want.view(torch.int32 if dt == np.float32 else torch.int64)))
+        except Exception as e:  # report, do not hide
+            res["error"] = f"{key}: {e!r}"
+    flags = torch.tensor([int(res["overlap"]), int(res["blocking"])], dtype=torch.int32)
+    if dist.get_backend(group) == "nccl":
+        flags = flags.to(torch.device("cuda", device))
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=group)
+    res["overlap"], res["blocking"] = bool(flags[0].item()), bool(flags[1].item())
+    return res
+
+
+__all__ = ["denoise_slabs", "slab_rows", "selfcheck_exchange"]

@@ -153,7 +153,7 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
     num, den = sums[:, 1].astype(dtype), sums[:, 2].astype(dtype)
     with np.errstate(divide="ignore", invalid="ignore"):
         delta_recon = np.where(ran, num / den, dtype.type(0)).astype(dtype)   # divided in the data dtype (utils.pyx:125)
-    recon = be.recon_tensor().cpu().numpy()
+    recon = be.recon_to_host()
 
     if stopping_relative_change is not None and not quiet and unaccelerated and n_plain and not ran[-1]:
         print(f"Stopping condition reached after {int(np.nonzero(ran)[0][-1])} iterations, stopping.")

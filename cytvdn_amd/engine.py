@@ -50,6 +50,7 @@ class SlabLayout:
     rank: int
     world: int
     bc_mode: int
+    bounds: tuple = None  # optional explicit partition: world+1 increasing row indices, 0 .. shape[0]
 
     def __post_init__(self):
         if self.world < 1 or not (0 <= self.rank < self.world):
@@ -58,14 +59,23 @@ class SlabLayout:
             raise ValueError(f"axis 0 ({self.shape[0]} rows) cannot be cut into {self.world} slabs")
         if self.bc_mode not in (0, 2):
             raise NotImplementedError("slab engine supports BC_mode 0 (periodic) and 2 (Jia-Zhao)")
+        if self.bounds is not None:
+            b = tuple(int(v) for v in self.bounds)
+            if len(b) != self.world + 1 or b[0] != 0 or b[-1] != self.shape[0] or any(y <= x for x, y in zip(b, b[1:])):
+                raise ValueError("bounds must be world+1 strictly increasing row indices from 0 to shape[0]")
+            object.__setattr__(self, "bounds", b)
 
-    # global rows [g0, g1) owned by this rank (balanced split)
+    # global rows [g0, g1) owned by this rank (balanced split unless `bounds` says otherwise)
     @property
     def g0(self) -> int:
+        if self.bounds is not None:
+            return self.bounds[self.rank]
         return (self.rank * self.shape[0]) // self.world
 
     @property
     def g1(self) -> int:
+        if self.bounds is not None:
+            return self.bounds[self.rank + 1]
         return ((self.rank + 1) * self.shape[0]) // self.world
 
     @property
@@ -157,21 +167,35 @@ class HipBackend:
         tdt = torch.float32 if self.dtype == np.float32 else torch.float64
         dev = torch.device("cuda", self.device)
         ls = layout.local_shape
+        # ONE allocation for the whole state, carved into arrays: one hipMalloc instead of 11-19, and one fill for
+        # every array except the two that `set_input` overwrites anyway (orig and the current recon).  Arrays start
+        # 256-byte aligned; TVDN_ARRAY_SKEW (bytes, a multiple of 256) staggers them further (measurement knob).
+        n_el = int(np.prod(ls))
+        item = self.dtype.itemsize
+        skew = int(os.environ.get("TVDN_ARRAY_SKEW", "0"))
+        stride_el = (-(-(n_el * item) // 256) * 256 + skew) // item
+        per_axis = (3 if fista else 2) if state == "compact" else (4 if fista else 2)
+        n_arr = 3 + self.nd * per_axis
+        self._slab = torch.empty(n_arr * stride_el, dtype=tdt, device=dev)
+        self._slab[:(n_arr - 2) * stride_el].zero_()
+        it = iter(range(n_arr))
 
-        def z():
-            return torch.zeros(ls, dtype=tdt, device=dev)
+        def arr():
+            i = next(it)
+            return self._slab[i * stride_el:i * stride_el + n_el].view(ls)
 
-        self.orig = z()
-        self.recon = [z(), z()]
         if state == "reference":
-            self.b = [[z(), z()] for _ in range(self.nd)]
-            self.d = [[z(), z()] for _ in range(self.nd)] if fista else None
+            self.b = [[arr(), arr()] for _ in range(self.nd)]
+            self.d = [[arr(), arr()] for _ in range(self.nd)] if fista else None
         else:
             # S[q][k]: k-th rotating array of axis q (3 with FISTA: d_k, d_k-1, next; 2 without: b, next)
-            self.S = [[z() for _ in range(3 if fista else 2)] for _ in range(self.nd)]
+            self.S = [[arr() for _ in range(per_axis)] for _ in range(self.nd)]
             self.i_d, self.i_prev, self.i_out = 0, 1, 2      # roles while the state is in d-form
             self.i_b, self.i_bout = 0, 1                     # roles while the state is in b-form
             self.d_form = bool(fista)                        # all-zero d_k, d_k-1 == all-zero b
+        r1 = arr()                                           # zeroed: its halo rows are read before any exchange fills them
+        self.orig = arr()
+        self.recon = [arr(), r1]
         self.tk_prev = 0.0
         self.sums = torch.zeros((max(int(max_iters), 1), 3), dtype=torch.float64, device=dev)
         self.cur = 0
@@ -201,9 +225,21 @@ class HipBackend:
 
     def set_input(self, local_block):
         """local_block: torch tensor or NumPy array of layout.local_shape (halo rows included)."""
-        t = local_block if isinstance(local_block, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local_block))
-        self.orig.copy_(t, non_blocking=False)
+        if isinstance(local_block, np.ndarray) and local_block.dtype == self.dtype \
+                and tuple(local_block.shape) == tuple(self.orig.shape):
+            # pageable host memory at PCIe speed: pinned multi-lane staging inside the library
+            torch.cuda.current_stream(self.device).synchronize()
+            _lib.copy_to_device(np.ascontiguousarray(local_block), self.orig)
+        else:
+            t = local_block if isinstance(local_block, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local_block))
+            self.orig.copy_(t, non_blocking=False)
         self.recon[self.cur].copy_(self.orig)
+
+    def recon_to_host(self) -> np.ndarray:
+        """The own rows of the current reconstruction as a fresh NumPy array."""
+        lay = self.layout
+        torch.cuda.current_stream(self.device).synchronize()
+        return _lib.copy_to_host(self.recon_tensor()[lay.row_lo:lay.row_hi], self.dtype)
 
     def _bind(self, tk_ratio):
         """Point the argument block at the arrays of the iteration about to run."""
@@ -349,6 +385,14 @@ class SlabRunner:
             self.dist = dist
             # batched P2P must not be the first collective of a group (torch.distributed.batch_isend_irecv note)
             dist.barrier(group=group)
+
+    @property
+    def transport(self) -> str:
+        """What moves the halo rows: "rccl" (device memory over xGMI), "gloo" (pinned host staging), or None."""
+        if self.layout.world == 1:
+            return None
+        b = self.dist.get_backend(self.group)
+        return "rccl" if b == "nccl" else str(b)
 
     def _device_p2p(self) -> bool:
         """True when the process group can send device memory directly (RCCL); a gloo group moves the

@@ -6,7 +6,8 @@ sum_square_error_*); re-exported by cyTVDN/__init__.py:1 and called directly by 
 Each call is ONE HIP pass through the C ABI (include/tvdn.h).  Arguments may be
   * NumPy arrays (the reference's calling convention): staged to HBM, updated there, copied back
     into the caller's arrays, which are therefore mutated in place exactly as upstream; or
-  * torch CUDA tensors: updated in place in HBM with no host round trip.
+  * torch CUDA tensors, or any other device array that speaks DLPack (`__dlpack__`: CuPy, JAX, ...):
+    updated in place in HBM with no host round trip and no copy.
 The return value is the Python float the reference returns (kept in f64 by a fixed reduction
 tree instead of the reference's thread-count-dependent dtype-width sum).
 
@@ -28,6 +29,13 @@ _TORCH_DT = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.fl
 _CNAME = {np.dtype(np.float32): "float", np.dtype(np.float64): "double"}
 
 
+def _as_array(x):
+    """NumPy arrays and torch tensors pass; any other DLPack producer is viewed (zero-copy) as a torch tensor."""
+    if isinstance(x, (np.ndarray, torch.Tensor)) or not hasattr(x, "__dlpack__"):
+        return x
+    return torch.from_dlpack(x)
+
+
 def _np_dtype(x):
     if isinstance(x, torch.Tensor):
         return {torch.float32: np.dtype(np.float32), torch.float64: np.dtype(np.float64)}.get(x.dtype)
@@ -38,6 +46,7 @@ class _Staged:
     """Arrays of one call, resident in HBM; copies NumPy outputs back on `finish`."""
 
     def __init__(self, nd, arrays, writable):
+        arrays = [_as_array(x) for x in arrays]
         first = arrays[0]
         if not isinstance(first, (np.ndarray, torch.Tensor)) or first.ndim != nd:
             raise TypeError("No matching signature found")

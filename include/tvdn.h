@@ -203,6 +203,18 @@ typedef struct tvdn_run_args {
 
 int tvdn_run(const tvdn_run_args *args);
 
+/* ------------------------------------------------------------------------------------------
+ * Whole-array transfers between ordinary (pageable) host memory and HBM at PCIe speed: what
+ * `recon = datacube.copy()` on the way in (cyTVDN/cyTVDN.py:145) and the returned array on the way
+ * out (:244-247) become when the state lives on the GPU.  Several host threads, each with two pinned
+ * bounce buffers and its own HIP stream, move interleaved 16 MiB chunks; a freshly allocated
+ * destination is first-touched by all of them.  Synchronous: returns when the bytes have arrived.
+ * The caller synchronises the stream that produced (to_host) or will consume (to_device) the
+ * device buffer.  tvdn_run uses these for its own transfers.
+ * ---------------------------------------------------------------------------------------- */
+int tvdn_copy_to_device(void *dst_device, const void *src_host, size_t bytes, int device);
+int tvdn_copy_to_host(void *dst_host, const void *src_device, size_t bytes, int device);
+
 /* Synthetic input (cytvdn_amd/synth.py restated on the device, bit-identical): fills rows
  * [row0, row0+rows) of the GLOBAL cube `shape` into `out` (rows*prod(shape[1:]) elements). */
 int tvdn_synth_fill(int dtype, int ndim, const int64_t *shape, uint64_t seed, int64_t row0,

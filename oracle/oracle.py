@@ -43,7 +43,7 @@ def build(force: bool = False) -> None:
     if force or not os.path.exists(_LIB_PATH) or (
         os.path.getmtime(_LIB_PATH)
         < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("tvdn_oracle.c", "tvdn_oracle_impl.h"))
-    ):
+    ) or not os.path.exists(os.path.join(_HERE, "libtvdn_oracle_timed.so")):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle"])
     subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
 
@@ -98,7 +98,7 @@ def _ptr(x):
     return x.ctypes.data_as(C.c_void_p)
 
 
-def acc_update(a, b, d, tk, ax, clip, BC_mode=2):
+def acc_update(a, b, d, tk, ax, clip, BC_mode=2, L=None):
     """Generic accumulator update; returns (norm in T, norm in f64)."""
     nd = a.ndim
     arrs = (a, b) if d is None else (a, b, d)
@@ -109,7 +109,7 @@ def acc_update(a, b, d, tk, ax, clip, BC_mode=2):
         raise ValueError("BC_mode must be 0, 1 or 2")
     if BC_mode == 1 and a.shape[ax] < 2:
         raise ValueError("mirror BC needs at least 2 entries along ax")
-    fn = getattr(lib(), "orc_accumulator_update_" + _SUF[dt])
+    fn = getattr(L or lib(), "orc_accumulator_update_" + _SUF[dt])
     ct = _CT[dt]
     nT, n64 = C.c_double(), C.c_double()
     fn.restype = None
@@ -120,7 +120,7 @@ def acc_update(a, b, d, tk, ax, clip, BC_mode=2):
     return nT.value, n64.value
 
 
-def recon_update(orig, recon, bs, lambda_mu, BC_mode=2):
+def recon_update(orig, recon, bs, lambda_mu, BC_mode=2, L=None):
     """Generic reconstruction update; returns (delta/rnorm in T, sum|delta| f64, sum|old| f64)."""
     nd = orig.ndim
     dt = _chk(nd, orig, recon, *bs)
@@ -133,7 +133,7 @@ def recon_update(orig, recon, bs, lambda_mu, BC_mode=2):
         raise ValueError("Buffer dtype mismatch")
     if lm.shape != (nd,):
         raise ValueError("lambda_mu must have one entry per axis")
-    fn = getattr(lib(), "orc_datacube_update_" + _SUF[dt])
+    fn = getattr(L or lib(), "orc_datacube_update_" + _SUF[dt])
     barr = (C.c_void_p * nd)(*[x.ctypes.data for x in bs])
     out = (C.c_double * 3)()
     fn.restype = None
@@ -199,6 +199,32 @@ def sum_square_error_4D(a, b):
 def sum_square_error_3D(a, b):
     _need(3, a)
     return sse(a, b)[0]
+
+
+# ---- timed variant: the same restatement compiled without the f64 yardstick sums ----
+
+_TIMED_PATH = os.path.join(_HERE, "libtvdn_oracle_timed.so")
+_timed = None
+
+
+def timed_kernels():
+    """Namespace with reference-named kernel functions backed by libtvdn_oracle_timed.so (-DORC_NO_YARDSTICK):
+    the reference's passes, visiting order, dtype-width sums and serial boundary hyperslab, nothing else.
+    This is what bench.py's cpu_baseline times (kind "port"); arrays are bit-identical to the full oracle."""
+    global _timed
+    if _timed is None:
+        if not os.path.exists(_TIMED_PATH):
+            build(force=True)
+        _timed = C.CDLL(_TIMED_PATH)
+    L = _timed
+    ns = types.SimpleNamespace()
+    ns.accumulator_update_4D = lambda a, b, ax, clip, BC_mode=2: acc_update(a, b, None, 0.0, ax, clip, BC_mode, L)[0]
+    ns.accumulator_update_4D_FISTA = lambda a, b, d, tk, ax, clip, BC_mode=2: acc_update(a, b, d, tk, ax, clip, BC_mode, L)[0]
+    ns.accumulator_update_3D = ns.accumulator_update_4D
+    ns.accumulator_update_3D_FISTA = ns.accumulator_update_4D_FISTA
+    ns.datacube_update_4D = lambda o, r, b1, b2, b3, b4, lm, BC_mode=2: recon_update(o, r, (b1, b2, b3, b4), lm, BC_mode, L)[0]
+    ns.datacube_update_3D = lambda o, r, b1, b2, b3, lm, BC_mode=2: recon_update(o, r, (b1, b2, b3), lm, BC_mode, L)[0]
+    return ns
 
 
 # ---- the iteration loop (reference cyTVDN/cyTVDN.py:147-242, :368-430) ----

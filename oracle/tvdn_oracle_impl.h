@@ -11,6 +11,16 @@
  * dtype-width running sums) unchanged.
  */
 
+/* The f64 yardstick sums cost time (a convert + a double add per element).  The timed variant of this
+ * library (liboracle_timed: -DORC_NO_YARDSTICK, oracle/Makefile) leaves them out, so that what bench.py's
+ * cpu_baseline times is the reference's own work per voxel: same passes, same visiting order, same
+ * dtype-width sums, same serial boundary hyperslab.  Arrays come out bit-identical in both variants. */
+#ifdef ORC_NO_YARDSTICK
+#define Y64(stmt)
+#else
+#define Y64(stmt) stmt
+#endif
+
 #define CAT_(a, b) a##_##b
 #define CAT(a, b) CAT_(a, b)
 #define FN(name) CAT(name, SUF)
@@ -72,7 +82,7 @@ void FN(orc_accumulator_update)(const T *a, T *b, T *d, T tk, int ax, T clip, in
                     dr[x] = dn;
                     br[x] = bn;
                     norm += (T)fabs((double)bn);
-                    norm64 += fabs((double)bn);
+                    Y64(norm64 += fabs((double)bn);)
                 }
             }
         }
@@ -91,7 +101,7 @@ void FN(orc_accumulator_update)(const T *a, T *b, T *d, T tk, int ax, T clip, in
                     const T bn = FN(orc_clip)(v, clip);
                     br[x] = bn;
                     norm += (T)fabs((double)bn);
-                    norm64 += fabs((double)bn);
+                    Y64(norm64 += fabs((double)bn);)
                 }
             }
         }
@@ -121,7 +131,7 @@ void FN(orc_accumulator_update)(const T *a, T *b, T *d, T tk, int ax, T clip, in
                     }
                     b[x] = bn;
                     norm += (T)fabs((double)bn);
-                    norm64 += fabs((double)bn);
+                    Y64(norm64 += fabs((double)bn);)
                 }
     *norm_T = (double)norm;
     *norm_f64 = norm64;
@@ -141,7 +151,6 @@ void FN(orc_datacube_update)(const T *orig, T *recon, const T *const *b, const T
 {
     const int64_t N0 = shape[0], N1 = shape[1], N2 = shape[2], N3 = shape[3];
     const int64_t st[4] = {N1 * N2 * N3, N2 * N3, N3, 1};
-    const int a0 = 4 - nax;
     T delta = (T)0, rnorm = (T)0;
     double delta64 = 0.0, rnorm64 = 0.0;
     const int64_t outer = N0 * N1;
@@ -151,25 +160,31 @@ void FN(orc_datacube_update)(const T *orig, T *recon, const T *const *b, const T
 #endif
     for (int64_t ij = 0; ij < outer; ++ij) {
         const int64_t i = ij / N1, j = ij % N1;
-        for (int64_t k = 0; k < N2; ++k)
+        /* (i+1)%N0, (j+1)%N1, (k+1)%N2 do not depend on l: the reference's compiler hoists them out of the
+         * innermost loop too (utils.c:5574-5628); only (l+1)%N3 is evaluated per voxel */
+        const int64_t di = (((i + 1) % N0) - i) * st[0], dj = (((j + 1) % N1) - j) * st[1];
+        for (int64_t k = 0; k < N2; ++k) {
+            const int64_t dk = (((k + 1) % N2) - k) * st[2];
+            const int64_t x0 = i * st[0] + j * st[1] + k * st[2];
             for (int64_t l = 0; l < N3; ++l) {
-                const int64_t idx[4] = {i, j, k, l};
-                const int64_t x = i * st[0] + j * st[1] + k * st[2] + l;
-                T s = (T)0;
-                for (int q = 0; q < nax; ++q) {
-                    const int axq = a0 + q;
-                    const int64_t nx = x + (((idx[axq] + 1) % shape[axq]) - idx[axq]) * st[axq];
-                    T term = lm[q] * (b[q][x] - b[q][nx]);
-                    s = (q == 0) ? term : (s + term);
-                }
+                const int64_t x = x0 + l;
+                const int64_t dl = ((l + 1) % N3) - l;
+                T s;
+                if (nax == 4) /* utils.c:5641: ((t0 + t1) + t2) + t3 */
+                    s = ((lm[0] * (b[0][x] - b[0][x + di]) + lm[1] * (b[1][x] - b[1][x + dj])) +
+                         lm[2] * (b[2][x] - b[2][x + dk])) + lm[3] * (b[3][x] - b[3][x + dl]);
+                else /* 3-D: canonical axes 1,2,3 (utils.pyx:176-178) */
+                    s = (lm[0] * (b[0][x] - b[0][x + dj]) + lm[1] * (b[1][x] - b[1][x + dk])) +
+                        lm[2] * (b[2][x] - b[2][x + dl]);
                 T old = recon[x];
                 T nw = orig[x] - s;
                 recon[x] = nw;
                 delta += (T)fabs((double)(T)(nw - old));
                 rnorm += (T)fabs((double)old);
-                delta64 += fabs((double)(T)(nw - old));
-                rnorm64 += fabs((double)old);
+                Y64(delta64 += fabs((double)(T)(nw - old));)
+                Y64(rnorm64 += fabs((double)old);)
             }
+        }
     }
     out[0] = (double)(T)(delta / rnorm);
     out[1] = delta64;
@@ -192,12 +207,13 @@ void FN(orc_sum_square_error)(const T *a, const T *b, const int64_t shape[4], in
         for (int64_t kl = 0; kl < inner; ++kl) {
             T t = a[ij * inner + kl] - b[ij * inner + kl];
             acc += t * t;
-            acc64 += (double)t * (double)t;
+            Y64(acc64 += (double)t * (double)t;)
         }
     out[0] = (double)acc;
     out[1] = acc64;
 }
 
+#undef Y64
 #undef FN
 #undef CAT
 #undef CAT_

@@ -168,3 +168,68 @@ def test_large_offsets_locality(oracle, shape, fista):
     assert np.all(np.isfinite(s)) and np.all(s[:, 2] > 0)
     del be
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("plane,own,thin,k", [
+    ((512, 256, 256), 64, 3, 3),     # BASELINE configs[3]: one GPU's slab, 66-row local block of 128 MiB rows (124 GiB of state)
+    ((1024, 256, 256), 40, 2, 2),    # configs[4] planes (256 MiB rows): 2^16 tiles x 5 marches = 327 680 workgroups
+], ids=["config4-slab-66x512x256x256", "config5-plane-42x1024x256x256"])
+def test_multi_gpu_slab_shape_on_one_gpu(oracle, plane, own, thin, k):
+    """The slab one GPU holds in the 8-GPU configurations, swept exactly as `step_overlapped` sweeps it (halo rows on
+    both sides, edge rows first, then the interior), with two thin neighbour slabs on the same GPU supplying true
+    halo rows.  Windows of the result (slab edges included) against the oracle; sums against the thin-slab-free
+    total are covered by the smaller slab tests."""
+    import torch
+    from cytvdn_amd import _lib, synth
+    from cytvdn_amd.engine import HipBackend, LocalSlabs, SlabLayout
+    dt = np.dtype(np.float32)
+    shape = (thin + own + thin,) + plane
+    bounds = (0, thin, thin + own, shape[0])
+    mu = np.array([1.0, 1.0, 0.5, 0.5], dt)
+    lam = mu / dt.type(32.0)
+    bes = []
+    for r in range(3):
+        lay = SlabLayout(shape, r, 3, 2, bounds=bounds)
+        be = HipBackend(lay, dt, True, device=0, max_iters=k)
+        be.set_params(1.0 / lam, (lam / mu).astype(dt))
+        _lib.check(_lib.lib().tvdn_synth_fill(be.code, 4, _lib.shape_arr(shape), synth.SEED_4D, lay.g0 - lay.halo_lo,
+                                              lay.local_shape[0], be.orig.data_ptr(), _lib.current_stream(0)))
+        be.recon[be.cur].copy_(be.orig)
+        bes.append(be)
+    big = bes[1]
+    assert big.layout.local_shape == (own + 2,) + plane
+    assert big.layout.lo_mode == _lib.EDGE_HALO and big.layout.hi_mode == _lib.EDGE_HALO
+    grp = LocalSlabs(bes, split_sweeps=True)
+    grp.run(k, 0)
+    torch.cuda.synchronize()
+    lay = big.layout
+    orig_rows = big.orig                       # global rows g0-1 .. g1+1
+    recon_rows = big.recon_tensor()
+    row0 = lay.g0 - 1
+    A, B, Cc = plane
+    wins = [
+        ((lay.g0, 0, 0, 0), (2, 6, 8, 16)),                              # first own row (swept on its own), cube corner
+        ((lay.g1 - 2, A - 7, B - 9, Cc - 16), (2, 7, 9, 16)),            # last own row, opposite corner
+        ((lay.g0 + own // 2 - 1, A // 2, B // 2 - 3, Cc // 2), (3, 5, 6, 12)),   # interior, across a march seam
+        ((lay.g0 + 7, A - 5, 0, Cc - 12), (3, 5, 6, 12)),                # rows 7..9 of the slab: seam between two marches
+    ]
+    for start, ext in wins:
+        # the window's 2k-row halo may reach into the thin slabs: take those rows from them
+        halo = 2 * k
+        need_lo, need_hi = max(0, start[0] - halo), min(shape[0], start[0] + ext[0] + halo)
+        rows_o = torch.cat([be.orig[be.layout.row_lo:be.layout.row_hi] for be in bes], dim=0)[need_lo:need_hi] \
+            if (need_lo < row0 or need_hi > row0 + own + 2) else orig_rows[need_lo - row0:need_hi - row0]
+        x_row0 = need_lo
+        # result rows always come from the big slab
+        lo = [need_lo] + [max(0, s - halo) for s in start[1:]]
+        hi = [need_hi] + [min(n, s + e + halo) for s, e, n in zip(start[1:], ext[1:], shape[1:])]
+        x = rows_o[(slice(0, need_hi - need_lo),) + tuple(slice(a, b) for a, b in zip(lo[1:], hi[1:]))].cpu().numpy().copy()
+        ref = oracle.denoise(x, mu, k, True)["recon"]
+        inner = tuple(slice(s - a, s - a + e) for s, a, e in zip(start, lo, ext))
+        got = recon_rows[(slice(start[0] - row0, start[0] - row0 + ext[0]),)
+                         + tuple(slice(s, s + e) for s, e in zip(start[1:], ext[1:]))].cpu().numpy()
+        assert bits_equal(got, ref[inner]), (start, ext)
+    s = grp.global_sums().cpu().numpy()
+    assert np.all(np.isfinite(s)) and np.all(s[:, 2] > 0)
+    del grp, bes, big
+    torch.cuda.empty_cache()

@@ -1,0 +1,133 @@
+"""The RCCL data path itself: one process per GPU, halo rows sent device-to-device over xGMI
+(`SlabRunner.step_overlapped`: edge rows first, transfer on a side HIP stream under the interior sweep; and the
+blocking exchange), chain (Jia-Zhao) and ring (periodic BC, where with two ranks both neighbours are the same peer),
+bit for bit against the oracle.  Needs >= 2 GPUs (>= 3 for the three-rank cases): collected and SKIPPED on the
+one-GPU box, so that the first multi-GPU machine that runs the suite checks the path before any number is taken
+from it.  `bench.py --gpus N` runs the same check as a pre-flight (cytvdn_amd.distributed.selfcheck_exchange)."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+
+from golden_util import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _ngpu():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, shape, dtype_name, bc, n_f, n_p, overlap, outdir):
+    import torch
+    import torch.distributed as dist
+    from cytvdn_amd import synth
+    from cytvdn_amd.engine import HipBackend, SlabLayout, SlabRunner
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        dt = np.dtype(dtype_name)
+        nd = len(shape)
+        lay = SlabLayout(tuple(shape), rank, world, bc)
+        be = HipBackend(lay, dt, n_f > 0, device=rank, max_iters=n_f + n_p)
+        mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+        lam = mu / dt.type(32.0 if nd == 4 else 16.0)
+        be.set_params(1.0 / lam, (lam / mu).astype(dt))
+        full = synth.cube(shape, seed=91, dtype=dt) + dt.type(0.25)
+        be.set_input(full[lay.local_rows_global()])
+        run = SlabRunner(be)
+        run.overlap = bool(overlap)
+        assert run.transport == "rccl"
+        run.run(n_f, n_p)
+        own = be.recon_tensor()[lay.row_lo:lay.row_hi].cpu().numpy()
+        sums = run.global_sums().cpu().numpy()
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), own=own, sums=sums)
+    finally:
+        dist.destroy_process_group()
+
+
+CASES = [
+    # world, shape, dtype, bc, n_fista, n_plain
+    (2, (12, 3, 8, 16), "float32", 2, 6, 2),     # chain
+    (2, (10, 6, 16), "float64", 0, 5, 0),        # ring of two: left and right neighbour are the same peer
+    (3, (13, 2, 4, 8), "float32", 2, 5, 0),      # uneven slabs
+    (3, (12, 4, 8), "float32", 0, 4, 2),         # ring of three, hybrid schedule
+]
+
+
+@pytest.mark.parametrize("overlap", [True, False], ids=["overlapped", "blocking"])
+@pytest.mark.parametrize("world,shape,dtype,bc,n_f,n_p", CASES,
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_rccl_halo_exchange_matches_oracle(oracle, world, shape, dtype, bc, n_f, n_p, overlap):
+    if _ngpu() < world:
+        pytest.skip(f"needs {world} GPUs for an RCCL run (one rank per GPU); this box has {_ngpu()}")
+    import torch.multiprocessing as mp
+    from cytvdn_amd import synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.start_processes(_worker, args=(world, _free_port(), shape, dtype, bc, n_f, n_p, overlap, tmp), nprocs=world,
+                           join=True, start_method="spawn")
+        parts = [np.load(os.path.join(tmp, f"r{r}.npz")) for r in range(world)]
+    recon = np.concatenate([p["own"] for p in parts], axis=0)
+    x = synth.cube(shape, seed=91, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    its = [n_f, n_p] if (n_f and n_p) else (n_f or n_p)
+    ref = oracle.denoise(x, mu, its, n_f > 0, BC_mode=bc)
+    assert bits_equal(recon, ref["recon"])
+    np.testing.assert_allclose(parts[0]["sums"][:, 0], ref["b_norm64"], rtol=1e-12)
+    np.testing.assert_allclose(parts[0]["sums"][:, 1], ref["delta64"], rtol=1e-12)
+
+
+def _selfcheck_worker(rank, world, port, backend, outdir):
+    import json
+    import torch
+    import torch.distributed as dist
+    from cytvdn_amd.distributed import selfcheck_exchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = selfcheck_exchange(device=dev)
+        json.dump(res, open(os.path.join(outdir, f"r{rank}.json"), "w"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_exchange_selfcheck(backend):
+    """The pre-flight that bench.py runs before a multi-GPU measurement: over gloo with two ranks sharing this GPU
+    (always runs), over RCCL when the box has two GPUs."""
+    import json
+    import torch.multiprocessing as mp
+    if backend == "nccl" and _ngpu() < 2:
+        pytest.skip("needs 2 GPUs")
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.start_processes(_selfcheck_worker, args=(2, _free_port(), backend, tmp), nprocs=2, join=True,
+                           start_method="spawn")
+        res = [json.load(open(os.path.join(tmp, f"r{r}.json"))) for r in range(2)]
+    assert res[0] == res[1]
+    assert res[0]["blocking"] and res[0]["overlap"] and res[0]["error"] is None
+    assert res[0]["transport"] == ("rccl" if backend == "nccl" else "gloo")

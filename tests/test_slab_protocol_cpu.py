@@ -40,6 +40,20 @@ def test_layout_chain_and_ring():
         SlabLayout((8, 4, 4), 0, 2, 1)
 
 
+def test_layout_explicit_bounds():
+    """Uneven slabs given as explicit row bounds (thin neighbours around one big slab: how a multi-GPU slab shape is
+    rehearsed on one GPU, tests/test_gpu_fullsize.py)."""
+    b = (0, 3, 67, 70)
+    lay = [SlabLayout((70, 2, 2, 4), r, 3, 2, bounds=b) for r in range(3)]
+    assert [(l.g0, l.g1) for l in lay] == [(0, 3), (3, 67), (67, 70)]
+    assert lay[1].local_shape == (66, 2, 2, 4) and lay[1].lo_mode == lay[1].hi_mode == _lib.EDGE_HALO
+    assert list(lay[1].local_rows_global()) == list(range(2, 68))
+    assert lay[2].hi_mode == _lib.EDGE_ZERO and lay[0].lo_mode == _lib.EDGE_BC
+    for bad in ((0, 3, 70), (0, 3, 3, 70), (1, 3, 67, 70), (0, 3, 67, 71)):
+        with pytest.raises(ValueError):
+            SlabLayout((70, 2, 2, 4), 0, 3, 2, bounds=bad)
+
+
 def test_fista_schedule_matches_reference_recurrence():
     r = fista_ratios(5)
     assert r[0] == 0.0
@@ -58,7 +72,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, shape, dtype_name, bc, n_f, n_p, outdir):
+def _worker(rank, world, port, shape, dtype_name, bc, n_f, n_p, outdir, bounds=None):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
@@ -69,7 +83,7 @@ def _worker(rank, world, port, shape, dtype_name, bc, n_f, n_p, outdir):
     try:
         dtype = np.dtype(dtype_name)
         nd = len(shape)
-        lay = SlabLayout(tuple(shape), rank, world, bc)
+        lay = SlabLayout(tuple(shape), rank, world, bc, bounds=bounds)
         be = OracleSlabBackend(lay, dtype, n_f > 0, max_iters=n_f + n_p)
         mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dtype)
         lam = mu / dtype.type(32.0 if nd == 4 else 16.0)
@@ -93,16 +107,18 @@ CASES = [
     (3, (8, 2, 3, 4), "float64", 2, 3, 2),
     (3, (7, 4, 6), "float32", 0, 4, 0),
     (2, (2, 3, 3, 4), "float32", 2, 3, 0),      # one row per slab
+    (3, (9, 2, 3, 4), "float32", 2, 4, 1, (0, 1, 8, 9)),   # explicit bounds: thin slabs around a big one
 ]
 
 
-@pytest.mark.parametrize("world,shape,dtype,bc,n_f,n_p", CASES,
-                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
-def test_slabs_reproduce_single_process(oracle, world, shape, dtype, bc, n_f, n_p):
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join("x".join(map(str, v)) if isinstance(v, tuple) else str(v) for v in c))
+def test_slabs_reproduce_single_process(oracle, case):
+    world, shape, dtype, bc, n_f, n_p = case[:6]
+    bounds = case[6] if len(case) > 6 else None
     dt = np.dtype(dtype)
     nd = len(shape)
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker, args=(world, _free_port(), shape, dtype, bc, n_f, n_p, tmp), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), shape, dtype, bc, n_f, n_p, tmp, bounds), nprocs=world, join=True)
         parts = [np.load(os.path.join(tmp, f"r{r}.npz")) for r in range(world)]
     recon = np.concatenate([p["own"] for p in parts], axis=0)
     x = synth.cube(shape, seed=91, dtype=dt) + dt.type(0.25)
