@@ -188,7 +188,8 @@ class EmulatedNeighbours:
 
     def __init__(self, be):
         import torch
-        self.be, self.torch = be, torch
+        from cytvdn_amd.engine import edge_block
+        self.be, self.torch, self.edge_block = be, torch, edge_block
         self.side = torch.cuda.Stream(device=be.device)
 
     def _step(self, tk, slot):
@@ -197,8 +198,9 @@ class EmulatedNeighbours:
         lo, hi = lay.row_lo, lay.row_hi
         main = torch.cuda.current_stream(be.device)
         main.wait_stream(self.side)
-        be.step(tk, slot, rows=(lo, lo + 1), accumulate=False)
-        be.step(tk, slot, rows=(hi - 1, hi), accumulate=True)
+        e = self.edge_block(hi - lo)
+        be.step(tk, slot, rows=(lo, lo + e), accumulate=False)
+        be.step(tk, slot, rows=(hi - e, hi), accumulate=True)
         done = torch.cuda.Event()
         done.record(main)
         r = be.recon_next()
@@ -206,7 +208,7 @@ class EmulatedNeighbours:
             self.side.wait_event(done)
             r[hi].copy_(r[lo], non_blocking=True)
             r[lo - 1].copy_(r[hi - 1], non_blocking=True)
-        be.step(tk, slot, rows=(lo + 1, hi - 1), accumulate=True)
+        be.step(tk, slot, rows=(lo + e, hi - e), accumulate=True)
         be.flip()
 
     def finish(self):

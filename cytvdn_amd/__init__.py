@@ -5,8 +5,13 @@ cyTVDN/__init__.py:1): denoise4D, denoise3D, check_memory and the kernel-level
 accumulator_update_* / datacube_update_* / sum_square_error_* functions.  All arithmetic runs in
 hand-written HIP kernels for gfx950 (libtvdn_hip.so, C ABI in include/tvdn.h); there is no CPU
 fallback: compute calls raise when the library or the GPU is missing.
+
+Beyond the reference's names: `plan_run` (HBM capacity planner: engine + slab count), `denoise_file` (memory-mapped
+file to file, the I/O half of the reference's cyTVMPI), `cytvdn_amd.distributed.denoise_slabs` (one slab per GPU).
 """
+from .cubeio import denoise_file
 from .driver import check_memory, denoise3D, denoise4D
+from .planner import plan_run
 from .kernels import (accumulator_update_3D, accumulator_update_3D_FISTA, accumulator_update_4D,
                       accumulator_update_4D_FISTA, datacube_update_3D, datacube_update_4D,
                       iso_accumulator_update_4D, iso_accumulator_update_4D_FISTA, sum_square_error_3D,
@@ -19,4 +24,5 @@ __all__ = [
     "accumulator_update_4D", "accumulator_update_4D_FISTA", "accumulator_update_3D", "accumulator_update_3D_FISTA",
     "datacube_update_4D", "datacube_update_3D", "sum_square_error_4D", "sum_square_error_3D",
     "iso_accumulator_update_4D", "iso_accumulator_update_4D_FISTA",
+    "plan_run", "denoise_file",
 ]

@@ -17,7 +17,8 @@ import numpy as np
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtvdn_hip.so")
+# TVDN_LIB: measurement aid -- load another build of the same library (e.g. a -DTVDN_NT_LOADS=0 variant)
+LIB_PATH = os.environ.get("TVDN_LIB") or os.path.join(_HERE, "libtvdn_hip.so")
 
 TVDN_F32, TVDN_F64 = 0, 1
 EDGE_BC, EDGE_HALO, EDGE_ZERO = 0, 1, 2

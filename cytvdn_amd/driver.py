@@ -25,6 +25,7 @@ import numpy as np
 import torch
 
 from .engine import HipBackend, SlabLayout, SlabRunner, hbm_plan
+from .planner import plan_run
 
 try:  # tqdm is what upstream shows (cyTVDN.py:148-152); it is optional here
     from tqdm import tqdm as _tqdm
@@ -60,7 +61,9 @@ def _split_iterations(iterations, FISTA):
 
 
 def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, reference_data, BC_mode, quiet,
-         device):
+         device, out=None):
+    """`datacube`: NumPy array, or a cubeio.LazyCube (a cube on disk, streamed in row blocks).  `out`: None (return the
+    reconstruction as a fresh array) or a cubeio.CubeWriter (write it there block by block; recon is then None)."""
     dtype = datacube.dtype
     lambdaInv = 1.0 / lam                      # cyTVDN.py:77 / :303
     lam_mu = (lam / mu).astype(dtype)          # cyTVDN.py:78 / :304
@@ -74,8 +77,8 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
         raise ValueError(f"BC_mode must be 0 or 2, got {BC_mode}")
     if datacube.size == 0:
         # nothing to sweep: upstream's loops fall through, every norm is 0 and delta_recon is 0/0 (utils.pyx:125)
-        out = (datacube.copy(), np.zeros(n_total, dtype), np.full(n_total, np.nan, dtype))
-        return out + (np.zeros(n_total + 1, dtype),) if reference_data is not None else out
+        res = (datacube.copy() if out is None else None, np.zeros(n_total, dtype), np.full(n_total, np.nan, dtype))
+        return res + (np.zeros(n_total + 1, dtype),) if reference_data is not None else res
 
     if not quiet:
         plan = hbm_plan(datacube.shape, dtype, FISTA)
@@ -84,21 +87,31 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
 
     if device is None:
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
-    staged = _staging_plan(datacube, FISTA, BC_mode, device, stopping_relative_change)
-    # a host-resident run without per-iteration host decisions takes the wavefront schedule (no redundant sweeps)
-    wf = os.environ.get("TVDN_WAVEFRONT")
-    if stopping_relative_change is None and \
-            (wf or (staged is not None and not os.environ.get("TVDN_STAGED"))):
-        plan = tuple(int(v) for v in wf.split(",")) if wf else _wavefront_plan(datacube, device)
-        if plan is not None:
-            if not quiet:
-                print(f"State exceeds HBM: streaming the cube from pinned host memory, {plan[1]} iterations per pass "
-                      f"(wavefront schedule, {plan[0]}-row chunks)", flush=True)
-            return _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device,
-                                  BC_mode, reference_data)
-    if staged is not None:
-        return _run_staged(staged, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain,
-                           stopping_relative_change, reference_data, BC_mode, quiet, device)
+    # engine choice (cytvdn_amd/planner.py): in-core when the state fits in the free HBM (or in TVDN_HBM_LIMIT),
+    # otherwise streamed from pinned host memory -- wavefront schedule, or trapezoid blocks with k = 1 when a
+    # stopping rule needs a host decision after every iteration.  TVDN_WAVEFRONT / TVDN_STAGED = "rows,k" force one.
+    stop = stopping_relative_change
+    wf, st = os.environ.get("TVDN_WAVEFRONT"), os.environ.get("TVDN_STAGED")
+    plan = plan_run(datacube.shape, dtype, FISTA, 1, stop=stop is not None, device=device)
+    if plan["mode"] == "does-not-fit" and not (wf or st):
+        raise MemoryError(f"cube of shape {datacube.shape} cannot be streamed through {_fmt_bytes(plan['hbm_bytes'])} "
+                          f"of HBM: {plan['why']}")
+    if stop is None and (wf or (plan["mode"] == "wavefront" and not st)):
+        rows_k = tuple(int(v) for v in wf.split(",")) if wf else (plan["chunk_rows"], plan["k"])
+        if not quiet:
+            print(f"State exceeds HBM: streaming the cube from pinned host memory, {rows_k[1]} iterations per pass "
+                  f"(wavefront schedule, {rows_k[0]}-row chunks)", flush=True)
+        return _run_wavefront(rows_k, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device,
+                              BC_mode, reference_data, out)
+    if st or plan["mode"] in ("trapezoid", "wavefront"):
+        if st:
+            rows, k = (int(v) for v in st.split(","))
+        else:
+            rows, k = plan["chunk_rows"], plan["k"]
+        if stop is not None:
+            k = 1      # the stopping test is per iteration (cyTVDN.py:189-194): no temporal blocking then
+        return _run_staged((max(1, rows), max(1, k)), datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista,
+                           n_plain, stop, reference_data, BC_mode, quiet, device, out)
     layout = SlabLayout(tuple(datacube.shape), 0, 1, int(BC_mode))
     be = HipBackend(layout, dtype, FISTA, device=device, max_iters=n_total)   # raises without a GPU
     be.set_params(lambdaInv, lam_mu)
@@ -153,7 +166,7 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
     num, den = sums[:, 1].astype(dtype), sums[:, 2].astype(dtype)
     with np.errstate(divide="ignore", invalid="ignore"):
         delta_recon = np.where(ran, num / den, dtype.type(0)).astype(dtype)   # divided in the data dtype (utils.pyx:125)
-    recon = be.recon_to_host()
+    recon = be.recon_to_host(out)
 
     if stopping_relative_change is not None and not quiet and unaccelerated and n_plain and not ran[-1]:
         print(f"Stopping condition reached after {int(np.nonzero(ran)[0][-1])} iterations, stopping.")
@@ -163,50 +176,8 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
     return recon, b_norm, delta_recon
 
 
-def _staging_plan(datacube, FISTA, BC_mode, device, stop):
-    """None when the state fits in HBM; otherwise (block_rows, k) for the out-of-core engine.
-    TVDN_STAGED="rows,k" forces staging (tests, measurements)."""
-    forced = os.environ.get("TVDN_STAGED")
-    plane_bytes = int(np.prod(datacube.shape[1:])) * datacube.dtype.itemsize
-    n_arr = hbm_plan(datacube.shape, datacube.dtype, FISTA)["arrays"]
-    if forced:
-        rows, k = (int(v) for v in forced.split(","))
-    else:
-        fr = _hbm_free(device)
-        if fr is None or n_arr * datacube.nbytes < 0.9 * fr[0]:
-            return None
-        # three staging buffers of (rows + 2k) rows each must fit in 80 % of the free HBM; deep temporal
-        # blocking is what makes the mode worth using (measured: k 16 -> 9, k 32 -> 21, k 64 -> 29 Gvoxel-iters/s)
-        per_row = 3 * (n_arr + 1) * plane_bytes
-        k = 64
-        rows = int(0.8 * fr[0] / per_row) - 2 * k
-        while rows < k and k > 1:
-            k //= 2
-            rows = int(0.8 * fr[0] / per_row) - 2 * k
-        rows = max(1, rows)
-    if stop is not None:
-        k = 1      # the stopping test is per iteration (cyTVDN.py:189-194): no temporal blocking then
-    return max(1, rows), max(1, k)
-
-
-def _wavefront_plan(datacube, device):
-    """(chunk_rows, k) whose level windows fit in 70 % of the free HBM, deepest first (measured on config-2 planes:
-    k 32 -> 36, k 64 -> 55-58, k 128 -> 60 Gvoxel-iters/s)."""
-    fr = _hbm_free(device)
-    if fr is None:
-        return None
-    nd = datacube.ndim
-    plane = int(np.prod(datacube.shape[1:])) * datacube.dtype.itemsize
-    for k, rows in ((64, 32), (64, 16), (32, 16), (16, 16), (8, 8), (4, 4), (2, 2)):
-        rows = min(rows, max(2, datacube.shape[0]))
-        need = ((k + 1) + (k + 2) * nd) * (rows + 3) + (rows + k + 3) + 2 * (3 + 4 * nd) * rows
-        if need * plane < 0.7 * fr[0]:
-            return rows, k
-    return None
-
-
 def _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device, BC_mode=2,
-                   reference_data=None):
+                   reference_data=None, out=None):
     """Host-resident state, wavefront schedule (cytvdn_amd/wavefront.py): anything but a stopping rule."""
     from .wavefront import WavefrontRunner
     dtype = datacube.dtype
@@ -220,12 +191,12 @@ def _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fi
     with np.errstate(divide="ignore", invalid="ignore"):
         delta_recon = (sums[:, 1].astype(dtype) / sums[:, 2].astype(dtype)).astype(dtype)
     if reference_data is not None:
-        return wr.recon(), b_norm, delta_recon, wr.mse().astype(dtype)
-    return wr.recon(), b_norm, delta_recon
+        return wr.recon(out), b_norm, delta_recon, wr.mse().astype(dtype)
+    return wr.recon(out), b_norm, delta_recon
 
 
 def _run_staged(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, stop, reference_data,
-                BC_mode, quiet, device):
+                BC_mode, quiet, device, out=None):
     from .outofcore import StagedRunner
     if BC_mode != 2:
         raise NotImplementedError("a host-staged run with a stopping rule or reference_data supports BC_mode=2 only")
@@ -257,7 +228,7 @@ def _run_staged(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista
     num, den = sums[:, 1].astype(dtype), sums[:, 2].astype(dtype)
     with np.errstate(divide="ignore", invalid="ignore"):
         delta_recon = np.where(ran, num / den, dtype.type(0)).astype(dtype)
-    recon = sr.recon()
+    recon = sr.recon(out)
     if reference_data is not None:
         return recon, b_norm, delta_recon, sr.mse().astype(dtype)
     return recon, b_norm, delta_recon
@@ -395,9 +366,10 @@ def check_memory(datacube, device: int = 0):
     print(f"Datacube size is {_fmt_bytes(datacube.nbytes)} with dtype {dtype}")
     if avail is not None:
         print(f"Free HBM on device {device}: {_fmt_bytes(avail)}")
-        fits = hbm_plan(shape, dtype, True)["bytes"] < 0.9 * avail
-        print("Engine denoise3D/4D will use (FISTA): " + ("in-core fused sweep" if fits else
-              "cube streamed from pinned host memory (wavefront schedule; trapezoid blocks with a stopping rule)"))
+        for fista in (True, False):
+            p = plan_run(shape, dtype, fista, 1, device=device)
+            extra = f", {p['chunk_rows']}-row chunks, {p['k']} iterations per pass" if p["k"] else ""
+            print(f"denoise{len(shape)}D ({'FISTA' if fista else 'unaccelerated'}) will run: {p['mode']}{extra} -- {p['why']}")
     try:
         from tabulate import tabulate
         print(tabulate(rows, ["Algorithm", "HBM Needed", "State", "OK?"]))

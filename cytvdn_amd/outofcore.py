@@ -115,13 +115,21 @@ class StagedRunner:
         def host(fill=None):
             t = torch.empty(self.shape, dtype=tdt, pin_memory=pin)
             t.zero_()
-            if fill is not None:
+            if fill is not None and hasattr(fill, "read_rows"):      # a cube on disk (cubeio.LazyCube): block by block
+                own = t[own_sl]
+                step = fill.block_rows()
+                for a in range(0, own.shape[0], step):
+                    own[a:a + step].copy_(torch.from_numpy(fill.read_rows(a, min(a + step, own.shape[0]))))
+            elif fill is not None:
                 t[own_sl].copy_(torch.from_numpy(fill))
             return t
 
+        def as_source(x):
+            return x if hasattr(x, "read_rows") else np.ascontiguousarray(x)
+
         # host state: orig, recon old/new, per axis up to two state arrays old/new
-        self.orig_h = host(np.ascontiguousarray(datacube))
-        self.recon_h = [host(np.ascontiguousarray(datacube)), host()]
+        self.orig_h = host(as_source(datacube))
+        self.recon_h = [host(as_source(datacube)), host()]
         n_state = 2 if self.fista else 1
         self.state_h = [[[host() for _ in range(n_state)] for _ in range(self.nd)] for _ in range(2)]  # [old/new][axis][j]
         self.ref_h = host(np.ascontiguousarray(reference)) if reference is not None else None
@@ -294,9 +302,10 @@ class StagedRunner:
     def mse(self) -> np.ndarray:
         return self._allreduce(sum(be.mse for be in self.stages).clone()).cpu().numpy()
 
-    def recon(self) -> np.ndarray:
-        """This rank's own rows of the current reconstruction."""
-        return self.recon_h[self.h_old][self.ext_lo:self.ext_lo + self.own].numpy().copy()
+    def recon(self, out=None):
+        """This rank's own rows of the current reconstruction (with `out`, a cubeio.CubeWriter: written there)."""
+        from .wavefront import _write_or_copy
+        return _write_or_copy(self.recon_h[self.h_old][self.ext_lo:self.ext_lo + self.own].numpy(), out)
 
 
 __all__ = ["StagedRunner", "plan_blocks"]

@@ -1,0 +1,140 @@
+"""Capacity planner for HBM: which engine runs a cube, with how many slabs.
+
+The reference's `check_memory` (cyTVDN/cyTVDN.py:438-467) adds up host RAM for its four algorithm variants and
+prints a table; the choice is left to the user.  Here the same sum is done for HBM and the choice is made:
+
+    plan = plan_run(shape, dtype, FISTA=True, n_gpus=8)
+    plan["mode"]      "in-core"            one GPU holds the whole state: one fused sweep per iteration
+                      "slabs"              axis 0 cut into plan["n_slabs"] slabs, one GPU each, halo rows over RCCL
+                      "wavefront"          one GPU, state in pinned host memory, streamed plan["k"] iterations per
+                                           pass in plan["chunk_rows"]-row chunks (cytvdn_amd/wavefront.py)
+                      "trapezoid"          the same with a decision after every iteration (stopping rule; k = 1)
+                      "slabs+wavefront"    every GPU streams its own slab from pinned host memory (BASELINE config 5)
+                      "does-not-fit"       not even one chunk window fits
+
+`denoise3D/4D` call it with n_gpus = 1 for their own choice (driver._run); `check_memory` prints it.
+The HBM figure is the free memory of the device (`torch.cuda.mem_get_info`) unless `hbm_bytes` is given or the
+environment variable TVDN_HBM_LIMIT (bytes; suffixes K/M/G/T = KiB.. allowed, e.g. "48G") caps it -- the knob that
+lets a test, or a cautious user sharing a GPU, drive the automatic out-of-core branch on a small cube.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+HEADROOM = 0.9            # fraction of the free HBM an in-core state may take
+STAGING_FRACTION = 0.7    # fraction the level windows of a streamed run may take
+
+
+def _parse_bytes(text: str) -> int:
+    t = text.strip().upper().rstrip("B").rstrip("I")
+    mult = {"K": 2 ** 10, "M": 2 ** 20, "G": 2 ** 30, "T": 2 ** 40}
+    if t and t[-1] in mult:
+        return int(float(t[:-1]) * mult[t[-1]])
+    return int(float(t))
+
+
+def hbm_available(device: int = 0, hbm_bytes: int = None):
+    """Bytes of HBM the planner may count on: explicit > min(TVDN_HBM_LIMIT, free) > free > None (no GPU)."""
+    if hbm_bytes is not None:
+        return int(hbm_bytes)
+    free = None
+    try:
+        import torch
+        if torch.cuda.is_available():
+            free = int(torch.cuda.mem_get_info(device)[0])
+    except Exception:
+        free = None
+    cap = os.environ.get("TVDN_HBM_LIMIT")
+    if cap:
+        cap = _parse_bytes(cap)
+        return cap if free is None else min(cap, free)
+    return free
+
+
+def state_arrays(ndim: int, fista: bool) -> int:
+    """Arrays of the fused engine's state: orig, recon x2, and per axis three rotating d arrays (FISTA) or two b."""
+    return 3 + ndim * (3 if fista else 2)
+
+
+def wavefront_windows(ndim: int, rows: int, k: int) -> int:
+    """Rows of HBM the wavefront engine keeps resident for chunk height `rows` and depth k (wavefront.py: recon
+    windows for levels 0..k, accumulator windows for levels -1..k per axis, the input window, in/out boxes)."""
+    return ((k + 1) + (k + 2) * ndim) * (rows + 3) + (rows + k + 3) + 2 * (3 + 4 * ndim) * rows
+
+
+def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int = None, stop: bool = False,
+             device: int = 0, host_bytes: int = None) -> dict:
+    """Pick the engine and the slab count for a cube of `shape` / `dtype` on `n_gpus` GPUs of `hbm_bytes` each.
+
+    Returns a dict: mode, n_slabs, arrays, bytes_per_gpu (HBM the chosen mode needs per GPU), state_bytes (whole
+    state), hbm_bytes (what was assumed available), chunk_rows / k for streamed modes, host_bytes_per_rank for them,
+    min_slabs_in_core (smallest slab count whose slab state fits, or None), and a one-line `why`."""
+    shape = tuple(int(s) for s in shape)
+    nd = len(shape)
+    if nd not in (3, 4):
+        raise TypeError("No matching signature found")
+    item = np.dtype(dtype).itemsize
+    plane = int(np.prod(shape[1:])) * item
+    n0 = shape[0]
+    n_arr = state_arrays(nd, FISTA)
+    avail = hbm_available(device, hbm_bytes)
+    out = dict(arrays=n_arr, state_bytes=n_arr * n0 * plane, hbm_bytes=avail, n_gpus=int(n_gpus), n_slabs=1,
+               chunk_rows=None, k=None, host_bytes_per_rank=None, min_slabs_in_core=None)
+    if avail is None:                       # no GPU visible: nothing to plan against, say what would be needed
+        out.update(mode="in-core", bytes_per_gpu=out["state_bytes"], why="no GPU visible: HBM need only")
+        return out
+
+    def slab_bytes(s):                      # tallest slab of an s-way split, with its halo rows
+        rows = -(-n0 // s) + (2 if s > 1 else 0)
+        return n_arr * rows * plane
+
+    max_slabs = max(1, min(int(n_gpus), n0))
+    for s in range(1, n0 + 1):
+        if slab_bytes(s) <= HEADROOM * avail:
+            out["min_slabs_in_core"] = s
+            break
+    if slab_bytes(1) <= HEADROOM * avail and n_gpus <= 1:
+        out.update(mode="in-core", bytes_per_gpu=slab_bytes(1), why=f"{n_arr} arrays fit in {HEADROOM:.0%} of the HBM")
+        return out
+    if n_gpus > 1 and slab_bytes(max_slabs) <= HEADROOM * avail:
+        out.update(mode="slabs", n_slabs=max_slabs, bytes_per_gpu=slab_bytes(max_slabs),
+                   why=f"one slab per GPU ({-(-n0 // max_slabs)} rows + halo rows) fits; fewest slabs that would: "
+                       f"{out['min_slabs_in_core']}")
+        return out
+    # streamed from pinned host memory: deepest temporal blocking whose windows fit
+    s = max_slabs
+    rows_own = -(-n0 // s)
+    if stop:
+        # a stopping rule wants a host decision after every iteration: trapezoid engine, k = 1, three staging buffers
+        per_row = 3 * (n_arr + 1) * plane
+        rows = int(STAGING_FRACTION * avail / per_row) - 2
+        if rows < 1:
+            out.update(mode="does-not-fit", bytes_per_gpu=per_row * 3, why="not even a one-row block fits")
+            return out
+        out.update(mode="trapezoid" if s == 1 else "slabs+trapezoid", n_slabs=s, chunk_rows=min(rows, rows_own), k=1,
+                   bytes_per_gpu=per_row * (min(rows, rows_own) + 2),
+                   host_bytes_per_rank=(3 + 2 * nd * (2 if FISTA else 1)) * (rows_own + 2) * plane,
+                   why="state exceeds HBM and the stopping rule needs a decision every iteration")
+        return out
+    for k, rows in ((64, 32), (64, 16), (32, 16), (32, 8), (16, 16), (16, 8), (16, 4), (8, 8), (8, 4), (4, 4), (4, 2), (2, 2),
+                    (1, 2)):       # depth first: PCIe traffic per iteration falls as 1/k
+        rows = min(rows, max(2, rows_own))
+        k = min(k, max(1, rows_own))
+        need = wavefront_windows(nd, rows, k) * plane
+        if need <= STAGING_FRACTION * avail:
+            out.update(mode="wavefront" if s == 1 else "slabs+wavefront", n_slabs=s, chunk_rows=rows, k=k,
+                       bytes_per_gpu=need,
+                       host_bytes_per_rank=(3 + 2 * nd * (2 if FISTA else 1)) * (rows_own + 2 * k) * plane,
+                       why=f"state of {out['state_bytes'] / 2 ** 30:.1f} GiB exceeds "
+                           f"{s} x {avail / 2 ** 30:.1f} GiB of HBM: streamed from pinned host memory")
+            if host_bytes is not None and out["host_bytes_per_rank"] > host_bytes:
+                out["why"] += " (WARNING: the pinned host state does not fit in the host memory given)"
+            return out
+    out.update(mode="does-not-fit", bytes_per_gpu=wavefront_windows(nd, 2, 1) * plane,
+               why="not even a 2-row chunk window fits in HBM")
+    return out
+
+
+__all__ = ["plan_run", "hbm_available", "state_arrays", "wavefront_windows"]

@@ -26,6 +26,16 @@ from . import _lib
 from .engine import fista_ratios
 
 
+def _write_or_copy(own: np.ndarray, out):
+    if out is None:
+        return own.copy()
+    row_bytes = max(1, own[0].nbytes)
+    step = max(1, min(own.shape[0], (256 << 20) // row_bytes))
+    for a in range(0, own.shape[0], step):
+        out.write_rows(a, own[a:a + step])
+    return None
+
+
 class _Window:
     """Sliding window of rows [base, top) of one array, stored from buffer row 0."""
 
@@ -116,12 +126,20 @@ class WavefrontRunner:
         def host(fill=None):
             t = torch.empty(self.shape, dtype=tdt, pin_memory=pin)
             t.zero_()
-            if fill is not None:
+            if fill is not None and hasattr(fill, "read_rows"):      # a cube on disk (cubeio.LazyCube): block by block
+                own = t[own_sl]
+                step = fill.block_rows()
+                for a in range(0, own.shape[0], step):
+                    own[a:a + step].copy_(torch.from_numpy(fill.read_rows(a, min(a + step, own.shape[0]))))
+            elif fill is not None:
                 t[own_sl].copy_(torch.from_numpy(fill))
             return t
 
-        self.orig_h = host(np.ascontiguousarray(datacube))
-        self.recon_h = [host(np.ascontiguousarray(datacube)), host()]
+        def as_source(x):
+            return x if hasattr(x, "read_rows") else np.ascontiguousarray(x)
+
+        self.orig_h = host(as_source(datacube))
+        self.recon_h = [host(as_source(datacube)), host()]
         n_state = 2 if self.fista else 1
         self.state_h = [[[host() for _ in range(n_state)] for _ in range(self.nd)] for _ in range(2)]
         self.ref_h = host(np.ascontiguousarray(reference)) if reference is not None else None
@@ -398,9 +416,10 @@ class WavefrontRunner:
             self.dist.all_reduce(t, group=self.group)
         return t.cpu().numpy()
 
-    def recon(self) -> np.ndarray:
-        """This rank's own rows of the current reconstruction."""
-        return self.recon_h[self.h_old][self.ext_lo:self.ext_lo + (self.g1 - self.g0)].numpy().copy()
+    def recon(self, out=None):
+        """This rank's own rows of the current reconstruction (with `out`, a cubeio.CubeWriter: written there)."""
+        own = self.recon_h[self.h_old][self.ext_lo:self.ext_lo + (self.g1 - self.g0)].numpy()
+        return _write_or_copy(own, out)
 
 
 __all__ = ["WavefrontRunner"]

@@ -44,8 +44,8 @@ def build(force: bool = False) -> None:
         os.path.getmtime(_LIB_PATH)
         < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("tvdn_oracle.c", "tvdn_oracle_impl.h"))
     ) or not os.path.exists(os.path.join(_HERE, "libtvdn_oracle_timed.so")):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle"])
-    subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle"], stdout=sys.stderr)
+    subprocess.check_call(["make", "-s", "-C", _HERE, "ref"], stdout=sys.stderr)   # bench.py's stdout carries one JSON line only
 
 
 def lib():

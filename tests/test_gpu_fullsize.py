@@ -179,9 +179,12 @@ def test_multi_gpu_slab_shape_on_one_gpu(oracle, plane, own, thin, k):
     both sides, edge rows first, then the interior), with two thin neighbour slabs on the same GPU supplying true
     halo rows.  Windows of the result (slab edges included) against the oracle; sums against the thin-slab-free
     total are covered by the smaller slab tests."""
+    import gc
     import torch
     from cytvdn_amd import _lib, synth
     from cytvdn_amd.engine import HipBackend, LocalSlabs, SlabLayout
+    gc.collect()
+    torch.cuda.empty_cache()                    # 140-180 GiB in one piece: start from an empty allocator
     dt = np.dtype(np.float32)
     shape = (thin + own + thin,) + plane
     bounds = (0, thin, thin + own, shape[0])
@@ -231,5 +234,6 @@ def test_multi_gpu_slab_shape_on_one_gpu(oracle, plane, own, thin, k):
         assert bits_equal(got, ref[inner]), (start, ext)
     s = grp.global_sums().cpu().numpy()
     assert np.all(np.isfinite(s)) and np.all(s[:, 2] > 0)
-    del grp, bes, big
+    del grp, bes, big, be, orig_rows, recon_rows, rows_o, got
+    gc.collect()
     torch.cuda.empty_cache()

@@ -42,6 +42,9 @@ def test_one_pass_kernels_on_device_tensors(tv, oracle, shape, dtype):
     ta = torch.from_numpy(a).cuda()
     clip, tk = dt.type(0.8), dt.type(0.41)
     sfx = f"{nd}D"
+    # f32 data summed in f64 is exact to the last few bits whatever the order; for f64 data the oracle's serial running
+    # sum over millions of terms and the tree sum here each carry ~1e-11 of rounding
+    stol = 1e-12 if dt == np.float32 else 1e-9
     for ax in range(nd):
         for bc in (0, 1, 2):
             for fista in (False, True):
@@ -55,7 +58,7 @@ def test_one_pass_kernels_on_device_tensors(tv, oracle, shape, dtype):
                     ret = getattr(tv, f"accumulator_update_{sfx}")(ta, tb, ax, clip, BC_mode=bc)
                     _, n64 = oracle.acc_update(a, b, None, 0.0, ax, clip, bc)
                 assert bits_equal(tb.cpu().numpy(), b), (ax, bc, fista)
-                assert ret == pytest.approx(n64, rel=1e-12)
+                assert ret == pytest.approx(n64, rel=stol)
     assert bits_equal(ta.cpu().numpy(), a)     # the read-only role is untouched
     orig, bs = _rand(rng, shape, dt, 3.0), [_rand(rng, shape, dt, 0.7) for _ in range(nd)]
     lm = np.array([1 / 32, 1 / 40, 1 / 64, 1 / 33][:nd]).astype(dt)
@@ -66,10 +69,11 @@ def test_one_pass_kernels_on_device_tensors(tv, oracle, shape, dtype):
         ret = getattr(tv, f"datacube_update_{sfx}")(to, tr, *tbs, lm, BC_mode=bc)
         _, dl, rn = oracle.recon_update(orig, recon, bs, lm, bc)
         assert bits_equal(tr.cpu().numpy(), recon), bc
-        assert ret == pytest.approx(float(dt.type(dl) / dt.type(rn)), rel=1e-6 if dt == np.float32 else 1e-12)
+        assert ret == pytest.approx(float(dt.type(dl) / dt.type(rn)), rel=1e-6 if dt == np.float32 else 1e-9)
     r2 = _rand(rng, shape, dt, 3.0)
     got = getattr(tv, f"sum_square_error_{sfx}")(to, torch.from_numpy(r2).cuda())
-    assert got == pytest.approx(oracle.sse(orig, r2)[1], rel=1e-12)
+    # squares are formed in the array dtype (utils.pyx:26), the oracle's yardstick squares in f64
+    assert got == pytest.approx(oracle.sse(orig, r2)[1], rel=1e-6 if dt == np.float32 else 1e-9)
 
 
 @pytest.mark.parametrize("chunk", ["3", "8"])
@@ -128,7 +132,7 @@ def test_dlpack_producers_are_updated_in_place(tv, oracle):
     oracle.recon_update(orig, recon, bs, lm, 2)
     assert bits_equal(tr.cpu().numpy(), recon)
     got = tv.sum_square_error_4D(_DLPackOnly(tr), _DLPackOnly(ta))
-    assert got == pytest.approx(oracle.sse(recon, a)[1], rel=1e-12)
+    assert got == pytest.approx(oracle.sse(recon, a)[1], rel=1e-6)
 
 
 def test_reduction_scratch_grows_and_folds_in_two_stages(tv, oracle):
@@ -139,8 +143,9 @@ def test_reduction_scratch_grows_and_folds_in_two_stages(tv, oracle):
     shape, dt = (300000 * 8, 1, 128), np.dtype(np.float32)      # 3-D with a unit middle axis: 32 units -> 1 tile per row
     a = _rand(rng, shape, dt, 1.0)
     b = _rand(rng, shape, dt, 1.0)
-    got = tv.sum_square_error_3D(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())      # 2.3e4 workgroups
-    assert got == pytest.approx(oracle.sse(a, b)[1], rel=1e-12)
+    got = tv.sum_square_error_3D(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())      # 3.7e4 workgroups
+    want = float(np.sum(((a - b) * (a - b)).astype(np.float64)))       # squares in f32 as upstream, summed in f64
+    assert got == pytest.approx(want, rel=1e-12)
     tb = torch.from_numpy(b).cuda()
     b2 = b.copy()
     ret = tv.accumulator_update_3D(torch.from_numpy(a).cuda(), tb, 0, np.float32(0.5))           # 3e5 marches of 8 rows

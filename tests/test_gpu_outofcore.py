@@ -102,3 +102,36 @@ def test_wavefront_equals_in_core(oracle, monkeypatch, shape, dtype, its, fista,
     assert bits_equal(got[0], ref["recon"])
     for a, b in zip(got[1:], want[1:]):
         np.testing.assert_allclose(a, b, rtol=1e-6 if dt == np.float32 else 1e-12)
+
+
+@pytest.mark.parametrize("stop", [None, 0.05], ids=["no-stop-rule", "stop-rule"])
+def test_planner_picks_the_streamed_engines_by_itself(oracle, monkeypatch, stop):
+    """with the HBM the planner may count on capped (TVDN_HBM_LIMIT) below the 39 MB this cube's state
+    needs, denoise4D must choose the out-of-core engine on its own -- wavefront schedule without a stopping rule,
+    trapezoid blocks with k = 1 with one -- and still return the oracle's bits."""
+    import cytvdn_amd as tv
+    from cytvdn_amd import driver, synth
+    calls = []
+    real_wf, real_st = driver._run_wavefront, driver._run_staged
+    monkeypatch.setattr(driver, "_run_wavefront", lambda plan, *a, **k: (calls.append(("wavefront", plan)), real_wf(plan, *a, **k))[1])
+    monkeypatch.setattr(driver, "_run_staged", lambda plan, *a, **k: (calls.append(("trapezoid", plan)), real_st(plan, *a, **k))[1])
+    monkeypatch.delenv("TVDN_WAVEFRONT", raising=False)
+    monkeypatch.delenv("TVDN_STAGED", raising=False)
+    monkeypatch.setenv("TVDN_HBM_LIMIT", "24M")
+    shape, dt = (40, 8, 32, 64), np.dtype(np.float32)
+    x = synth.cube(shape, seed=5, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 1.0, 0.5, 0.5], dt)
+    its = [5, 3] if stop is None else 30
+    got = tv.denoise4D(x, mu, its, FISTA=True, stopping_relative_change=stop, quiet=True)
+    ref = oracle.denoise(x, mu, its, True, stopping_relative_change=stop)
+    assert calls and calls[0][0] == ("wavefront" if stop is None else "trapezoid"), calls
+    if stop is not None:
+        assert calls[0][1][1] == 1                                   # k = 1: a decision after every iteration
+        assert 0 < np.count_nonzero(got[2]) < 30                     # the rule did fire
+    assert bits_equal(got[0], ref["recon"])
+    assert np.array_equal(got[2] == 0, ref["delta_recon"] == 0)
+    # the same call with room to spare stays in core and gives the same bits
+    calls.clear()
+    monkeypatch.setenv("TVDN_HBM_LIMIT", "4G")
+    again = tv.denoise4D(x, mu, its, FISTA=True, stopping_relative_change=stop, quiet=True)
+    assert not calls and bits_equal(again[0], got[0])

@@ -1,0 +1,55 @@
+"""Capacity planner: engine and slab count for BASELINE.json's five configurations on 288 GB
+devices, and the TVDN_HBM_LIMIT knob.  Pure arithmetic: runs without a GPU."""
+import pytest
+
+from cytvdn_amd.planner import _parse_bytes, plan_run, state_arrays, wavefront_windows
+
+GIB = 2 ** 30
+HBM = 268 * GIB       # what an MI355X reports free (288 GB)
+
+
+def test_state_arrays():
+    assert state_arrays(4, True) == 15 and state_arrays(4, False) == 11
+    assert state_arrays(3, True) == 12 and state_arrays(3, False) == 9
+
+
+def test_baseline_configs():
+    c1 = plan_run((128, 128, 512), "float32", True, 1, hbm_bytes=HBM)
+    assert c1["mode"] == "in-core" and c1["bytes_per_gpu"] == 12 * 32 * 2 ** 20
+    c2 = plan_run((256, 256, 128, 128), "float32", True, 1, hbm_bytes=HBM)
+    assert c2["mode"] == "in-core" and c2["bytes_per_gpu"] == 60 * GIB and c2["n_slabs"] == 1
+    c3 = plan_run((256, 256, 128, 128), "float64", False, 1, hbm_bytes=HBM)
+    assert c3["mode"] == "in-core" and c3["bytes_per_gpu"] == 88 * GIB
+    c4 = plan_run((512, 512, 256, 256), "float32", True, 8, hbm_bytes=HBM)
+    assert c4["mode"] == "slabs" and c4["n_slabs"] == 8 and c4["min_slabs_in_core"] == 5
+    assert c4["bytes_per_gpu"] == 15 * 66 * 128 * 2 ** 20            # 64 own rows + 2 halo rows of 128 MiB
+    # the same cube on fewer GPUs than it needs, or on one: streamed from pinned host memory
+    assert plan_run((512, 512, 256, 256), "float32", True, 4, hbm_bytes=HBM)["mode"] == "slabs+wavefront"
+    one = plan_run((512, 512, 256, 256), "float32", True, 1, hbm_bytes=HBM)
+    assert one["mode"] == "wavefront" and one["k"] >= 2 and one["bytes_per_gpu"] <= 0.7 * HBM
+    assert one["bytes_per_gpu"] == wavefront_windows(4, one["chunk_rows"], one["k"]) * 128 * 2 ** 20
+    c5 = plan_run((1024, 1024, 256, 256), "float32", True, 8, hbm_bytes=HBM)
+    assert c5["mode"] == "slabs+wavefront" and c5["n_slabs"] == 8 and c5["min_slabs_in_core"] > 8
+    assert c5["state_bytes"] == 15 * 256 * GIB
+    assert c5["host_bytes_per_rank"] == 19 * (128 + 2 * c5["k"]) * 256 * 2 ** 20
+
+
+def test_stop_rule_selects_per_iteration_engine():
+    p = plan_run((512, 512, 256, 256), "float32", True, 1, hbm_bytes=HBM, stop=True)
+    assert p["mode"] == "trapezoid" and p["k"] == 1 and p["chunk_rows"] >= 1
+    assert plan_run((256, 256, 128, 128), "float32", True, 1, hbm_bytes=HBM, stop=True)["mode"] == "in-core"
+
+
+def test_limit_knob_and_misfits(monkeypatch):
+    assert _parse_bytes("48G") == 48 * GIB and _parse_bytes("24M") == 24 * 2 ** 20 and _parse_bytes("1.5GiB") == int(1.5 * GIB)
+    assert _parse_bytes("1000") == 1000
+    monkeypatch.setenv("TVDN_HBM_LIMIT", "24M")
+    p = plan_run((40, 8, 32, 64), "float32", True, 1)      # 39 MB of state against 24 MB
+    assert p["hbm_bytes"] == 24 * 2 ** 20 and p["mode"] == "wavefront" and (p["chunk_rows"], p["k"]) == (2, 4)
+    assert plan_run((40, 8, 32, 64), "float32", True, 1, stop=True)["mode"] == "trapezoid"
+    monkeypatch.setenv("TVDN_HBM_LIMIT", "1G")
+    assert plan_run((40, 8, 32, 64), "float32", True, 1)["mode"] == "in-core"
+    monkeypatch.setenv("TVDN_HBM_LIMIT", "64K")
+    assert plan_run((40, 8, 32, 64), "float32", True, 1)["mode"] == "does-not-fit"
+    with pytest.raises(TypeError):
+        plan_run((4, 4), "float32")
