@@ -55,10 +55,11 @@ class RunArgs(C.Structure):
     _fields_ = [
         ("dtype", C.c_int32), ("ndim", C.c_int32), ("shape", C.c_int64 * 4),
         ("bc_mode", C.c_int32), ("device", C.c_int32), ("n_fista", C.c_int32), ("n_plain", C.c_int32),
-        ("use_stop", C.c_int32), ("reserved", C.c_int32), ("stop", C.c_double),
+        ("use_stop", C.c_int32), ("n_devices", C.c_int32), ("stop", C.c_double),
         ("clip", C.c_double * 4), ("lambda_mu", C.c_double * 4),
         ("data", C.c_void_p), ("reference", C.c_void_p), ("recon_out", C.c_void_p),
         ("sums_out", C.c_void_p), ("mse_out", C.c_void_p), ("iters_run", C.c_void_p),
+        ("devices", C.c_int32 * 16),
     ]
 
 
@@ -105,7 +106,7 @@ def lib():
     L.tvdn_synth_fill.argtypes = [C.c_int, C.c_int, i64p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header and library out of step
-    if L.tvdn_abi_version() != 1:
+    if L.tvdn_abi_version() != 2:
         raise TvdnError("libtvdn_hip.so ABI version mismatch")
     _lib = L
     return L

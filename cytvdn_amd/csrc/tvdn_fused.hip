@@ -72,7 +72,10 @@ struct FusedParams {
     double *partials;
 };
 
-constexpr int kFusedBlock = 256;
+#ifndef TVDN_FUSED_BLOCK
+#define TVDN_FUSED_BLOCK 256
+#endif
+constexpr int kFusedBlock = TVDN_FUSED_BLOCK;  // threads per workgroup (measurement knob: 512 tried)
 
 // One accumulator update at one voxel.  v1/v2 are the values loaded from in1/in2.
 // Returns b_new (what the divergence and b_norm use); o1/o2 are what out1/out2 receive.

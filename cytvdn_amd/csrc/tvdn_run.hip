@@ -1,6 +1,10 @@
 // tvdn_run: the whole denoise loop on host arrays, for non-Python callers (include/tvdn.h).
-// Mirrors cytvdn_amd/driver.py + engine.HipBackend (compact d-rotation state) in C++.
+// Mirrors cytvdn_amd/driver.py + engine.{SlabLayout,HipBackend,LocalSlabs} in C++: compact d-rotation state, one
+// slab of axis 0 per entry of the device list, halo rows moved device-to-device (peer copies over xGMI) on a
+// copy stream per slab while the interior rows are swept.  One host thread drives every device; nothing here
+// needs Python, torch or RCCL.
 #include <cmath>
+#include <memory>
 
 #include "tvdn_common.hpp"
 
@@ -8,7 +12,14 @@ namespace tvdn {
 
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    int device = 0;
+    ~DevBuf()
+    {
+        if (p) {
+            (void)hipSetDevice(device);
+            (void)hipFree(p);
+        }
+    }
 };
 
 template <typename T>
@@ -18,87 +29,250 @@ static T delta_in_dtype(const double s[3])
     return (T)s[1] / (T)s[2];
 }
 
+// One slab: rows [g0, g1) of the cube plus a halo row on every interior side, resident on one device.
+struct Slab {
+    int device = 0;
+    int64_t g0 = 0, g1 = 0, halo_lo = 0, halo_hi = 0;  // global own rows; halo rows held
+    tvdn_ctx *ctx = nullptr;
+    hipStream_t main = nullptr, copy = nullptr;
+    hipEvent_t edge_done = nullptr, halo_done = nullptr;
+    DevBuf state;  // ONE allocation: per axis 2-3 rotating arrays, recon x2, orig
+    DevBuf ref, sums, mse;
+    char *S[4][3] = {};
+    char *recon[2] = {nullptr, nullptr};
+    char *orig = nullptr;
+    tvdn_iter_args it;
+    int64_t rows() const { return halo_lo + (g1 - g0) + halo_hi; }
+    int64_t row_lo() const { return halo_lo; }
+    int64_t row_hi() const { return halo_lo + (g1 - g0); }
+    ~Slab()
+    {
+        (void)hipSetDevice(device);
+        if (edge_done) (void)hipEventDestroy(edge_done);
+        if (halo_done) (void)hipEventDestroy(halo_done);
+        if (main) (void)hipStreamDestroy(main);
+        if (copy) (void)hipStreamDestroy(copy);
+        if (ctx) (void)tvdn_ctx_destroy(ctx);
+    }
+};
+
+static int64_t edge_block(int64_t own)
+{
+    const int64_t e = 8;  // a whole march per side: no extra look-ahead rows (engine.edge_block)
+    const int64_t cap = (own - 1) / 2;
+    return cap < 1 ? 1 : (e < cap ? e : cap);
+}
+
 static int run_impl(const tvdn_run_args *a)
 {
     const int nd = a->ndim;
     const size_t item = a->dtype == TVDN_F32 ? 4 : 8;
-    size_t n = 1;
-    for (int i = 0; i < nd; ++i) n *= (size_t)a->shape[i];
-    const size_t bytes = n * item;
+    size_t plane = 1;
+    for (int i = 1; i < nd; ++i) plane *= (size_t)a->shape[i];
+    const size_t row_bytes = plane * item;
+    const int64_t N0 = a->shape[0];
     const int n_total = a->n_fista + a->n_plain;
     const bool fista = a->n_fista > 0;
-
-    TVDN_HIP(hipSetDevice(a->device));
-    tvdn_ctx *ctx = nullptr;
-    int rc = tvdn_ctx_create(&ctx, a->device);
-    if (rc) return rc;
-    struct CtxGuard { tvdn_ctx *c; ~CtxGuard() { (void)tvdn_ctx_destroy(c); } } guard{ctx};
-
     const int per_axis = fista ? 3 : 2;
-    DevBuf orig, recon[2], S[4][3], ref, sums, mse;
-    TVDN_HIP(hipMalloc(&orig.p, bytes));
-    for (auto &r : recon) TVDN_HIP(hipMalloc(&r.p, bytes));
-    for (int q = 0; q < nd; ++q)
-        for (int k = 0; k < per_axis; ++k) {
-            TVDN_HIP(hipMalloc(&S[q][k].p, bytes));
-            TVDN_HIP(hipMemsetAsync(S[q][k].p, 0, bytes, nullptr));
-        }
-    TVDN_HIP(hipMalloc(&sums.p, sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1)));
-    TVDN_HIP(hipMemsetAsync(sums.p, 0, sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1), nullptr));
-    rc = tvdn_copy_to_device(orig.p, a->data, bytes, a->device);
-    if (rc) return rc;
-    TVDN_HIP(hipMemcpyAsync(recon[0].p, orig.p, bytes, hipMemcpyDeviceToDevice, nullptr));
     const bool want_mse = a->mse_out != nullptr && a->reference != nullptr;
-    if (want_mse) {
-        TVDN_HIP(hipMalloc(&ref.p, bytes));
-        rc = tvdn_copy_to_device(ref.p, a->reference, bytes, a->device);
-        if (rc) return rc;
-        TVDN_HIP(hipMalloc(&mse.p, sizeof(double) * (size_t)(n_total + 1)));
-        TVDN_HIP(hipMemsetAsync(mse.p, 0, sizeof(double) * (size_t)(n_total + 1), nullptr));
-        rc = tvdn_sum_square_error(ctx, a->dtype, nd, a->shape, orig.p, ref.p, (double *)mse.p, nullptr);
-        if (rc) return rc;
-    }
+    const bool periodic = a->bc_mode == TVDN_BC_PERIODIC;
 
-    tvdn_iter_args it;
-    std::memset(&it, 0, sizeof it);
-    it.dtype = a->dtype;
-    it.ndim = nd;
-    for (int i = 0; i < nd; ++i) it.shape[i] = a->shape[i];
-    it.row_lo = 0;
-    it.row_hi = a->shape[0];
-    it.lo_mode = TVDN_EDGE_BC;
-    it.hi_mode = TVDN_EDGE_BC;
-    it.bc_mode = a->bc_mode;
-    for (int q = 0; q < nd; ++q) {
-        it.clip[q] = a->clip[q];
-        it.lambda_mu[q] = a->lambda_mu[q];
+    // ---- the slabs -----------------------------------------------------------------------------------
+    int world = a->n_devices > 0 ? a->n_devices : 1;
+    TVDN_REQUIRE(world <= TVDN_MAX_DEVICES, "n_devices = %d exceeds %d", world, TVDN_MAX_DEVICES);
+    TVDN_REQUIRE(N0 >= world, "axis 0 (%lld rows) cannot be cut into %d slabs", (long long)N0, world);
+    std::unique_ptr<Slab[]> sl(new Slab[world]);
+    const bool ring = world > 1 && periodic;
+    for (int r = 0; r < world; ++r) {
+        Slab &s = sl[r];
+        s.device = a->n_devices > 0 ? a->devices[r] : a->device;
+        s.g0 = (int64_t)r * N0 / world;
+        s.g1 = (int64_t)(r + 1) * N0 / world;
+        s.halo_lo = (world > 1 && (r > 0 || ring)) ? 1 : 0;
+        s.halo_hi = (world > 1 && (r < world - 1 || ring)) ? 1 : 0;
+        TVDN_HIP(hipSetDevice(s.device));
+        int rc = tvdn_ctx_create(&s.ctx, s.device);
+        if (rc) return rc;
+        TVDN_HIP(hipStreamCreateWithFlags(&s.main, hipStreamNonBlocking));
+        TVDN_HIP(hipStreamCreateWithFlags(&s.copy, hipStreamNonBlocking));
+        TVDN_HIP(hipEventCreateWithFlags(&s.edge_done, hipEventDisableTiming));
+        TVDN_HIP(hipEventCreateWithFlags(&s.halo_done, hipEventDisableTiming));
+        // state: one allocation, 256-byte aligned arrays; everything but orig and recon[0] zeroed in one fill
+        const size_t bytes = (size_t)s.rows() * row_bytes;
+        const size_t stride = (bytes + 255) / 256 * 256;
+        const int n_arr = 3 + nd * per_axis;
+        s.state.device = s.device;
+        TVDN_HIP(hipMalloc(&s.state.p, stride * (size_t)n_arr));
+        TVDN_HIP(hipMemsetAsync(s.state.p, 0, stride * (size_t)(n_arr - 2), s.main));
+        char *base = (char *)s.state.p;
+        int k = 0;
+        for (int q = 0; q < nd; ++q)
+            for (int j = 0; j < per_axis; ++j) s.S[q][j] = base + stride * (size_t)(k++);
+        s.recon[1] = base + stride * (size_t)(k++);
+        s.orig = base + stride * (size_t)(k++);
+        s.recon[0] = base + stride * (size_t)(k++);
+        s.sums.device = s.device;
+        TVDN_HIP(hipMalloc(&s.sums.p, sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1)));
+        TVDN_HIP(hipMemsetAsync(s.sums.p, 0, sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1), s.main));
     }
-    it.orig = orig.p;
+    if (world > 1)  // let every device address its neighbours' memory (no-op when they are the same device)
+        for (int r = 0; r < world; ++r)
+            for (int d : {(r + 1) % world, (r + world - 1) % world})
+                if (sl[d].device != sl[r].device) {
+                    TVDN_HIP(hipSetDevice(sl[r].device));
+                    (void)hipDeviceEnablePeerAccess(sl[d].device, 0);  // direct xGMI copies where the link exists;
+                    (void)hipGetLastError();                            // without it the peer copy is staged, still correct
+                }
+
+    // ---- upload: own rows + halo rows, straight from the caller's array ---------------------------------------
+    auto rows_to_device = [&](Slab &s, char *dst, const void *src_cube) -> int {
+        TVDN_HIP(hipSetDevice(s.device));
+        const char *src = (const char *)src_cube;
+        // local row i holds global row (g0 - halo_lo + i) mod N0: at most three contiguous pieces
+        int64_t i = 0;
+        while (i < s.rows()) {
+            const int64_t g = ((s.g0 - s.halo_lo + i) % N0 + N0) % N0;
+            int64_t n = s.rows() - i;
+            if (g + n > N0) n = N0 - g;
+            int rc = tvdn_copy_to_device(dst + (size_t)i * row_bytes, src + (size_t)g * row_bytes, (size_t)n * row_bytes, s.device);
+            if (rc) return rc;
+            i += n;
+        }
+        return TVDN_OK;
+    };
+    for (int r = 0; r < world; ++r) {
+        Slab &s = sl[r];
+        int rc = rows_to_device(s, s.orig, a->data);
+        if (rc) return rc;
+        TVDN_HIP(hipMemcpyAsync(s.recon[0], s.orig, (size_t)s.rows() * row_bytes, hipMemcpyDeviceToDevice, s.main));
+        if (want_mse) {
+            s.ref.device = s.mse.device = s.device;
+            TVDN_HIP(hipMalloc(&s.ref.p, (size_t)s.rows() * row_bytes));
+            rc = rows_to_device(s, (char *)s.ref.p, a->reference);
+            if (rc) return rc;
+            TVDN_HIP(hipMalloc(&s.mse.p, sizeof(double) * (size_t)(n_total + 1)));
+            TVDN_HIP(hipMemsetAsync(s.mse.p, 0, sizeof(double) * (size_t)(n_total + 1), s.main));
+        }
+        tvdn_iter_args &it = s.it;
+        std::memset(&it, 0, sizeof it);
+        it.dtype = a->dtype;
+        it.ndim = nd;
+        it.shape[0] = s.rows();
+        for (int i = 1; i < nd; ++i) it.shape[i] = a->shape[i];
+        it.row_lo = s.row_lo();
+        it.row_hi = s.row_hi();
+        it.lo_mode = s.halo_lo ? TVDN_EDGE_HALO : TVDN_EDGE_BC;
+        it.hi_mode = s.halo_hi ? TVDN_EDGE_HALO : (world == 1 ? TVDN_EDGE_BC : TVDN_EDGE_ZERO);
+        it.bc_mode = a->bc_mode;
+        for (int q = 0; q < nd; ++q) {
+            it.clip[q] = a->clip[q];
+            it.lambda_mu[q] = a->lambda_mu[q];
+        }
+        it.orig = s.orig;
+    }
+    // sum of squared errors over the own rows of every slab, into mse[slot]
+    auto sse_all = [&](int cur, int slot) -> int {
+        for (int r = 0; r < world; ++r) {
+            Slab &s = sl[r];
+            TVDN_HIP(hipSetDevice(s.device));
+            int64_t shp[4];
+            shp[0] = s.g1 - s.g0;
+            for (int i = 1; i < nd; ++i) shp[i] = a->shape[i];
+            const size_t off = (size_t)s.row_lo() * row_bytes;
+            int rc = tvdn_sum_square_error(s.ctx, a->dtype, nd, shp, (char *)s.ref.p + off, s.recon[cur] + off,
+                                           (double *)s.mse.p + slot, s.main);
+            if (rc) return rc;
+        }
+        return TVDN_OK;
+    };
+    if (want_mse) {
+        int rc = sse_all(0, 0);  // MSE[0]: input against reference (cyTVDN.py:124-125)
+        if (rc) return rc;
+    }
 
     int cur = 0, i_d = 0, i_prev = 1, i_out = 2, i_b = 0, i_bout = 1;
     bool d_form = fista;
     double tk = 1.0, tk_prev_ratio = 0.0;
     int ran = 0;
 
-    auto one = [&](int slot, bool use_fista, double ratio) -> int {
-        it.recon_in = recon[cur].p;
-        it.recon_out = recon[cur ^ 1].p;
+    // one launch on slab s over rows [lo, hi) of its own rows (0, 0 = all)
+    auto sweep = [&](Slab &s, int slot, bool use_fista, double ratio, int64_t lo, int64_t hi, bool accumulate) -> int {
+        tvdn_iter_args &it = s.it;
+        it.recon_in = s.recon[cur];
+        it.recon_out = s.recon[cur ^ 1];
         it.tk = use_fista ? ratio : 0.0;
         it.tk_prev = tk_prev_ratio;
         for (int q = 0; q < nd; ++q) {
             it.b_in[q] = it.d_in[q] = it.dprev_in[q] = nullptr;
             it.b_out[q] = it.d_out[q] = nullptr;
             if (use_fista) {
-                it.d_in[q] = S[q][i_d].p; it.dprev_in[q] = S[q][i_prev].p; it.d_out[q] = S[q][i_out].p;
+                it.d_in[q] = s.S[q][i_d]; it.dprev_in[q] = s.S[q][i_prev]; it.d_out[q] = s.S[q][i_out];
             } else if (d_form) {
-                it.d_in[q] = S[q][i_d].p; it.dprev_in[q] = S[q][i_prev].p; it.b_out[q] = S[q][i_out].p;
+                it.d_in[q] = s.S[q][i_d]; it.dprev_in[q] = s.S[q][i_prev]; it.b_out[q] = s.S[q][i_out];
             } else {
-                it.b_in[q] = S[q][i_b].p; it.b_out[q] = S[q][i_bout].p;
+                it.b_in[q] = s.S[q][i_b]; it.b_out[q] = s.S[q][i_bout];
             }
         }
         it.mode = use_fista ? TVDN_ITER_FISTA_D : (d_form ? TVDN_ITER_FISTA_D_TO_PLAIN : TVDN_ITER_PLAIN);
-        int r = tvdn_iterate_fused(ctx, &it, (double *)sums.p + 3 * (size_t)slot, nullptr);
-        if (r) return r;
+        it.sweep_lo = lo;
+        it.sweep_hi = hi;
+        it.accumulate = accumulate ? 1 : 0;
+        TVDN_HIP(hipSetDevice(s.device));
+        return tvdn_iterate_fused(s.ctx, &it, (double *)s.sums.p + 3 * (size_t)slot, s.main);
+    };
+
+    auto one = [&](int slot, bool use_fista, double ratio) -> int {
+        const int nxt = cur ^ 1;
+        if (world == 1) {
+            int r = sweep(sl[0], slot, use_fista, ratio, 0, 0, false);
+            if (r) return r;
+        } else {
+            // edge blocks first, on every slab; then their outermost rows travel while the interiors are swept
+            for (int r = 0; r < world; ++r) {
+                Slab &s = sl[r];
+                TVDN_HIP(hipSetDevice(s.device));
+                TVDN_HIP(hipStreamWaitEvent(s.main, s.halo_done, 0));  // last iteration's halo rows have arrived
+                const int64_t lo = s.row_lo(), hi = s.row_hi();
+                if (hi - lo < 3) {
+                    int rc = sweep(s, slot, use_fista, ratio, 0, 0, false);
+                    if (rc) return rc;
+                } else {
+                    const int64_t e = edge_block(hi - lo);
+                    int rc = sweep(s, slot, use_fista, ratio, lo, lo + e, false);
+                    if (!rc) rc = sweep(s, slot, use_fista, ratio, hi - e, hi, true);
+                    if (rc) return rc;
+                }
+                TVDN_HIP(hipEventRecord(s.edge_done, s.main));
+            }
+            for (int r = 0; r < world; ++r) {
+                Slab &s = sl[r];
+                TVDN_HIP(hipSetDevice(s.device));
+                // pull the neighbours' fresh edge rows into my halo rows: my copy stream, after THEIR edge sweeps of
+                // this iteration and after MY OWN (so every read of those halo rows by my previous iteration is over)
+                TVDN_HIP(hipStreamWaitEvent(s.copy, s.edge_done, 0));
+                if (s.halo_lo) {
+                    Slab &l = sl[(r + world - 1) % world];
+                    TVDN_HIP(hipStreamWaitEvent(s.copy, l.edge_done, 0));
+                    TVDN_HIP(hipMemcpyPeerAsync(s.recon[nxt] + (size_t)(s.row_lo() - 1) * row_bytes, s.device,
+                                                l.recon[nxt] + (size_t)(l.row_hi() - 1) * row_bytes, l.device, row_bytes, s.copy));
+                }
+                if (s.halo_hi) {
+                    Slab &h = sl[(r + 1) % world];
+                    TVDN_HIP(hipStreamWaitEvent(s.copy, h.edge_done, 0));
+                    TVDN_HIP(hipMemcpyPeerAsync(s.recon[nxt] + (size_t)s.row_hi() * row_bytes, s.device,
+                                                h.recon[nxt] + (size_t)h.row_lo() * row_bytes, h.device, row_bytes, s.copy));
+                }
+                TVDN_HIP(hipEventRecord(s.halo_done, s.copy));
+                const int64_t lo = s.row_lo(), hi = s.row_hi();
+                if (hi - lo >= 3) {
+                    const int64_t e = edge_block(hi - lo);
+                    if (lo + e < hi - e) {
+                        int rc = sweep(s, slot, use_fista, ratio, lo + e, hi - e, true);
+                        if (rc) return rc;
+                    }
+                }
+            }
+        }
         cur ^= 1;
         if (use_fista) {
             const int t = i_prev; i_prev = i_d; i_d = i_out; i_out = t;
@@ -109,19 +283,22 @@ static int run_impl(const tvdn_run_args *a)
             const int t = i_b; i_b = i_bout; i_bout = t;
         }
         ++ran;
-        if (want_mse) {
-            r = tvdn_sum_square_error(ctx, a->dtype, nd, a->shape, ref.p, recon[cur].p, (double *)mse.p + slot + 1, nullptr);
-            if (r) return r;
-        }
+        if (want_mse) return sse_all(cur, slot + 1);
         return TVDN_OK;
     };
 
     auto stopped = [&](int slot, bool &stop) -> int {
         stop = false;
         if (!a->use_stop) return TVDN_OK;
-        double s[3];
-        TVDN_HIP(hipMemcpy(s, (double *)sums.p + 3 * (size_t)slot, sizeof s, hipMemcpyDeviceToHost));
-        const double delta = a->dtype == TVDN_F32 ? (double)delta_in_dtype<float>(s) : delta_in_dtype<double>(s);
+        double tot[3] = {0.0, 0.0, 0.0};
+        for (int r = 0; r < world; ++r) {  // the global criterion: sums over every slab
+            double s3[3];
+            TVDN_HIP(hipSetDevice(sl[r].device));
+            TVDN_HIP(hipMemcpyAsync(s3, (double *)sl[r].sums.p + 3 * (size_t)slot, sizeof s3, hipMemcpyDeviceToHost, sl[r].main));
+            TVDN_HIP(hipStreamSynchronize(sl[r].main));
+            for (int j = 0; j < 3; ++j) tot[j] += s3[j];
+        }
+        const double delta = a->dtype == TVDN_F32 ? (double)delta_in_dtype<float>(tot) : delta_in_dtype<double>(tot);
         stop = delta < a->stop;
         return TVDN_OK;
     };
@@ -131,7 +308,7 @@ static int run_impl(const tvdn_run_args *a)
         const double tk_new = (1.0 + std::sqrt(1.0 + 4.0 * (tk * tk))) / 2.0;
         const double ratio = (tk - 1.0) / tk_new;
         tk = tk_new;
-        rc = one(i, true, ratio);
+        int rc = one(i, true, ratio);
         if (rc) return rc;
         bool st;
         rc = stopped(i, st);
@@ -140,7 +317,7 @@ static int run_impl(const tvdn_run_args *a)
     }
     for (int j = 0; j < a->n_plain; ++j) {
         const int slot = j + a->n_fista;
-        rc = one(slot, false, 0.0);
+        int rc = one(slot, false, 0.0);
         if (rc) return rc;
         bool st;
         rc = stopped(slot, st);
@@ -148,13 +325,28 @@ static int run_impl(const tvdn_run_args *a)
         if (st) break;
     }
 
-    TVDN_HIP(hipDeviceSynchronize());
-    rc = tvdn_copy_to_host(a->recon_out, recon[cur].p, bytes, a->device);
-    if (rc) return rc;
-    if (n_total > 0) TVDN_HIP(hipMemcpy(a->sums_out, sums.p, sizeof(double) * 3 * (size_t)n_total, hipMemcpyDeviceToHost));
-    if (want_mse) TVDN_HIP(hipMemcpy(a->mse_out, mse.p, sizeof(double) * (size_t)(n_total + 1), hipMemcpyDeviceToHost));
+    // ---- results home ---------------------------------------------------------------------------------
+    if (n_total > 0) std::memset(a->sums_out, 0, sizeof(double) * 3 * (size_t)n_total);
+    if (want_mse) std::memset(a->mse_out, 0, sizeof(double) * (size_t)(n_total + 1));
+    std::unique_ptr<double[]> tmp(new double[3 * (size_t)(n_total > 0 ? n_total : 1) + (size_t)n_total + 1]);
+    for (int r = 0; r < world; ++r) {
+        Slab &s = sl[r];
+        TVDN_HIP(hipSetDevice(s.device));
+        TVDN_HIP(hipStreamSynchronize(s.main));
+        TVDN_HIP(hipStreamSynchronize(s.copy));
+        int rc = tvdn_copy_to_host((char *)a->recon_out + (size_t)s.g0 * row_bytes, s.recon[cur] + (size_t)s.row_lo() * row_bytes,
+                                   (size_t)(s.g1 - s.g0) * row_bytes, s.device);
+        if (rc) return rc;
+        if (n_total > 0) {
+            TVDN_HIP(hipMemcpy(tmp.get(), s.sums.p, sizeof(double) * 3 * (size_t)n_total, hipMemcpyDeviceToHost));
+            for (int i = 0; i < 3 * n_total; ++i) a->sums_out[i] += tmp[i];
+        }
+        if (want_mse) {
+            TVDN_HIP(hipMemcpy(tmp.get(), s.mse.p, sizeof(double) * (size_t)(n_total + 1), hipMemcpyDeviceToHost));
+            for (int i = 0; i <= n_total; ++i) a->mse_out[i] += tmp[i];
+        }
+    }
     if (a->iters_run) *a->iters_run = ran;
-    TVDN_HIP(hipDeviceSynchronize());
     return TVDN_OK;
 }
 
@@ -169,6 +361,17 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
     TVDN_REQUIRE(a->n_fista >= 0 && a->n_plain >= 0, "negative iteration count");
     TVDN_REQUIRE(a->data && a->recon_out, "data / recon_out is NULL");
     TVDN_REQUIRE(a->sums_out || a->n_fista + a->n_plain == 0, "sums_out is NULL");
+    TVDN_REQUIRE(a->n_devices >= 0 && a->n_devices <= TVDN_MAX_DEVICES, "n_devices must be 0..%d", TVDN_MAX_DEVICES);
+    {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n < 1) {
+            tvdn::set_error("no HIP device visible: the product path needs an MI355X (gfx950); there is no CPU fallback");
+            return TVDN_ERR_NO_DEVICE;
+        }
+        if (a->n_devices == 0) TVDN_REQUIRE(a->device >= 0 && a->device < n, "device %d out of range (0..%d)", a->device, n - 1);
+        for (int i = 0; i < a->n_devices; ++i)
+            TVDN_REQUIRE(a->devices[i] >= 0 && a->devices[i] < n, "devices[%d] = %d out of range (0..%d)", i, a->devices[i], n - 1);
+    }
     if (a->bc_mode == TVDN_BC_MIRROR) {
         tvdn::set_error("bc_mode 1 (mirror) reconstruction update reads out of bounds upstream (utils.pyx:117-120): unsupported");
         return TVDN_ERR_UNSUPPORTED;

@@ -72,6 +72,18 @@ def denoise_slabs(my_rows, global_shape, mu, iterations=10, FISTA=True, stopping
     block[lay.row_lo:lay.row_hi] = my_rows.cpu() if is_t else torch.from_numpy(np.ascontiguousarray(my_rows))
     be.set_input(block)
     run = SlabRunner(be, group)
+    # the overlapped exchange (edge rows first, transfer on a side stream) is used only on a process group on which it
+    # has reproduced a single-GPU run bit for bit in this process (selfcheck_exchange, cached per group); otherwise
+    # the blocking exchange, loudly
+    if world > 1 and backend_factory is None and run.transport == "rccl":
+        ok = exchange_verified(group, device)
+        if not ok["overlap"]:
+            import warnings
+            warnings.warn(f"overlapped halo exchange failed its self-check on this process group ({ok}); "
+                          "using the blocking exchange", RuntimeWarning)
+            run.overlap = False
+        if not ok["blocking"]:
+            raise RuntimeError(f"halo exchange over {ok['transport']} does not reproduce the single-GPU result: {ok}")
     run.exchange_halos()
     dt = dtype.type
 
@@ -143,6 +155,17 @@ def _denoise_slabs_staged(my_rows, lay, dtype, mu, lam, FISTA, unacc, n_f, n_p, 
     return sr.recon(), b_norm, delta
 
 
+_VERIFIED = {}
+
+
+def exchange_verified(group=None, device=None) -> dict:
+    """selfcheck_exchange, run once per process group and remembered."""
+    key = id(group) if group is not None else 0
+    if key not in _VERIFIED:
+        _VERIFIED[key] = selfcheck_exchange(group=group, device=device)
+    return _VERIFIED[key]
+
+
 def selfcheck_exchange(group=None, device=None, iterations: int = 6, dtype=np.float32, plane=(6, 16, 32)):
     """Pre-flight check of the multi-GPU exchange on THIS process group: a small cube (4 rows per rank) is
     denoised three ways -- one slab on this rank's own GPU (no communication), the slab runner with the halo
@@ -192,4 +215,4 @@ def selfcheck_exchange(group=None, device=None, iterations: int = 6, dtype=np.fl
     return res
 
 
-__all__ = ["denoise_slabs", "slab_rows", "selfcheck_exchange"]
+__all__ = ["denoise_slabs", "slab_rows", "selfcheck_exchange", "exchange_verified"]

@@ -6,6 +6,13 @@ expressed MI355X-first: axis 0 is cut into contiguous slabs, one per GPU, so tha
 single contiguous block that RCCL sends straight out of / into the recon buffer (no packing), and
 only recon is ever exchanged (accumulators of the halo row are recomputed locally).
 
+Non-finite data.  Under the Jia-Zhao boundary condition the axis-0 accumulator of global row 0 is identically zero
+for finite data (clip((r - r) + 0)), which is what lets the last slab close the periodic wrap of the reconstruction
+update with a constant (TVDN_EDGE_ZERO) instead of a message from rank 0.  If row 0 holds an Inf or a NaN, upstream
+(and the single-slab run here, which wraps for real) gets NaN from Inf - Inf in that accumulator and propagates it
+into the LAST row; a multi-slab, wavefront or staged run does not.  Bit parity of those three paths therefore holds
+for data whose first row stays finite; everywhere else NaN/Inf propagate exactly as upstream on every path.
+
 Pieces
 ------
 SlabLayout   pure bookkeeping: which global rows a rank owns, which halo rows it keeps, how its two

@@ -39,38 +39,74 @@ def plan_blocks(n_rows: int, block_rows: int):
     return [(g, min(g + block_rows, n_rows)) for g in range(0, n_rows, block_rows)]
 
 
-def exchange_halo_rows(dist, group, rank, world, device, arrays, lo, hi, ext_lo, ext_hi, depth):
-    """Slab mode: for every host array (own rows [lo, hi), halo rows around them) send my lowest / highest
-    `depth` own rows to the left / right neighbour's halo rows and receive theirs into mine.
-    gloo moves host memory directly; RCCL stages the rows through HBM."""
-    left = rank - 1 if rank > 0 else None
-    right = rank + 1 if rank < world - 1 else None
-    dl, dh = min(depth, ext_lo), min(depth, ext_hi)
-    via_dev = dist.get_backend(group) != "gloo"
-    peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
-    cuda = torch.device("cuda", device)
-    ops, post = [], []
-    for i, t in enumerate(arrays):
-        def snd(view):
-            return view.to(cuda, non_blocking=False) if via_dev else view.contiguous()
+class HaloSwap:
+    """Slab mode: for every host array (own rows [lo, hi), halo rows around them) my highest `depth` own rows go to the
+    right neighbour's low halo rows and my lowest `depth` own rows to the left neighbour's high halo rows.
 
-        def rcv(view):
-            buf = torch.empty(view.shape, dtype=view.dtype, device=cuda) if via_dev else view
-            if via_dev:
-                post.append((view, buf))
-            return buf
-        if left is not None:
-            ops.append(dist.P2POp(dist.isend, snd(t[lo:lo + depth]), peer(left), group, tag=4 * i + 1))
-        if right is not None:
-            ops.append(dist.P2POp(dist.isend, snd(t[hi - depth:hi]), peer(right), group, tag=4 * i + 2))
-            ops.append(dist.P2POp(dist.irecv, rcv(t[hi:hi + dh]), peer(right), group, tag=4 * i + 1))
-        if left is not None:
-            ops.append(dist.P2POp(dist.irecv, rcv(t[lo - dl:lo]), peer(left), group, tag=4 * i + 2))
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
+    Two uniform shifts, so every rank takes part in each at the same time (no chain of dependent messages):
+      phase 1  everybody sends UP and receives its LOW halo rows   -- a pass needs them at once: `start` waits;
+      phase 2  everybody sends DOWN and receives its HIGH halo rows -- a pass that streams upward needs them only for
+               its last chunks: `start` posts the messages, `finish` waits, and the transfer hides under the pass.
+    gloo moves host memory directly; RCCL stages the rows through HBM."""
+
+    def __init__(self, dist, group, rank, world, device):
+        self.dist, self.group, self.rank, self.world, self.device = dist, group, rank, world, device
+        self.left = rank - 1 if rank > 0 else None
+        self.right = rank + 1 if rank < world - 1 else None
+        self.via_dev = dist.get_backend(group) != "gloo"
+        self.peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+        self.cuda = torch.device("cuda", device)
+        self._pending = None
+
+    def _snd(self, view):
+        return view.to(self.cuda, non_blocking=False) if self.via_dev else view.contiguous()
+
+    def _rcv(self, view, post):
+        if not self.via_dev:
+            return view
+        buf = torch.empty(view.shape, dtype=view.dtype, device=self.cuda)
+        post.append((view, buf))
+        return buf
+
+    def start(self, arrays, lo, hi, ext_lo, ext_hi, depth, overlap=True):
+        self.finish()
+        dist, dl, dh = self.dist, min(depth, ext_lo), min(depth, ext_hi)
+        up, post_up, down, post_down = [], [], [], []
+        for i, t in enumerate(arrays):
+            if self.right is not None:
+                up.append(dist.P2POp(dist.isend, self._snd(t[hi - depth:hi]), self.peer(self.right), self.group, tag=4 * i + 2))
+            if self.left is not None:
+                up.append(dist.P2POp(dist.irecv, self._rcv(t[lo - dl:lo], post_up), self.peer(self.left), self.group, tag=4 * i + 2))
+        for i, t in enumerate(arrays):
+            if self.left is not None:
+                down.append(dist.P2POp(dist.isend, self._snd(t[lo:lo + depth]), self.peer(self.left), self.group, tag=4 * i + 1))
+            if self.right is not None:
+                down.append(dist.P2POp(dist.irecv, self._rcv(t[hi:hi + dh], post_down), self.peer(self.right), self.group, tag=4 * i + 1))
+        if up:
+            for w in dist.batch_isend_irecv(up):
+                w.wait()
+        for view, buf in post_up:
+            view.copy_(buf)
+        if down:
+            self._pending = (dist.batch_isend_irecv(down), post_down)
+        if not overlap:
+            self.finish()
+
+    def finish(self):
+        """Join phase 2 (no-op when nothing is pending)."""
+        if self._pending is None:
+            return
+        works, post = self._pending
+        self._pending = None
+        for w in works:
             w.wait()
-    for view, buf in post:
-        view.copy_(buf)
+        for view, buf in post:
+            view.copy_(buf)
+
+
+def exchange_halo_rows(dist, group, rank, world, device, arrays, lo, hi, ext_lo, ext_hi, depth):
+    """Blocking form of HaloSwap: both shifts completed on return."""
+    HaloSwap(dist, group, rank, world, device).start(arrays, lo, hi, ext_lo, ext_hi, depth, overlap=False)
 
 
 class StagedRunner:

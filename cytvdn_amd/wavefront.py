@@ -150,11 +150,13 @@ class WavefrontRunner:
         self.tk_prev = 0.0
         self.iters_done = 0
         self.sums_dev = torch.zeros((self.max_iters + 1, 3), dtype=torch.float64, device=dev)   # last row: discard slot
+        self._swap = None
         if self.world > 1:
-            from .outofcore import exchange_halo_rows
-            self._exchange = lambda arrays, depth: exchange_halo_rows(
-                self.dist, self.group, self.rank, self.world, self.device, arrays, self.ext_lo,
-                self.ext_lo + own_shape[0], self.ext_lo, self.ext_hi, depth)
+            from .outofcore import HaloSwap
+            # the neighbours' rows of the state: the low halo rows at once, the high ones while the pass streams upward
+            self._swap = HaloSwap(self.dist, self.group, self.rank, self.world, self.device)
+            self._exchange = lambda arrays, depth, overlap=False: self._swap.start(
+                arrays, self.ext_lo, self.ext_lo + own_shape[0], self.ext_lo, self.ext_hi, depth, overlap=overlap)
             self._exchange([self.orig_h], self.k)
         elif self.periodic:
             self._exchange = self._wrap_rows
@@ -244,7 +246,10 @@ class WavefrontRunner:
         art_hi = (E1 < N0) or self.periodic
         if halo:
             arrays = [self.recon_h[old]] + [t for q in range(nd) for t in self.state_h[old][q][: (2 if self.d_form else 1)]]
-            self._exchange(arrays, kk)
+            if self._swap is not None:
+                self._exchange(arrays, kk, overlap=True)     # high halo rows arrive while the pass works its way up
+            else:
+                self._exchange(arrays, kk)
         discard = self.max_iters
         # form and mode of every level of this pass
         forms = [self.d_form]
@@ -280,6 +285,8 @@ class WavefrontRunner:
             u0, u1 = E0 + c * R, min(E0 + (c + 1) * R, E1)
             if u0 >= u1:
                 return
+            if self._swap is not None and u1 > g1:
+                self._swap.finish()                          # this chunk reads the neighbour's rows above my slab
             box = self.inbox[c % 2]
             with torch.cuda.stream(self.up):
                 if in_free[c % 2] is not None:
@@ -387,6 +394,8 @@ class WavefrontRunner:
                     out_free[c % 2] = ev2
         self.down.synchronize()
         main.synchronize()
+        if self._swap is not None:
+            self._swap.finish()
         self.h_old = new
         self.d_form = forms[kk]
         self.tk_prev = prev_ratio

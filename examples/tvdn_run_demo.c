@@ -3,6 +3,7 @@
  *
  *   gcc -O2 -Iinclude examples/tvdn_run_demo.c -Lcytvdn_amd -ltvdn_hip -Wl,-rpath,$PWD/cytvdn_amd -lm -o tvdn_run_demo
  *   ./tvdn_run_demo 12 10 16 32 8        # shape (4-D) and FISTA iterations
+ *   ./tvdn_run_demo 12 10 16 32 8 2      # ... cut into 2 slabs: devices 0 and 1 (or both on device 0 if there is one GPU)
  *
  * Fills a cube with a deterministic pattern, runs denoise4D's loop through tvdn_run and prints the
  * traces and an FNV-1a checksum of recon (tests/test_gpu_parity.py compares it with the Python path).
@@ -20,6 +21,7 @@ int main(int argc, char **argv)
     int iters = 8;
     for (int i = 0; i < 4 && i + 1 < argc; ++i) shape[i] = atoll(argv[i + 1]);
     if (argc > 5) iters = atoi(argv[5]);
+    const int slabs = argc > 6 ? atoi(argv[6]) : 0;
     size_t n = (size_t)(shape[0] * shape[1] * shape[2] * shape[3]);
     float *x = malloc(n * sizeof(float)), *recon = malloc(n * sizeof(float));
     double *sums = calloc((size_t)iters * 3, sizeof(double));
@@ -33,6 +35,11 @@ int main(int argc, char **argv)
     tvdn_run_args a = {0};
     a.dtype = TVDN_F32; a.ndim = 4; a.bc_mode = TVDN_BC_JIA_ZHAO; a.device = 0;
     a.n_fista = iters; a.n_plain = 0; a.use_stop = 0;
+    if (slabs > 0) {                                     /* one slab of axis 0 per device-list entry */
+        const int ngpu = tvdn_device_count();
+        a.n_devices = slabs > TVDN_MAX_DEVICES ? TVDN_MAX_DEVICES : slabs;
+        for (int i = 0; i < a.n_devices; ++i) a.devices[i] = ngpu > 0 ? i % ngpu : 0;
+    }
     for (int q = 0; q < 4; ++q) {
         a.shape[q] = shape[q];
         const float lam = mu[q] * 1.0f / 32.0f;          /* cyTVDN.py:67-68, in the data dtype */

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TVDN_ABI_VERSION 1
+#define TVDN_ABI_VERSION 2
 
 typedef enum tvdn_dtype { TVDN_F32 = 0, TVDN_F64 = 1 } tvdn_dtype;
 
@@ -169,27 +169,37 @@ int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *args, double *sums_o
 /* ------------------------------------------------------------------------------------------
  * Whole-loop entry point on HOST arrays: what denoise4D / denoise3D do between their argument
  * checks and their return (cyTVDN/cyTVDN.py:122-247, :345-435), for callers that are not Python.
- * Copies `data` to HBM once, runs n_fista FISTA iterations then n_plain unaccelerated ones
- * (float64 tk recurrence of cyTVDN.py:153-156; compact d-rotation state), copies recon back once.
+ * Copies `data` to HBM once (pinned multi-lane staging, tvdn_copy_to_device), runs n_fista FISTA
+ * iterations then n_plain unaccelerated ones (float64 tk recurrence of cyTVDN.py:153-156; compact
+ * d-rotation state), copies recon back once.
+ *   n_devices 0: everything on `device`.  n >= 1: axis 0 is cut into n slabs of (almost) equal height, slab i
+ *             resident on devices[i] (entries may repeat: several slabs on one GPU); each iteration sweeps the
+ *             edge rows of every slab first, then moves one recon row per neighbour device-to-device (peer
+ *             copies over xGMI, on a copy stream per slab) while the interior rows are swept -- the
+ *             single-process form of the slab decomposition that replaces cyTVDN/mpi.py:314-434 (the
+ *             multi-process form over RCCL is cytvdn_amd.distributed.denoise_slabs).  The slab state must fit
+ *             in each device's HBM: cubes beyond that are the Python engines' business (cytvdn_amd.plan_run).
  *   sums_out  host, (n_fista+n_plain) x 3 doubles: sum|b_new|, sum|recon_new-recon_old|, sum|recon_old|
- *             per iteration (the reference's b_norm[i] and delta_recon[i] = [1]/[2]); rows of
- *             iterations that did not run stay zero
+ *             per iteration over the WHOLE cube (the reference's b_norm[i] and delta_recon[i] = [1]/[2]);
+ *             rows of iterations that did not run stay zero
  *   mse_out   host, n_fista+n_plain+1 doubles, or NULL; needs `reference` (sum of squared errors)
- *   use_stop  when non-zero a phase ends as soon as delta_recon (formed in the data dtype, as upstream)
- *             drops below `stop`; a FISTA-phase stop still falls through to the unaccelerated phase
- *             (cyTVDN.py:189-195)
+ *   use_stop  when non-zero a phase ends as soon as delta_recon (formed in the data dtype, as upstream, from
+ *             the sums over all slabs) drops below `stop`; a FISTA-phase stop still falls through to the
+ *             unaccelerated phase (cyTVDN.py:189-195)
  *   iters_run host, optional: number of iterations executed
  * ---------------------------------------------------------------------------------------- */
+#define TVDN_MAX_DEVICES 16
+
 typedef struct tvdn_run_args {
     int32_t dtype;
     int32_t ndim;
     int64_t shape[4];
     int32_t bc_mode;       /* 0 or 2 */
-    int32_t device;
+    int32_t device;        /* used when n_devices == 0 */
     int32_t n_fista;
     int32_t n_plain;
     int32_t use_stop;
-    int32_t reserved;
+    int32_t n_devices;     /* 0, or the number of slabs = entries of `devices` */
     double stop;
     double clip[4];        /* 1/lambda per axis, already rounded to the data dtype by the caller */
     double lambda_mu[4];   /* lambda/mu per axis, idem */
@@ -199,6 +209,7 @@ typedef struct tvdn_run_args {
     double *sums_out;
     double *mse_out;
     int32_t *iters_run;
+    int32_t devices[TVDN_MAX_DEVICES];
 } tvdn_run_args;
 
 int tvdn_run(const tvdn_run_args *args);

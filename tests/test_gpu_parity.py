@@ -231,6 +231,65 @@ def test_tvdn_run_host_entry(tv, shape, dtype, its, fista, stop, with_ref):
         assert bits_equal(mse.astype(dt), want[3])
 
 
+@pytest.mark.parametrize("shape,dtype,its,fista,stop,with_ref,bc,devices", [
+    ((23, 5, 8, 12), np.float32, 7, True, None, False, 2, [0, 0]),          # two slabs on one GPU: peer copies degenerate to D2D
+    ((23, 5, 8, 12), np.float32, [4, 3], True, None, True, 2, [0, 0, 0]),   # hybrid + reference_data over three slabs
+    ((20, 6, 16), np.float64, 6, True, None, False, 0, [0, 0]),             # periodic ring of two slabs
+    ((31, 3, 7, 9), np.float32, 40, False, 0.02, False, 2, [0, 0, 0, 0]),   # global stopping rule over four slabs (scalar packs)
+    ((7, 4, 8, 8), np.float32, 5, True, None, False, 2, [0] * 7),           # one row per slab
+    ((64, 6, 8, 16), np.float32, 6, True, None, False, 2, [0, 0]),          # 32-row slabs: 8-row edge blocks + interior
+])
+def test_tvdn_run_device_list(tv, shape, dtype, its, fista, stop, with_ref, bc, devices):
+    """tvdn_run with a device list: one slab of axis 0 per entry, edge blocks first, halo rows moved by peer copies on
+    a copy stream under the interior sweep -- bit-identical to the single-device run (and so to the reference),
+    including the global sums, the stopping iteration and the MSE trace."""
+    import ctypes as C
+    from cytvdn_amd import _lib, synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=37, dtype=dt) + dt.type(0.25)
+    refd = synth.cube(shape, seed=37, dtype=dt, kind="mean") if with_ref else None
+    mu = np.array([1.0, 1.0, 0.5, 0.5][:nd], dt)
+    lam = mu / dt.type(32.0 if nd == 4 else 16.0)
+    fn = tv.denoise4D if nd == 4 else tv.denoise3D
+    want = fn(x, mu, its, FISTA=fista, stopping_relative_change=stop, reference_data=refd, BC_mode=bc, quiet=True)
+    n_f, n_p = (its if isinstance(its, list) else ((its, 0) if fista else (0, its)))
+    n = n_f + n_p
+    a = _lib.RunArgs(dtype=_lib.dtype_code(dt), ndim=nd, bc_mode=bc, device=0, n_fista=n_f, n_plain=n_p,
+                     use_stop=int(stop is not None), stop=float(stop or 0.0), n_devices=len(devices))
+    for i, d in enumerate(devices):
+        a.devices[i] = d
+    for i, s in enumerate(shape):
+        a.shape[i] = s
+    for q in range(nd):
+        a.clip[q] = float((1.0 / lam)[q])
+        a.lambda_mu[q] = float((lam / mu).astype(dt)[q])
+    recon = np.empty_like(x)
+    sums = np.zeros((n, 3))
+    mse = np.zeros(n + 1)
+    ran = C.c_int32(0)
+    a.data, a.recon_out, a.sums_out = x.ctypes.data, recon.ctypes.data, sums.ctypes.data
+    if with_ref:
+        a.reference, a.mse_out = refd.ctypes.data, mse.ctypes.data
+    a.iters_run = C.addressof(ran)
+    _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+    assert bits_equal(recon, want[0])
+    assert ran.value == int(np.count_nonzero(want[2]))
+    tol = 1e-6 if dt == np.float32 else 1e-12            # sums are added slab by slab: same value, other rounding
+    np.testing.assert_allclose(np.where(sums[:, 2] != 0, sums[:, 0], 0).astype(dt), want[1], rtol=tol)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dl = np.where(sums[:, 2] != 0, sums[:, 1].astype(dt) / sums[:, 2].astype(dt), 0).astype(dt)
+    np.testing.assert_allclose(dl, want[2], rtol=tol)
+    assert np.array_equal(dl == 0, want[2] == 0)
+    if with_ref:
+        np.testing.assert_allclose(mse.astype(dt), want[3], rtol=tol)
+    # argument errors of the device list
+    a.n_devices = 40
+    assert _lib.lib().tvdn_run(C.byref(a)) == -1
+    a.n_devices, a.devices[0] = 1, 99
+    assert _lib.lib().tvdn_run(C.byref(a)) == -1 and b"devices[0]" in _lib.lib().tvdn_last_error()
+
+
 def test_subnormals_signed_zeros_and_infinities(tv, oracle):
     """f32 subnormals are kept (no flush-to-zero), -0.0 survives, +-inf/NaN propagate as on the CPU:
     the arithmetic contract of SURVEY Appendix A, on the one-pass kernels and on the fused sweep."""
