@@ -23,6 +23,7 @@
 namespace tvdn {
 
 constexpr int kBlock = 256;
+constexpr int kReconTA = 2;  // A-rows per thread of the reconstruction update (see recon_update_kernel)
 
 // How the (M, A, B, C) block is cut into workgroups: `tiles` workgroups per cross-section, each marching
 // `chunk` rows.
@@ -39,7 +40,9 @@ static March make_march(const Geom &g, int vec)
     h.M = g.n[0]; h.A = g.n[1]; h.B = g.n[2]; h.C = g.n[3];
     h.units = h.A * h.B * (h.C / vec);
     h.tiles = (h.units + kBlock - 1) / kBlock;
-    long long chunk = 8;
+    // rows per march: 16 measured best for the accumulator updates on MI355X (interleaved A/B at 256x256x128x128 f32,
+    // FISTA form: 8 rows 4.09-4.50 ms, 16 rows 3.56-4.10 ms, 32 rows 3.52-4.10 ms; the other passes do not care)
+    long long chunk = 16;
     const char *e = getenv("TVDN_PASS_CHUNK");  // measurement / test knob: rows per march, taken as given
     if (e && atoll(e) > 0)
         chunk = atoll(e);
@@ -192,12 +195,16 @@ struct ReconParams {
 
 // datacube_update_{3D,4D}: periodic-wrap branch (BC 0 and 2), association of the sum from the generated C,
 // utils.c:5641: ((t0 + t1) + t2) + t3.
-template <typename T, int VEC, int NAX>
+// TA consecutive A-rows per thread (4-D only): the A-neighbour of all but the last of them is a register the thread
+// already holds, so of the re-reads that cross workgroups (the next A-row sits 64 KiB - 256 KiB away, beyond what
+// the XCD's L2 keeps) only one in TA is left.
+template <typename T, int VEC, int NAX, int TA>
 __global__ void __launch_bounds__(kBlock) recon_update_kernel(ReconParams<T> p)
 {
     using P = Pack<T, VEC>;
     constexpr int iM = 0, iA = 1, iB = NAX - 2, iC = NAX - 1;
     constexpr bool HAS_A = (NAX == 4);
+    static_assert(HAS_A || TA == 1, "A-tiling needs the A axis");
     double acc[2] = {0.0, 0.0};
     const long long L = xcd_remap(blockIdx.x, gridDim.x);
     const long long chunk_id = L / p.tiles, tile = L % p.tiles;
@@ -206,60 +213,85 @@ __global__ void __launch_bounds__(kBlock) recon_update_kernel(ReconParams<T> p)
     const long long m1 = (m0 + p.chunk < p.M) ? m0 + p.chunk : p.M;
     if (u < p.units && m0 < m1) {
         const long long LR = p.C / VEC;
-        const long long cv = u % LR, bb = (u / LR) % p.B, aa = u / (LR * p.B);
+        const long long cv = u % LR, bb = (u / LR) % p.B, a0 = (u / (LR * p.B)) * TA;
         const long long c0 = cv * VEC;
         const long long SM = p.A * p.B * p.C, SA = p.B * p.C, SB = p.C;
-        const long long xs = aa * SA + bb * SB + c0;
+        const long long xs = a0 * SA + bb * SB + c0;
         // "next" along each in-plane axis with the periodic wrap of utils.pyx:98-101
-        const long long offA = HAS_A ? ((aa + 1 == p.A) ? -(p.A - 1) * SA : SA) : 0;
+        const long long offA = HAS_A ? ((a0 + TA == p.A) ? -(p.A - 1) * SA : SA) : 0;  // from the thread's LAST A-row
         const long long offB = (bb + 1 == p.B) ? -(p.B - 1) * SB : SB;
         const long long offC = (c0 + VEC == p.C) ? -(p.C - VEC) : VEC;  // element that follows the pack
         const T lmM = p.lm[iM], lmB = p.lm[iB], lmC = p.lm[iC];
         const T *bM = p.b[iM], *bB = p.b[iB], *bC = p.b[iC];
 
-        P bM_cur = ldv<T, VEC>(bM + m0 * SM + xs);
+        P bM_cur[TA];
+#pragma unroll
+        for (int t = 0; t < TA; ++t) bM_cur[t] = ldv<T, VEC>(bM + m0 * SM + xs + t * SA);
         for (long long m = m0; m < m1; ++m) {
-            const long long x = m * SM + xs;
-            const long long xn = ((m + 1 < p.M) ? m + 1 : 0) * SM + xs;
-            const P bM_next = ldv<T, VEC>(bM + xn);
-            P s;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) s.v[j] = lmM * (bM_cur.v[j] - bM_next.v[j]);
+            const long long x0 = m * SM + xs;
+            const long long xn0 = ((m + 1 < p.M) ? m + 1 : 0) * SM + xs;
+            P bA[TA + 1];
             if (HAS_A) {
-                const P o = ldv<T, VEC>(p.b[iA] + x), n = ldv<T, VEC>(p.b[iA] + x + offA);
-                const T lmA = p.lm[iA];
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) s.v[j] = s.v[j] + lmA * (o.v[j] - n.v[j]);
+                for (int t = 0; t < TA; ++t) bA[t] = ldv<T, VEC>(p.b[iA] + x0 + t * SA);
+                bA[TA] = ldv<T, VEC>(p.b[iA] + x0 + (TA - 1) * SA + offA);
             }
-            {
-                const P o = ldv<T, VEC>(bB + x), n = ldv<T, VEC>(bB + x + offB);
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) s.v[j] = s.v[j] + lmB * (o.v[j] - n.v[j]);
-            }
-            {
-                const P o = ldv<T, VEC>(bC + x);
-                const T after = bC[x + offC];
+            for (int t = 0; t < TA; ++t) {
+                const long long x = x0 + t * SA;
+                const P bM_next = ldv<T, VEC>(bM + xn0 + t * SA);
+                P s;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) s.v[j] = lmM * (bM_cur[t].v[j] - bM_next.v[j]);
+                if (HAS_A) {
+                    const T lmA = p.lm[iA];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) s.v[j] = s.v[j] + lmA * (bA[t].v[j] - bA[t + 1].v[j]);
+                }
+                {
+                    const P o = ldv<T, VEC>(bB + x), n = ldv<T, VEC>(bB + x + offB);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) s.v[j] = s.v[j] + lmB * (o.v[j] - n.v[j]);
+                }
+                {
+                    const P o = ldv<T, VEC>(bC + x);
+                    const T after = bC[x + offC];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const T nx = (j + 1 < VEC) ? o.v[j + 1 < VEC ? j + 1 : 0] : after;
+                        s.v[j] = s.v[j] + lmC * (o.v[j] - nx);
+                    }
+                }
+                const P og = ldv_nt<T, VEC>(p.orig + x);
+                const P old = ldv_nt<T, VEC>(p.recon + x);
+                P nw;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    const T nx = (j + 1 < VEC) ? o.v[j + 1 < VEC ? j + 1 : 0] : after;
-                    s.v[j] = s.v[j] + lmC * (o.v[j] - nx);
+                    nw.v[j] = og.v[j] - s.v[j];
+                    const T df = nw.v[j] - old.v[j];
+                    acc[0] += fabs((double)df);
+                    acc[1] += fabs((double)old.v[j]);
                 }
+                stv<T, VEC>(p.recon + x, nw);
+                bM_cur[t] = bM_next;
             }
-            const P og = ldv_nt<T, VEC>(p.orig + x);
-            const P old = ldv_nt<T, VEC>(p.recon + x);
-            P nw;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                nw.v[j] = og.v[j] - s.v[j];
-                const T df = nw.v[j] - old.v[j];
-                acc[0] += fabs((double)df);
-                acc[1] += fabs((double)old.v[j]);
-            }
-            stv<T, VEC>(p.recon + x, nw);
-            bM_cur = bM_next;
         }
     }
     block_store_partials<2, kBlock>(acc, p.partials);
+}
+
+template <typename T, int VEC>
+static void launch_recon(const ReconParams<T> &p, int nax, int ta, long long grid, hipStream_t s)
+{
+    const dim3 g((unsigned)grid), blk(kBlock);
+    if (nax == 3)
+        hipLaunchKernelGGL((recon_update_kernel<T, VEC, 3, 1>), g, blk, 0, s, p);
+    else if (ta == 4)
+        hipLaunchKernelGGL((recon_update_kernel<T, VEC, 4, 4>), g, blk, 0, s, p);
+    else if (ta == 2)
+        hipLaunchKernelGGL((recon_update_kernel<T, VEC, 4, 2>), g, blk, 0, s, p);
+    else
+        hipLaunchKernelGGL((recon_update_kernel<T, VEC, 4, 1>), g, blk, 0, s, p);
 }
 
 template <typename T>
@@ -270,7 +302,18 @@ static int recon_update_impl(tvdn_ctx *ctx, const Geom &g, const void *orig, voi
     bool al = aligned16(orig) && aligned16(recon);
     for (int q = 0; q < g.nax; ++q) al = al && aligned16(b[q]);
     const int vec = (al && g.n[3] % VMAX == 0) ? VMAX : 1;
-    const March h = make_march(g, vec);
+    // A-rows per thread: 2 when the extent allows it and there is enough work to fill the chip
+    int ta = 1;
+    if (g.nax == 4 && vec == VMAX) {
+        const char *e = getenv("TVDN_RECON_TA");  // measurement / test knob: taken as given where A allows it
+        int want = e ? atoi(e) : kReconTA;
+        if (want != 4 && want != 2) want = 1;
+        while (want > 1 && (g.n[1] % want != 0 || (!e && g.total / VMAX / want < 256LL * 256 * 8))) want /= 2;
+        ta = want;
+    }
+    Geom gt = g;  // the march sees A/ta "rows" of ta A-rows each
+    gt.n[1] = g.n[1] / ta;
+    March h = make_march(gt, vec);
     TVDN_REQUIRE(h.grid >= 1 && h.grid <= kMaxPartialBlocks, "grid %lld out of range", h.grid);
     int rc = ensure_partials(ctx, h.grid);
     if (rc) return rc;
@@ -281,17 +324,13 @@ static int recon_update_impl(tvdn_ctx *ctx, const Geom &g, const void *orig, voi
         p.b[q] = q < g.nax ? (const T *)b[q] : nullptr;
         p.lm[q] = q < g.nax ? (T)lm[q] : (T)0;
     }
-    p.M = h.M; p.A = h.A; p.B = h.B; p.C = h.C;
+    p.M = g.n[0]; p.A = g.n[1]; p.B = g.n[2]; p.C = g.n[3];
     p.tiles = h.tiles; p.units = h.units; p.chunk = h.chunk;
     p.partials = ctx->partials;
-    const dim3 grid((unsigned)h.grid), blk(kBlock);
-    if (vec == VMAX) {
-        if (g.nax == 4) hipLaunchKernelGGL((recon_update_kernel<T, VMAX, 4>), grid, blk, 0, s, p);
-        else hipLaunchKernelGGL((recon_update_kernel<T, VMAX, 3>), grid, blk, 0, s, p);
-    } else {
-        if (g.nax == 4) hipLaunchKernelGGL((recon_update_kernel<T, 1, 4>), grid, blk, 0, s, p);
-        else hipLaunchKernelGGL((recon_update_kernel<T, 1, 3>), grid, blk, 0, s, p);
-    }
+    if (vec == VMAX)
+        launch_recon<T, VMAX>(p, g.nax, ta, h.grid, s);
+    else
+        launch_recon<T, 1>(p, g.nax, 1, h.grid, s);
     TVDN_HIP(hipGetLastError());
     return launch_finalize(ctx, (int)h.grid, 2, sums_out, s);
 }

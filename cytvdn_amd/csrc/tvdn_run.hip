@@ -99,7 +99,7 @@ static int run_impl(const tvdn_run_args *a)
         TVDN_HIP(hipEventCreateWithFlags(&s.halo_done, hipEventDisableTiming));
         // state: one allocation, 256-byte aligned arrays; everything but orig and recon[0] zeroed in one fill
         const size_t bytes = (size_t)s.rows() * row_bytes;
-        const size_t stride = (bytes + 255) / 256 * 256;
+        const size_t stride = (bytes + 255) / 256 * 256 + 4096;  // staggered by 4 KiB, as engine.ARRAY_SKEW
         const int n_arr = 3 + nd * per_axis;
         s.state.device = s.device;
         TVDN_HIP(hipMalloc(&s.state.p, stride * (size_t)n_arr));

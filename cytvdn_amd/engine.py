@@ -37,6 +37,7 @@ from . import _lib
 
 # accumulator state representation used by HipBackend unless told otherwise (see its docstring)
 DEFAULT_STATE = os.environ.get("TVDN_STATE", "compact")
+ARRAY_SKEW = 4096   # bytes by which consecutive state arrays are staggered inside the state allocation
 
 
 def fista_ratios(n: int) -> np.ndarray:
@@ -176,10 +177,13 @@ class HipBackend:
         ls = layout.local_shape
         # ONE allocation for the whole state, carved into arrays: one hipMalloc instead of 11-19, and one fill for
         # every array except the two that `set_input` overwrites anyway (orig and the current recon).  Arrays start
-        # 256-byte aligned; TVDN_ARRAY_SKEW (bytes, a multiple of 256) staggers them further (measurement knob).
+        # 256-byte aligned and staggered by ARRAY_SKEW bytes each: with every array at the same offset modulo a large
+        # power of two the 15 streams of a sweep compete for the same cache sets / DRAM banks at the same moment
+        # (interleaved A/B on config 2, four rounds: 11.42/12.25/12.80/12.79 ms unstaggered against
+        # 11.26/11.30/12.08/11.53 ms with 4 KiB; 2 KiB in between).  TVDN_ARRAY_SKEW overrides (multiple of 256).
         n_el = int(np.prod(ls))
         item = self.dtype.itemsize
-        skew = int(os.environ.get("TVDN_ARRAY_SKEW", "0"))
+        skew = int(os.environ.get("TVDN_ARRAY_SKEW", str(ARRAY_SKEW)))
         stride_el = (-(-(n_el * item) // 256) * 256 + skew) // item
         per_axis = (3 if fista else 2) if state == "compact" else (4 if fista else 2)
         n_arr = 3 + self.nd * per_axis

@@ -76,6 +76,24 @@ def test_one_pass_kernels_on_device_tensors(tv, oracle, shape, dtype):
     assert got == pytest.approx(oracle.sse(orig, r2)[1], rel=1e-6 if dt == np.float32 else 1e-9)
 
 
+@pytest.mark.parametrize("ta", ["1", "2", "4"])
+def test_recon_update_a_rows_per_thread(tv, oracle, monkeypatch, ta):
+    """datacube_update_4D with 1, 2 and 4 A-rows per thread (the A-neighbour of all but the last is a register):
+    extents of A that are and are not multiples of the tile, both wrap-sharing boundary conditions."""
+    monkeypatch.setenv("TVDN_RECON_TA", ta)
+    rng = np.random.default_rng(int(ta))
+    for shape, dt in (((5, 8, 3, 16), np.dtype(np.float32)), ((4, 12, 5, 8), np.dtype(np.float64)),
+                      ((3, 6, 4, 32), np.dtype(np.float32)), ((6, 2, 3, 8), np.dtype(np.float32)), ((3, 7, 2, 8), np.dtype(np.float32))):
+        orig, recon = _rand(rng, shape, dt, 3.0), _rand(rng, shape, dt, 3.0)
+        bs = [_rand(rng, shape, dt, 0.7) for _ in range(4)]
+        lm = np.array([1 / 32, 1 / 40, 1 / 64, 1 / 33]).astype(dt)
+        for bc in (0, 2):
+            r1, r2 = recon.copy(), recon.copy()
+            tv.datacube_update_4D(orig, r1, *bs, lm, BC_mode=bc)
+            oracle.recon_update(orig, r2, bs, lm, bc)
+            assert bits_equal(r1, r2), (shape, bc)
+
+
 @pytest.mark.parametrize("chunk", ["3", "8"])
 def test_one_pass_march_seams(tv, oracle, monkeypatch, chunk):
     """Marches of a forced length (odd, so the last one is short; 8, the production length) on a small array: the
