@@ -24,6 +24,15 @@ namespace tvdn {
 
 constexpr int kBlock = 256;
 constexpr int kReconTA = 2;  // A-rows per thread of the reconstruction update (see recon_update_kernel)
+#ifndef TVDN_PASS_M_NT
+#define TVDN_PASS_M_NT 1
+#endif
+// Arrays whose rows a marching thread loads exactly once (the axis-0 operand carried in registers) are streamed too.
+template <typename T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> ldv_m(const T *p)
+{
+    return TVDN_PASS_M_NT ? ldv_nt<T, VEC>(p) : ldv<T, VEC>(p);
+}
 
 // How the (M, A, B, C) block is cut into workgroups: `tiles` workgroups per cross-section, each marching
 // `chunk` rows.
@@ -106,7 +115,7 @@ __global__ void __launch_bounds__(kBlock) acc_update_kernel(AccParams<T> p)
         }
         for (long long m = m0; m < m1; ++m) {
             const long long x = m * SM + xs;
-            const P a_cur = ldv<T, VEC>(p.a + x);
+            const P a_cur = (AXK == 0) ? ldv_m<T, VEC>(p.a + x) : ldv<T, VEC>(p.a + x);
             P pv;
             if (AXK == 0) {
                 pv = a_prev;
@@ -239,7 +248,7 @@ __global__ void __launch_bounds__(kBlock) recon_update_kernel(ReconParams<T> p)
 #pragma unroll
             for (int t = 0; t < TA; ++t) {
                 const long long x = x0 + t * SA;
-                const P bM_next = ldv<T, VEC>(bM + xn0 + t * SA);
+                const P bM_next = ldv_m<T, VEC>(bM + xn0 + t * SA);
                 P s;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) s.v[j] = lmM * (bM_cur[t].v[j] - bM_next.v[j]);

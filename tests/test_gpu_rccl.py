@@ -131,3 +131,39 @@ def test_exchange_selfcheck(backend):
     assert res[0] == res[1]
     assert res[0]["blocking"] and res[0]["overlap"] and res[0]["error"] is None
     assert res[0]["transport"] == ("rccl" if backend == "nccl" else "gloo")
+
+
+def _mixed_groups_worker(rank, world, port, outdir):
+    """What bench.py's init_groups does: gloo control group first, RCCL data group beside it."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = dist.new_group(backend="nccl", device_id=torch.device("cuda", rank))
+        dist.barrier(group=g)
+        t = torch.full((3,), float(rank + 1), dtype=torch.float64, device=f"cuda:{rank}")
+        dist.all_reduce(t, group=g)
+        c = torch.tensor([float(rank + 1)])
+        dist.all_reduce(c)                                  # default group: gloo, host memory
+        ok = dist.get_backend(g) == "nccl" and dist.get_backend() == "gloo"
+        open(os.path.join(outdir, f"r{rank}.txt"), "w").write(f"{ok} {t[0].item()} {c[0].item()}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_data_group_beside_gloo_control_group():
+    """bench.py --gpus N keeps its decisions and timing reductions on a gloo group and moves halo rows over an RCCL
+    group created beside it (`init_groups`).  One rank is enough to check that this torch/RCCL build accepts the
+    arrangement; with two GPUs the all-reduces really cross."""
+    import torch.multiprocessing as mp
+    world = 2 if _ngpu() >= 2 else 1
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.start_processes(_mixed_groups_worker, args=(world, _free_port(), tmp), nprocs=world, join=True, start_method="spawn")
+        res = [open(os.path.join(tmp, f"r{r}.txt")).read().split() for r in range(world)]
+    want = float(sum(range(1, world + 1)))
+    for ok, t, c in res:
+        assert ok == "True" and float(t) == want and float(c) == want

@@ -11,6 +11,7 @@ build() { # tag, extra flags
 build ntl0 "-DTVDN_NT_LOADS=0" &
 build nts0 "-DTVDN_NT_STORES=0" &
 build nt00 "-DTVDN_NT_LOADS=0 -DTVDN_NT_STORES=0" &
+build mnt0 "-DTVDN_PASS_M_NT=0" &
 build blk512 "-DTVDN_FUSED_BLOCK=512" &
 build blk128 "-DTVDN_FUSED_BLOCK=128" &
 wait
