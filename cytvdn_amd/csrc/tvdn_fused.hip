@@ -69,6 +69,8 @@ struct FusedParams {
     long long tiles;  // workgroups per cross-section
     long long units;  // A * B * (C / VEC)
     int xcd;          // 1: remap workgroup ids so each XCD sweeps a contiguous run of tiles
+    // patch order of the tiles of a cross-section (0 = plain order): patches of patch_a A-rows x patch_t tiles
+    long long patch_a, patch_t, tiles_per_arow;
     double *partials;
 };
 
@@ -181,7 +183,18 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
     constexpr bool HAS_A = (NAX == 4);
 
     const long long L = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (long long)blockIdx.x;
-    const long long chunk_id = L / p.tiles, tile = L % p.tiles;
+    const long long chunk_id = L / p.tiles;
+    long long tile = L % p.tiles;
+    if (HAS_A && p.patch_a > 1) {
+        // The workgroups resident on an XCD at one time cover ~128 consecutive tiles.  In plain order that is a run
+        // of 512 KiB of B x C, which for long A-rows (config-4 planes: 256 KiB each) holds only two of them, so the
+        // A neighbours -- 64 tiles away -- are rarely in flight together.  Patch order makes the run a 2-D patch of
+        // patch_a A-rows x patch_t tiles: every row's A neighbours are patch_t tiles away, whatever the plane.
+        const long long per = p.patch_a * p.patch_t, n_gt = p.tiles_per_arow / p.patch_t;
+        const long long patch = tile / per, r = tile % per;
+        const long long pa = patch / n_gt, pt = patch % n_gt;
+        tile = (pa * p.patch_a + r / p.patch_t) * p.tiles_per_arow + pt * p.patch_t + r % p.patch_t;
+    }
 
     const long long u = tile * kFusedBlock + threadIdx.x;
     double acc[3] = {0.0, 0.0, 0.0};  // b_norm, sum|delta|, sum|old|
@@ -372,6 +385,26 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
     // tuning knobs (measurement only): TVDN_CHUNK = rows per march, TVDN_XCD = 0 disables the XCD remap
     const char *e_chunk = getenv("TVDN_CHUNK"), *e_xcd = getenv("TVDN_XCD");
     p.xcd = e_xcd ? atoi(e_xcd) : 1;
+    {
+        // Patch order (see the kernel): needs whole tiles per A-row and extents divisible by the patch.  A patch holds
+        // the 128 tiles an XCD has in flight.  Interleaved A/B on one MI355X (profiles/r02_ab_patch_order.txt):
+        //   A-rows of 16 tiles (config 2, 64 KiB):      plain order 11.36 ms, every patch shape slower (11.50-12.01)
+        //   A-rows of 32 tiles (config 3, f64, 128 KiB): plain 17.52, 8x16 16.82, 32x4 16.91, 16x8 17.04 ms
+        //   A-rows of 64 tiles (config-4 slab, 256 KiB): plain 24.37, 8x16 23.39, 16x16 23.22, 16x8 23.15, 32x8 23.04 ms
+        const long long row_units = p.B * (p.C / vec);
+        const long long tr = (row_units % kFusedBlock == 0) ? row_units / kFusedBlock : 0;
+        long long ga = tr >= 64 ? 16 : 8, gt = tr >= 64 ? 8 : 16;
+        const char *e_patch = getenv("TVDN_PATCH");  // "A-rows,tiles"; "0" switches it off (measurement knob)
+        if (e_patch) {
+            ga = atoll(e_patch);
+            const char *c = strchr(e_patch, ',');
+            gt = c ? atoll(c + 1) : 16;
+        }
+        p.patch_a = p.patch_t = p.tiles_per_arow = 0;
+        if (nax == 4 && ga > 1 && gt >= 1 && tr > 0 && tr % gt == 0 && (e_patch ? tr > gt : tr >= 32) && p.A % ga == 0) {
+            p.patch_a = ga; p.patch_t = gt; p.tiles_per_arow = tr;
+        }
+    }
     const long long rows = p.sweep_hi - p.sweep_lo;
     // rows per march: long enough to amortise the look-ahead row (3 extra pack loads per chunk); short
     // marches measured best on MI355X (2..8 rows: 14.7-14.9 ms, 32 rows: 15.3 ms on 256x256x128x128 f32):

@@ -25,6 +25,7 @@ import numpy as np
 
 HEADROOM = 0.9            # fraction of the free HBM an in-core state may take
 STAGING_FRACTION = 0.7    # fraction the level windows of a streamed run may take
+MAX_DEPTH = 128           # iterations per pass beyond which the sweeps, not PCIe, set the pace
 
 
 def _parse_bytes(text: str) -> int:
@@ -118,20 +119,29 @@ def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int =
                    host_bytes_per_rank=(3 + 2 * nd * (2 if FISTA else 1)) * (rows_own + 2) * plane,
                    why="state exceeds HBM and the stopping rule needs a decision every iteration")
         return out
-    for k, rows in ((64, 32), (64, 16), (32, 16), (32, 8), (16, 16), (16, 8), (16, 4), (8, 8), (8, 4), (4, 4), (4, 2), (2, 2),
-                    (1, 2)):       # depth first: PCIe traffic per iteration falls as 1/k
+    # Depth first: PCIe traffic per iteration falls as 1/k, and a streamed run is PCIe-bound until k ~ 100 (measured on
+    # config-2 planes: k 32 -> 36, k 64 -> 55-58, k 128 -> 60 Gvoxel-iters/s).  For every chunk height the deepest k
+    # whose level windows fit is taken (the need is linear in k); among those the deepest wins, taller chunks on ties.
+    budget = int(STAGING_FRACTION * avail // plane)            # planes of HBM the windows may take
+    best = None
+    for rows in (32, 16, 8, 4, 2):
         rows = min(rows, max(2, rows_own))
-        k = min(k, max(1, rows_own))
+        slope = wavefront_windows(nd, rows, 2) - wavefront_windows(nd, rows, 1)
+        k = (budget - wavefront_windows(nd, rows, 0)) // slope if slope > 0 else 0
+        k = int(min(k, MAX_DEPTH, max(1, rows_own)))
+        if k >= 1 and wavefront_windows(nd, rows, k) <= budget and (best is None or k > best[0]):
+            best = (k, rows)
+    if best is not None:
+        k, rows = best
         need = wavefront_windows(nd, rows, k) * plane
-        if need <= STAGING_FRACTION * avail:
-            out.update(mode="wavefront" if s == 1 else "slabs+wavefront", n_slabs=s, chunk_rows=rows, k=k,
-                       bytes_per_gpu=need,
-                       host_bytes_per_rank=(3 + 2 * nd * (2 if FISTA else 1)) * (rows_own + 2 * k) * plane,
-                       why=f"state of {out['state_bytes'] / 2 ** 30:.1f} GiB exceeds "
-                           f"{s} x {avail / 2 ** 30:.1f} GiB of HBM: streamed from pinned host memory")
-            if host_bytes is not None and out["host_bytes_per_rank"] > host_bytes:
-                out["why"] += " (WARNING: the pinned host state does not fit in the host memory given)"
-            return out
+        out.update(mode="wavefront" if s == 1 else "slabs+wavefront", n_slabs=s, chunk_rows=rows, k=k,
+                   bytes_per_gpu=need,
+                   host_bytes_per_rank=(3 + 2 * nd * (2 if FISTA else 1)) * (rows_own + 2 * k) * plane,
+                   why=f"state of {out['state_bytes'] / 2 ** 30:.1f} GiB exceeds "
+                       f"{s} x {avail / 2 ** 30:.1f} GiB of HBM: streamed from pinned host memory")
+        if host_bytes is not None and out["host_bytes_per_rank"] > host_bytes:
+            out["why"] += " (WARNING: the pinned host state does not fit in the host memory given)"
+        return out
     out.update(mode="does-not-fit", bytes_per_gpu=wavefront_windows(nd, 2, 1) * plane,
                why="not even a 2-row chunk window fits in HBM")
     return out

@@ -153,6 +153,24 @@ def test_fused_vs_oracle(tv, oracle, monkeypatch, shape, dtype, bc, mode, state)
     np.testing.assert_allclose(dl.astype(np.float64), want, rtol=1e-6 if dtype == np.float32 else 1e-12)
 
 
+@pytest.mark.parametrize("patch", ["2,4", "4,2", "8,16", "0"])
+def test_fused_patch_order_of_tiles(tv, oracle, monkeypatch, patch):
+    """The fused sweep's workgroups may walk the cross-section in 2-D patches (A-rows x tiles) instead of plain order
+    (long A-rows: config-4 planes).  A pure permutation of who computes what: the bits must not move."""
+    from cytvdn_amd import synth
+    monkeypatch.setenv("TVDN_PATCH", patch)
+    for shape, dtype, bc in (((5, 4, 64, 128), np.float32, 2), ((3, 8, 128, 256), np.float32, 0), ((4, 4, 64, 128), np.float64, 2),
+                             ((6, 8, 32, 512), np.float32, 2)):
+        dt = np.dtype(dtype)
+        x = synth.cube(shape, seed=61, dtype=dt) + dt.type(0.25)
+        mu = np.array([1.0, 0.8, 0.5, 0.6], dt)
+        recon, bn, dl = tv.denoise4D(x, mu, [3, 2], BC_mode=bc, quiet=True)
+        ref = oracle.denoise(x, mu, [3, 2], True, BC_mode=bc)
+        assert bits_equal(recon, ref["recon"]), (shape, patch)
+        np.testing.assert_allclose(bn.astype(np.float64), ref["b_norm64"].astype(dt).astype(np.float64),
+                                   rtol=1e-6 if dt == np.float32 else 1e-12)
+
+
 def test_device_tensors_in_place(tv, oracle):
     """Kernel-level calls on torch CUDA tensors update HBM in place."""
     import torch

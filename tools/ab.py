@@ -4,7 +4,7 @@ per round, alternating the variants, and prints mean / min of the sweep-kernel t
 by several per cent, so only numbers taken alternately on one box in one call are comparable.
 
     python tools/ab.py --rounds 4 "base:" "skew4k:TVDN_ARRAY_SKEW=4096" -- --steps 20 --warmup 3
-    python tools/ab.py --passes --rounds 3 "c8:TVDN_PASS_CHUNK=8" "c32:TVDN_PASS_CHUNK=32"
+    python tools/ab.py --passes --rounds 3 "c8:TVDN_PASS_CHUNK=8" "c32:TVDN_PASS_CHUNK=32;TVDN_LIB=/path/variant.so"
 """
 import json
 import os
@@ -28,7 +28,7 @@ def main():
     variants = []
     for v in args:
         label, _, envs = v.partition(":")
-        env = dict(e.split("=", 1) for e in envs.split(",") if e)
+        env = dict(e.split("=", 1) for e in envs.split(";") if e)   # several: "A=1;B=2" (values may hold commas)
         variants.append((label, env))
     res = defaultdict(lambda: defaultdict(list))
     for r in range(rounds):
