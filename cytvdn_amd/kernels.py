@@ -84,20 +84,28 @@ class _Staged:
             dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
         self.device = dev
         _lib.ctx(self.device)  # raises TvdnError without a GPU: no CPU fallback
+        cuda = torch.device("cuda", self.device)
         for x, w in zip(self._arrays, self._writable):
             if isinstance(x, np.ndarray):
-                t = torch.from_numpy(np.ascontiguousarray(x)).to(torch.device("cuda", self.device))
+                # host arrays cross PCIe through the library's pinned multi-lane staging (csrc/tvdn_hostio.hip)
+                t = torch.empty(self.shape, dtype=_TORCH_DT[self.dt], device=cuda)
+                torch.cuda.current_stream(self.device).synchronize()
+                _lib.copy_to_device(np.ascontiguousarray(x), t)
                 if w:
                     self.back.append((x, t))
             else:
                 t = x
             self.dev_tensors.append(t)
-        self.out = torch.zeros(4, dtype=torch.float64, device=torch.device("cuda", self.device))
+        self.out = torch.zeros(4, dtype=torch.float64, device=cuda)
 
     def finish(self):
         vals = self.out.cpu().numpy()  # synchronises the stream
         for x, t in self.back:
-            x[...] = t.cpu().numpy()
+            if x.flags["C_CONTIGUOUS"]:
+                _lib.check(_lib.lib().tvdn_copy_to_host(C.c_void_p(x.ctypes.data), C.c_void_p(t.data_ptr()), x.nbytes,
+                                                        self.device))       # straight into the caller's array
+            else:
+                x[...] = _lib.copy_to_host(t, self.dt)                       # strided view: via a dense temporary
         return vals
 
 
