@@ -219,9 +219,11 @@ class EmulatedNeighbours:
         return self.be.sums_tensor().clone()
 
 
-def measure(shape, dtype_name, fista, state, steps, warmup, device, rank=0, world=1, group=None, ctl=None,
+def measure(shape, dtype_name, fista, state, steps, warmup, device, rank=0, world=1, group=None,
             slab_of=0, overlap=True, traffic_table=None):
-    """Runs warmup + steps iterations of one workload on this rank's slab; returns the result dict (same on all ranks)."""
+    """Runs warmup + steps iterations of one workload on this rank's slab; returns the result dict (same on all ranks).
+    `group` is the data-plane group (RCCL; None = the default group); barriers and the timing reduction use the
+    default group, which `init_groups` makes a gloo one (host memory)."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -256,7 +258,7 @@ def measure(shape, dtype_name, fista, state, steps, warmup, device, rank=0, worl
         runner.finish()
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(group=ctl)
+            dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(warmup):
@@ -275,7 +277,7 @@ def measure(shape, dtype_name, fista, state, steps, warmup, device, rank=0, worl
     kern_ms = tot_ms.value / max(steps, 1)
     if world > 1:
         t = torch.tensor([elapsed, kern_ms], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)      # control-plane group (gloo, host memory)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)      # control-plane group (gloo, host memory)
         elapsed, kern_ms = float(t[0]), float(t[1])
     sums = runner.global_sums().cpu().numpy()      # all-reduced over the data-plane group when world > 1
     own_vox = float(lay.own_rows) * float(np.prod(shape[1:]))
@@ -409,7 +411,7 @@ def main():
         traffic_table = None
 
     main_res = measure(shape, dtype_name, fista, a.state, a.steps, a.warmup, local_rank, rank, world, group,
-                       None, a.slab_of, overlap, traffic_table)
+                       a.slab_of, overlap, traffic_table)
 
     also = None
     headline = world == 1 and not a.slab_of and not a.shape and dtype_name == "f32" and fista

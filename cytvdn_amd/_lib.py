@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TVDN_LIB") or os.path.join(_HERE, "libtvdn_hip.so")
 
 TVDN_F32, TVDN_F64 = 0, 1
-EDGE_BC, EDGE_HALO, EDGE_ZERO = 0, 1, 2
+EDGE_BC, EDGE_HALO, EDGE_ZERO, EDGE_WRAP = 0, 1, 2, 3
 ITER_PLAIN, ITER_FISTA, ITER_FISTA_D, ITER_FISTA_D_TO_PLAIN = 0, 1, 2, 3
 
 EXPORTS = (
@@ -47,6 +47,7 @@ class IterArgs(C.Structure):
         ("b_in", C.c_void_p * 4), ("b_out", C.c_void_p * 4), ("d_in", C.c_void_p * 4), ("d_out", C.c_void_p * 4),
         ("dprev_in", C.c_void_p * 4),
         ("sweep_lo", C.c_int64), ("sweep_hi", C.c_int64), ("accumulate", C.c_int32), ("reserved", C.c_int32),
+        ("wrap_recon", C.c_void_p),
     ]
 
 

@@ -56,6 +56,7 @@ struct FusedParams {
     const T *orig;
     const T *r_in;
     T *r_out;
+    const T *wrap;  // TVDN_EDGE_WRAP: current recon of global row 0 (one plane)
     AxisState<T> ax[4];
     T tk;       // momentum ratio of this iteration
     T tk_prev;  // momentum ratio of the previous iteration (FISTA_D*: rebuilds b_k)
@@ -264,12 +265,25 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
             for (int j = 0; j < VEC; ++j) bM_next.v[j] = (T)0;  // TVDN_EDGE_ZERO
             if (!(at_end && p.hi_mode == TVDN_EDGE_ZERO)) {
                 const bool wrap = at_end && p.hi_mode == TVDN_EDGE_BC;
-                const long long xn = (wrap ? p.row_lo : m + 1) * SM + xs;
-                r_next = ldv<T, VEC>(p.r_in + xn);
-                const P v1 = ldv_nt<T, VEC>(sM.in1 + xn);
+                // TVDN_EDGE_WRAP (Jia-Zhao, last slab of several): the wrapped neighbour is global row 0, whose axis-0
+                // accumulator upstream forms as clip((r0 - r0) + b0) -- zero while row 0 is finite, NaN from the moment it
+                // is not (anisotropic.pyx:65-73).  p.wrap holds row 0's current recon; its state is that zero (the
+                // state loads below then land on the own row and are discarded).
+                const bool wrapz = at_end && p.hi_mode == TVDN_EDGE_WRAP;
+                const long long xn = (wrap ? p.row_lo : (wrapz ? m : m + 1)) * SM + xs;
+                const T *rbase = wrapz ? p.wrap - m * SM : p.r_in;  // wave-uniform: p.wrap + xs == rbase + xn
+                r_next = ldv<T, VEC>(rbase + xn);
+                P v1 = ldv_nt<T, VEC>(sM.in1 + xn);
                 P v2, o1, o2;
                 if (MT::kIn2) v2 = ldv_nt<T, VEC>(sM.in2 + xn);
-                const bool self = wrap && bc2;
+                if (wrapz) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        v1.v[j] = (T)0;
+                        if (MT::kIn2) v2.v[j] = (T)0;
+                    }
+                }
+                const bool self = (wrap && bc2) || wrapz;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j)
                     bM_next.v[j] = acc_new<T, MODE>(r_next.v[j], self ? r_next.v[j] : r_cur.v[j], v1.v[j],
@@ -377,6 +391,8 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
     p.sweep_lo = whole ? a->row_lo : a->sweep_lo;
     p.sweep_hi = whole ? a->row_hi : a->sweep_hi;
     p.lo_mode = a->lo_mode; p.hi_mode = a->hi_mode; p.bc = a->bc_mode;
+    if (a->hi_mode == TVDN_EDGE_WRAP)  // an explicit plane, or by convention the row that follows the own rows
+        p.wrap = a->wrap_recon ? (const T *)a->wrap_recon : p.r_in + a->row_hi * (p.A * p.B * p.C);
     p.partials = ctx->partials;
 
     const int vec = (al && (p.C % VMAX == 0)) ? VMAX : 1;
@@ -467,7 +483,10 @@ extern "C" int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *a, double
                      (a->row_lo <= a->sweep_lo && a->sweep_lo < a->sweep_hi && a->sweep_hi <= a->row_hi),
                  "sweep rows [%lld,%lld) not inside the own rows", (long long)a->sweep_lo, (long long)a->sweep_hi);
     TVDN_REQUIRE(a->lo_mode == TVDN_EDGE_BC || a->lo_mode == TVDN_EDGE_HALO, "bad lo_mode %d", a->lo_mode);
-    TVDN_REQUIRE(a->hi_mode >= TVDN_EDGE_BC && a->hi_mode <= TVDN_EDGE_ZERO, "bad hi_mode %d", a->hi_mode);
+    TVDN_REQUIRE(a->hi_mode >= TVDN_EDGE_BC && a->hi_mode <= TVDN_EDGE_WRAP, "bad hi_mode %d", a->hi_mode);
+    TVDN_REQUIRE(!(a->hi_mode == TVDN_EDGE_WRAP && a->bc_mode != TVDN_BC_JIA_ZHAO), "hi_mode WRAP is a Jia-Zhao property");
+    TVDN_REQUIRE(!(a->hi_mode == TVDN_EDGE_WRAP && !a->wrap_recon && a->row_hi >= a->shape[0]),
+                 "hi_mode WRAP needs wrap_recon or a row at row_hi holding global row 0");
     TVDN_REQUIRE(!(a->lo_mode == TVDN_EDGE_HALO && a->row_lo < 1), "lo_mode HALO needs a row below row_lo");
     TVDN_REQUIRE(!(a->hi_mode == TVDN_EDGE_HALO && a->row_hi >= a->shape[0]), "hi_mode HALO needs a row at row_hi");
     TVDN_REQUIRE(!(a->hi_mode == TVDN_EDGE_ZERO && a->bc_mode != TVDN_BC_JIA_ZHAO), "hi_mode ZERO is a Jia-Zhao property");

@@ -83,13 +83,27 @@ static int run_impl(const tvdn_run_args *a)
     TVDN_REQUIRE(N0 >= world, "axis 0 (%lld rows) cannot be cut into %d slabs", (long long)N0, world);
     std::unique_ptr<Slab[]> sl(new Slab[world]);
     const bool ring = world > 1 && periodic;
+    // Jia-Zhao across several slabs: the last slab closes the wrap of the reconstruction update with the axis-0
+    // accumulator of global row 0, which is zero for finite data (TVDN_EDGE_ZERO).  If the cube's first row holds an
+    // Inf or a NaN, upstream gets NaN there (anisotropic.pyx:65-73): the last slab then keeps row 0's current recon
+    // as one more halo row, refreshed like any other, and forms the accumulator from it (TVDN_EDGE_WRAP).
+    bool exact_wrap = false;
+    if (world > 1 && !periodic) {
+        if (a->dtype == TVDN_F32) {
+            const float *p0 = (const float *)a->data;
+            for (size_t i = 0; i < plane && !exact_wrap; ++i) exact_wrap = !std::isfinite(p0[i]);
+        } else {
+            const double *p0 = (const double *)a->data;
+            for (size_t i = 0; i < plane && !exact_wrap; ++i) exact_wrap = !std::isfinite(p0[i]);
+        }
+    }
     for (int r = 0; r < world; ++r) {
         Slab &s = sl[r];
         s.device = a->n_devices > 0 ? a->devices[r] : a->device;
         s.g0 = (int64_t)r * N0 / world;
         s.g1 = (int64_t)(r + 1) * N0 / world;
         s.halo_lo = (world > 1 && (r > 0 || ring)) ? 1 : 0;
-        s.halo_hi = (world > 1 && (r < world - 1 || ring)) ? 1 : 0;
+        s.halo_hi = (world > 1 && (r < world - 1 || ring || exact_wrap)) ? 1 : 0;
         TVDN_HIP(hipSetDevice(s.device));
         int rc = tvdn_ctx_create(&s.ctx, s.device);
         if (rc) return rc;
@@ -162,7 +176,8 @@ static int run_impl(const tvdn_run_args *a)
         it.row_lo = s.row_lo();
         it.row_hi = s.row_hi();
         it.lo_mode = s.halo_lo ? TVDN_EDGE_HALO : TVDN_EDGE_BC;
-        it.hi_mode = s.halo_hi ? TVDN_EDGE_HALO : (world == 1 ? TVDN_EDGE_BC : TVDN_EDGE_ZERO);
+        it.hi_mode = s.halo_hi ? ((exact_wrap && r == world - 1) ? TVDN_EDGE_WRAP : TVDN_EDGE_HALO)
+                               : (world == 1 ? TVDN_EDGE_BC : TVDN_EDGE_ZERO);
         it.bc_mode = a->bc_mode;
         for (int q = 0; q < nd; ++q) {
             it.clip[q] = a->clip[q];

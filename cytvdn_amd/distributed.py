@@ -50,6 +50,18 @@ def denoise_slabs(my_rows, global_shape, mu, iterations=10, FISTA=True, stopping
     if BC_mode == 1:
         raise NotImplementedError("BC_mode=1 (mirror) is undefined behaviour upstream (utils.pyx:117-120)")
     lay = SlabLayout(tuple(int(s) for s in global_shape), rank, world, int(BC_mode))
+    if world > 1 and int(BC_mode) == 2 and staged is None and lay.own_rows == my_rows.shape[0]:
+        # exact Jia-Zhao wrap for a cube whose FIRST row is not finite (see engine.py): every rank must agree
+        bad = 0
+        if rank == 0 and my_rows.shape[0] > 0:
+            first = my_rows[0]
+            bad = int(not bool(torch.isfinite(first).all() if is_t else np.isfinite(first).all()))
+        flag = torch.tensor([bad], dtype=torch.int32)
+        if dist.get_backend(group) == "nccl":
+            flag = flag.to(torch.device("cuda", torch.cuda.current_device() if device is None else device))
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag.item()):
+            lay = SlabLayout(lay.shape, rank, world, 2, wrap_row=True)
     if tuple(my_rows.shape) != (lay.own_rows,) + tuple(global_shape[1:]):
         raise ValueError(f"rank {rank} owns rows {lay.g0}..{lay.g1}: expected shape "
                          f"{(lay.own_rows,) + tuple(global_shape[1:])}, got {tuple(my_rows.shape)}")

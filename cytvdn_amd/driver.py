@@ -92,6 +92,9 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
     # stopping rule needs a host decision after every iteration.  TVDN_WAVEFRONT / TVDN_STAGED = "rows,k" force one.
     stop = stopping_relative_change
     wf, st = os.environ.get("TVDN_WAVEFRONT"), os.environ.get("TVDN_STAGED")
+    # streamed engines, Jia-Zhao: exact wrap at the cube's top face when the FIRST row is not finite (engine.py)
+    first = datacube.read_rows(0, 1) if hasattr(datacube, "read_rows") else datacube[:1]
+    exact_wrap = bool(BC_mode == 2 and not np.isfinite(first).all())
     plan = plan_run(datacube.shape, dtype, FISTA, 1, stop=stop is not None, device=device)
     if plan["mode"] == "does-not-fit" and not (wf or st):
         raise MemoryError(f"cube of shape {datacube.shape} cannot be streamed through {_fmt_bytes(plan['hbm_bytes'])} "
@@ -102,7 +105,7 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
             print(f"State exceeds HBM: streaming the cube from pinned host memory, {rows_k[1]} iterations per pass "
                   f"(wavefront schedule, {rows_k[0]}-row chunks)", flush=True)
         return _run_wavefront(rows_k, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device,
-                              BC_mode, reference_data, out)
+                              BC_mode, reference_data, out, exact_wrap)
     if st or plan["mode"] in ("trapezoid", "wavefront"):
         if st:
             rows, k = (int(v) for v in st.split(","))
@@ -111,7 +114,7 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
         if stop is not None:
             k = 1      # the stopping test is per iteration (cyTVDN.py:189-194): no temporal blocking then
         return _run_staged((max(1, rows), max(1, k)), datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista,
-                           n_plain, stop, reference_data, BC_mode, quiet, device, out)
+                           n_plain, stop, reference_data, BC_mode, quiet, device, out, exact_wrap)
     layout = SlabLayout(tuple(datacube.shape), 0, 1, int(BC_mode))
     be = HipBackend(layout, dtype, FISTA, device=device, max_iters=n_total)   # raises without a GPU
     be.set_params(lambdaInv, lam_mu)
@@ -177,14 +180,14 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
 
 
 def _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device, BC_mode=2,
-                   reference_data=None, out=None):
+                   reference_data=None, out=None, exact_wrap=False):
     """Host-resident state, wavefront schedule (cytvdn_amd/wavefront.py): anything but a stopping rule."""
     from .wavefront import WavefrontRunner
     dtype = datacube.dtype
     n_total = n_fista + n_plain
     rows, k = plan
     wr = WavefrontRunner(datacube, FISTA, lambdaInv, lam_mu, device=device, chunk_rows=rows, k=k, max_iters=n_total,
-                         bc_mode=int(BC_mode), reference=reference_data)
+                         bc_mode=int(BC_mode), reference=reference_data, exact_wrap=exact_wrap)
     wr.run(n_fista if FISTA else 0, n_plain if unaccelerated else 0)
     sums = wr.sums()[:n_total] if n_total else np.zeros((0, 3))
     b_norm = sums[:, 0].astype(dtype)
@@ -196,7 +199,7 @@ def _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fi
 
 
 def _run_staged(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, stop, reference_data,
-                BC_mode, quiet, device, out=None):
+                BC_mode, quiet, device, out=None, exact_wrap=False):
     from .outofcore import StagedRunner
     if BC_mode != 2:
         raise NotImplementedError("a host-staged run with a stopping rule or reference_data supports BC_mode=2 only")
@@ -207,7 +210,7 @@ def _run_staged(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista
         print(f"State exceeds HBM: staging {rows}-row blocks through pinned host memory, {k} iterations per pass",
               flush=True)
     sr = StagedRunner(datacube, FISTA, lambdaInv, lam_mu, bc_mode=int(BC_mode), device=device, block_rows=rows, k=k,
-                      max_iters=n_total, reference=reference_data)
+                      max_iters=n_total, reference=reference_data, exact_wrap=exact_wrap)
     ran = np.zeros(n_total, dtype=bool)
 
     def on_ss(first, count):

@@ -10,8 +10,11 @@ Non-finite data.  Under the Jia-Zhao boundary condition the axis-0 accumulator o
 for finite data (clip((r - r) + 0)), which is what lets the last slab close the periodic wrap of the reconstruction
 update with a constant (TVDN_EDGE_ZERO) instead of a message from rank 0.  If row 0 holds an Inf or a NaN, upstream
 (and the single-slab run here, which wraps for real) gets NaN from Inf - Inf in that accumulator and propagates it
-into the LAST row; a multi-slab, wavefront or staged run does not.  Bit parity of those three paths therefore holds
-for data whose first row stays finite; everywhere else NaN/Inf propagate exactly as upstream on every path.
+into the LAST row.  `SlabLayout(..., wrap_row=True)` reproduces that: rank 0 then also sends its first row to the last
+rank every iteration, which forms the wrapped accumulator from it as upstream does (TVDN_EDGE_WRAP).  `denoise_slabs`,
+`denoise3D/4D` (wavefront / staged engines, single process) and `tvdn_run` switch it on by themselves when the first
+row of the input is not finite; `bench.py` and finite data never pay for the extra message.  Left out: staged slabs
+across ranks (`denoise_slabs(staged=...)`), which keep the constant.
 
 Pieces
 ------
@@ -59,6 +62,9 @@ class SlabLayout:
     world: int
     bc_mode: int
     bounds: tuple = None  # optional explicit partition: world+1 increasing row indices, 0 .. shape[0]
+    wrap_row: bool = False  # Jia-Zhao, several slabs: the last slab also keeps the CURRENT recon of global row 0 (sent by
+    #                         rank 0 every iteration) and forms the wrapped axis-0 accumulator from it as upstream does
+    #                         (TVDN_EDGE_WRAP) instead of taking it as zero: exact when row 0 holds Inf/NaN as well
 
     def __post_init__(self):
         if self.world < 1 or not (0 <= self.rank < self.world):
@@ -95,8 +101,12 @@ class SlabLayout:
         return 1 if self.world > 1 and (self.rank > 0 or self.ring) else 0
 
     @property
+    def wraps(self) -> bool:
+        return bool(self.wrap_row) and self.world > 1 and self.bc_mode == 2
+
+    @property
     def halo_hi(self) -> int:
-        return 1 if self.world > 1 and (self.rank < self.world - 1 or self.ring) else 0
+        return 1 if self.world > 1 and (self.rank < self.world - 1 or self.ring or self.wraps) else 0
 
     @property
     def own_rows(self) -> int:
@@ -120,6 +130,8 @@ class SlabLayout:
 
     @property
     def hi_mode(self) -> int:
+        if self.wraps and self.rank == self.world - 1:
+            return _lib.EDGE_WRAP
         if self.halo_hi:
             return _lib.EDGE_HALO
         return _lib.EDGE_BC if self.world == 1 else _lib.EDGE_ZERO
@@ -133,9 +145,18 @@ class SlabLayout:
 
     @property
     def right(self):
-        if not self.halo_hi:
+        if not self.halo_hi or (self.rank == self.world - 1 and not self.ring):
             return None
         return (self.rank + 1) % self.world
+
+    @property
+    def wrap_to(self):
+        """Rank that keeps a copy of my first row (rank 0 of a `wrap_row` layout -> the last rank)."""
+        return self.world - 1 if self.wraps and self.rank == 0 else None
+
+    @property
+    def wrap_from(self):
+        return 0 if self.wraps and self.rank == self.world - 1 else None
 
     def local_rows_global(self) -> np.ndarray:
         """Global row index held by each local row (halo rows included, periodic wrap applied)."""
@@ -347,6 +368,7 @@ class HipBackend:
         a.shape[0] = int(rows)
         a.row_lo, a.row_hi = 0, int(rows)
         a.lo_mode, a.hi_mode = _lib.EDGE_BC, int(hi_mode)
+        a.wrap_recon = None                     # TVDN_EDGE_WRAP callers point it at their plane before each step
 
     def set_form(self, d_form: bool, tk_prev: float):
         """Declare what the state arrays hold after an upload: (d_k, d_k-1) pairs or b."""
@@ -443,13 +465,15 @@ class SlabRunner:
         lay, dist = self.layout, self.dist
         if self._stage is None:
             row = r[lay.row_lo]
-            self._stage = [torch.empty(row.shape, dtype=row.dtype, pin_memory=True) for _ in range(4)]
-        s_lo, s_hi, r_lo, r_hi = self._stage
+            self._stage = [torch.empty(row.shape, dtype=row.dtype, pin_memory=True) for _ in range(6)]
+        s_lo, s_hi, r_lo, r_hi, s_wr, r_wr = self._stage
         ops = []
         if lay.left is not None:
             s_lo.copy_(r[lay.row_lo])
         if lay.right is not None:
             s_hi.copy_(r[lay.row_hi - 1])
+        if lay.wrap_to is not None:
+            s_wr.copy_(r[lay.row_lo])
         torch.cuda.current_stream(r.device).synchronize()
         if lay.left is not None:
             ops.append(dist.P2POp(dist.isend, s_lo, self._peer(lay.left), self.group, tag=1))
@@ -458,12 +482,18 @@ class SlabRunner:
             ops.append(dist.P2POp(dist.irecv, r_hi, self._peer(lay.right), self.group, tag=1))
         if lay.left is not None:
             ops.append(dist.P2POp(dist.irecv, r_lo, self._peer(lay.left), self.group, tag=2))
+        if lay.wrap_to is not None:
+            ops.append(dist.P2POp(dist.isend, s_wr, self._peer(lay.wrap_to), self.group, tag=3))
+        if lay.wrap_from is not None:
+            ops.append(dist.P2POp(dist.irecv, r_wr, self._peer(lay.wrap_from), self.group, tag=3))
         for w in dist.batch_isend_irecv(ops):
             w.wait()
         if lay.right is not None:
             r[lay.row_hi].copy_(r_hi)
         if lay.left is not None:
             r[lay.row_lo - 1].copy_(r_lo)
+        if lay.wrap_from is not None:
+            r[lay.row_hi].copy_(r_wr)
 
     def exchange_halos(self):
         """Send my first/last own recon rows to the neighbours, receive theirs into my halo rows.
@@ -494,6 +524,12 @@ class SlabRunner:
             ops.append(dist.P2POp(dist.irecv, r[lay.row_hi], self._peer(lay.right), self.group, tag=1))
         if lay.left is not None:
             ops.append(dist.P2POp(dist.irecv, r[lay.row_lo - 1], self._peer(lay.left), self.group, tag=2))
+        # `wrap_row` layouts: rank 0's first row also goes to the last rank (after the ordinary rows, on both sides, so
+        # that with two ranks -- one peer, three messages -- sends and receives still pair up in issue order)
+        if lay.wrap_to is not None:
+            ops.append(dist.P2POp(dist.isend, r[lay.row_lo], self._peer(lay.wrap_to), self.group, tag=3))
+        if lay.wrap_from is not None:
+            ops.append(dist.P2POp(dist.irecv, r[lay.row_hi], self._peer(lay.wrap_from), self.group, tag=3))
         return ops
 
     def step_overlapped(self, tk_ratio, slot: int):
@@ -598,6 +634,9 @@ class LocalSlabs:
             if lay.right is not None:
                 rb = self.bes[lay.right]
                 rb.recon_tensor()[rb.layout.row_lo - 1].copy_(r[lay.row_hi - 1])  # my last row -> right's low halo
+            if lay.wrap_to is not None:
+                wb = self.bes[lay.wrap_to]
+                wb.recon_tensor()[wb.layout.row_hi].copy_(r[lay.row_lo])          # row 0 -> the last slab's wrap row
 
     def run(self, n_fista: int, n_plain: int):
         ratios = fista_ratios(n_fista)
@@ -625,11 +664,11 @@ class LocalSlabs:
 
 
 def hbm_plan(shape, dtype, fista: bool, world: int = 1) -> dict:
-    """Bytes of HBM one slab needs in the fused (double-buffered) engine (cf. check_memory)."""
+    """Bytes of HBM one slab needs in the fused (multi-buffered) engine (cf. check_memory; planner.plan_run decides)."""
+    from .planner import state_arrays
     n = int(np.prod(shape)) // max(world, 1)
     item = np.dtype(dtype).itemsize
-    nd = len(shape)
-    arrays = 1 + 2 + nd * (3 if fista else 2)   # orig, recon x2, rotating accumulator arrays per axis
+    arrays = state_arrays(len(shape), fista)   # orig, recon x2, rotating accumulator arrays per axis
     return dict(arrays=arrays, bytes=arrays * n * item, per_array=n * item)
 
 

@@ -121,7 +121,7 @@ class StagedRunner:
     def __init__(self, datacube: np.ndarray, fista: bool, clip, lam_mu, bc_mode: int = 2, device: int = 0,
                  block_rows: int = 32, k: int = 8, max_iters: int = 1, reference: np.ndarray = None,
                  pin: bool = True, global_rows: int = None, row0: int = 0, group=None, world: int = 1, rank: int = 0,
-                 n_stages: int = 3):
+                 n_stages: int = 3, exact_wrap: bool = False):
         if bc_mode != 2:
             raise NotImplementedError("the staged engine supports the Jia-Zhao boundary condition (BC_mode=2) only")
         own_shape = tuple(int(s) for s in datacube.shape)
@@ -188,6 +188,12 @@ class StagedRunner:
             be.mse = torch.zeros(self.max_iters + 1, dtype=torch.float64, device=be.orig.device) if reference is not None else None
             be.tmp = torch.zeros(1, dtype=torch.float64, device=be.orig.device)
             self.stages.append(be)
+        # `exact_wrap` (single process): the block at the cube's top face forms the wrapped axis-0 accumulator from the
+        # recon of global row 0 at each level (TVDN_EDGE_WRAP), which the block at the bottom face sets aside as it
+        # goes; see wavefront.py and engine.py ("Non-finite data")
+        self.row0 = None
+        if exact_wrap and self.world == 1:
+            self.row0 = [torch.empty(tuple(plane), dtype=tdt, device=self.stages[0].orig.device) for _ in range(self.k + 1)]
         self.bytes_h2d = 0
         self.bytes_d2h = 0
         if self.ref_h is not None:  # MSE[0]: input against reference (cyTVDN.py:124-125), block by block
@@ -220,14 +226,16 @@ class StagedRunner:
         discard = self.max_iters                      # sums row nobody reads
         form_after = tk_after = None
         prev = None                                   # (s0, s1, carry-ready event, first carried row) of the previous block
+        row0_ready = None                             # exact_wrap: the bottom block has set row 0 of every level aside
         for bi, (g0, g1) in enumerate(self.blocks):
             be = self.stages[bi % len(self.stages)]
             s0, s1 = max(0, g0 - kk), min(N0, g1 + kk)
             rows = s1 - s0
             lo_edge, hi_edge = (s0 == 0), (s1 == N0)
             whole = lo_edge and hi_edge
+            stash = self.row0 is not None and not whole
             with torch.cuda.stream(be.stream):
-                be.set_block(rows, _lib.EDGE_BC if (whole or not hi_edge) else _lib.EDGE_ZERO)
+                be.set_block(rows, _lib.EDGE_BC if (whole or not hi_edge) else (_lib.EDGE_WRAP if stash else _lib.EDGE_ZERO))
                 be.set_form(self.d_form, self.tk_prev)
                 # ---- bring in the block with its halo rows ------------------------------------------------
                 # Rows it shares with the previous block (that block's top 2k rows, still at the state of the
@@ -261,10 +269,15 @@ class StagedRunner:
                 # ---- k iterations on a shrinking range of rows ----------------------------------------
                 v0, v1 = 0, rows                      # rows whose state is current
                 o0, o1 = g0 - s0, g1 - s0             # own rows, local
+                if stash and lo_edge:
+                    self.row0[0].copy_(be.recon_tensor()[0])
+                if stash and hi_edge:
+                    be.stream.wait_event(row0_ready)  # recorded by the bottom block, which is always issued first
                 for j, tk in enumerate(ratios):
                     a = v0 if lo_edge else v0 + 1
                     b = v1 if hi_edge else v1 - 1
                     slot = slot0 + j
+                    be._args.wrap_recon = self.row0[j].data_ptr() if (stash and hi_edge) else None
                     # the sums count own rows only: halo rows go to a discard slot
                     if a < o0:
                         be.step(tk, discard, rows=(a, o0), accumulate=True)
@@ -273,8 +286,14 @@ class StagedRunner:
                         be.step(tk, discard, rows=(o1, b), accumulate=True)
                     be.flip()
                     v0, v1 = a, b
+                    if stash and lo_edge:
+                        self.row0[j + 1].copy_(be.recon_tensor()[0])
                     if self.ref_h is not None:
                         self._sse(be, be.ref[:o1 - o0], be.recon_tensor()[o0:o1], slot + 1)
+                if stash and lo_edge:
+                    row0_ready = torch.cuda.Event()
+                    row0_ready.record(be.stream)
+                be._args.wrap_recon = None
                 # ---- download the own rows ----------------------------------------------------------------
                 self.recon_h[new][g0 - base:g1 - base].copy_(be.recon_tensor()[o0:o1], non_blocking=True)
                 n_down = 1

@@ -72,7 +72,8 @@ class WavefrontRunner:
 
     def __init__(self, datacube: np.ndarray, fista: bool, clip, lam_mu, device: int = 0, chunk_rows: int = 16,
                  k: int = 32, max_iters: int = 1, pin: bool = True, global_rows: int = None, row0: int = 0,
-                 group=None, world: int = 1, rank: int = 0, bc_mode: int = 2, reference: np.ndarray = None):
+                 group=None, world: int = 1, rank: int = 0, bc_mode: int = 2, reference: np.ndarray = None,
+                 exact_wrap: bool = False):
         """Slab mode (`world` > 1): `datacube` holds this rank's own rows [row0, row0+rows) of a cube with
         `global_rows` rows.  The host arrays then carry up to k extra rows per interior side, refreshed from the
         neighbouring ranks before every pass; at those artificial faces the wavefront gives up one row per
@@ -178,6 +179,13 @@ class WavefrontRunner:
         self.up = torch.cuda.Stream(device=dev)
         self.down = torch.cuda.Stream(device=dev)
         self._args = _lib.IterArgs()
+        # Jia-Zhao, `exact_wrap` (single process): the sweeps at the cube's top face form the wrapped axis-0 accumulator
+        # from the recon of global row 0 AT THEIR OWN LEVEL (TVDN_EDGE_WRAP) instead of taking it as zero, which it is
+        # only while row 0 is finite (engine.py, "Non-finite data").  Row 0 of every level is computed at the start of a
+        # pass and has long left its window when the top is reached, so one plane per level is kept aside.
+        self.row0 = None
+        if exact_wrap and self.world == 1 and not self.periodic:
+            self.row0 = [torch.empty(tuple(plane), dtype=tdt, device=dev) for _ in range(K + 1)]
 
     def _wrap_rows(self, arrays, depth):
         """Periodic BC: the halo rows below the first / above the last own row are the cube's own other end."""
@@ -212,6 +220,9 @@ class WavefrontRunner:
         A.sweep_lo, A.sweep_hi = a - ref, b - ref
         A.lo_mode = _lib.EDGE_BC
         A.hi_mode = _lib.EDGE_ZERO if at_top else _lib.EDGE_BC
+        A.wrap_recon = None
+        if at_top and self.row0 is not None:
+            A.hi_mode, A.wrap_recon = _lib.EDGE_WRAP, self.row0[j].data_ptr()
         A.bc_mode = self.bc
         A.mode = mode
         A.tk, A.tk_prev = float(tk or 0.0), float(tk_prev)
@@ -327,6 +338,8 @@ class WavefrontRunner:
                 main.wait_event(in_ready[c % 2])
                 self.Ow.rows(u0, u1).copy_(box[0][:n])
                 self.Rw[0].rows(u0, u1).copy_(box[1][:n])
+                if self.row0 is not None and u0 == 0:
+                    self.row0[0].copy_(self.Rw[0].rows(0, 1)[0])
                 i = 2
                 for q in range(nd):
                     self.Aw[1][q].rows(u0, u1).copy_(box[i][:n])          # level 0: d_k (or b)
@@ -357,6 +370,8 @@ class WavefrontRunner:
                 for x0, x1, slot in ((a, min(b, g0), discard), (max(a, g0), min(b, g1), slot0 + j), (max(a, g1), b, discard)):
                     if x0 < x1:
                         self._launch(j, x0, x1, ratios[j], tkp[j], modes[j], slot)
+                        if self.row0 is not None and x0 == 0:
+                            self.row0[j + 1].copy_(self.Rw[j + 1].rows(0, 1)[0])
                         if self.Fw is not None and slot != discard:
                             self._sse(self.Fw.rows(x0, x1), self.Rw[j + 1].rows(x0, x1), slot + 1)
                 self.Rw[j + 1].top = b

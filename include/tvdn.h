@@ -119,13 +119,19 @@ int tvdn_sum_square_error(tvdn_ctx *ctx, int dtype, int ndim, const int64_t *sha
  *                            global first row (single-slab case): wrap onto it
  *            TVDN_EDGE_HALO  row row_hi is a halo row; its axis-0 accumulator is kept locally
  *            TVDN_EDGE_ZERO  row_hi-1 is the global last row of a multi-slab Jia-Zhao run: the
- *                            wrapped axis-0 accumulator is identically zero
+ *                            wrapped axis-0 accumulator is identically zero (true while the cube's
+ *                            first row is finite)
+ *            TVDN_EDGE_WRAP  the same place, exact for any data: `wrap_recon` (or, when NULL, row row_hi
+ *                            of recon_in) holds the CURRENT recon of global row 0, from which the wrapped
+ *                            accumulator is formed as upstream forms it -- zero, or NaN where row 0 is
+ *                            Inf/NaN (anisotropic.pyx:65-73: clip((a[0]-a[0]) + b[0]))
  * sums_out (device, 3 doubles): [0] sum over all axes of |b_new| (b_norm), [1] sum |recon_new -
  * recon_old|, [2] sum |recon_old|, over the slab's own rows only.
  * ---------------------------------------------------------------------------------------- */
 #define TVDN_EDGE_BC 0
 #define TVDN_EDGE_HALO 1
 #define TVDN_EDGE_ZERO 2
+#define TVDN_EDGE_WRAP 3
 
 #define TVDN_ITER_PLAIN 0
 #define TVDN_ITER_FISTA 1
@@ -162,6 +168,7 @@ typedef struct tvdn_iter_args {
     int64_t sweep_hi;
     int32_t accumulate;
     int32_t reserved;
+    const void *wrap_recon; /* TVDN_EDGE_WRAP: one plane, current recon of global row 0 (NULL: row row_hi) */
 } tvdn_iter_args;
 
 int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *args, double *sums_out, void *stream);
