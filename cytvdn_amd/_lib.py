@@ -28,7 +28,7 @@ EXPORTS = (
     "tvdn_abi_version", "tvdn_last_error", "tvdn_device_count", "tvdn_ctx_create", "tvdn_ctx_destroy",
     "tvdn_ctx_timing_enable", "tvdn_ctx_timing_read",
     "tvdn_accumulator_update", "tvdn_datacube_update", "tvdn_sum_square_error", "tvdn_iterate_fused",
-    "tvdn_synth_fill", "tvdn_run", "tvdn_copy_to_device", "tvdn_copy_to_host",
+    "tvdn_synth_fill", "tvdn_run", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many",
 )
 
 
@@ -48,6 +48,15 @@ class IterArgs(C.Structure):
         ("dprev_in", C.c_void_p * 4),
         ("sweep_lo", C.c_int64), ("sweep_hi", C.c_int64), ("accumulate", C.c_int32), ("reserved", C.c_int32),
         ("wrap_recon", C.c_void_p),
+    ]
+
+
+class ManyArgs(C.Structure):
+    """struct tvdn_many_args (include/tvdn.h)."""
+    _fields_ = [
+        ("base", IterArgs), ("recon", C.c_void_p * 2), ("S", (C.c_void_p * 3) * 4),
+        ("cur", C.c_int32), ("i_d", C.c_int32), ("i_prev", C.c_int32), ("i_out", C.c_int32),
+        ("i_b", C.c_int32), ("i_bout", C.c_int32), ("d_form", C.c_int32), ("tk_prev", C.c_double),
     ]
 
 
@@ -102,6 +111,8 @@ def lib():
                                         C.c_void_p]
     L.tvdn_iterate_fused.argtypes = [C.c_void_p, C.POINTER(IterArgs), C.c_void_p, C.c_void_p]
     L.tvdn_run.argtypes = [C.POINTER(RunArgs)]
+    L.tvdn_iterate_many.argtypes = [C.c_void_p, C.POINTER(ManyArgs), C.c_int32, C.POINTER(C.c_double), C.c_int32,
+                                    C.c_void_p, C.c_void_p]
     L.tvdn_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     L.tvdn_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     L.tvdn_synth_fill.argtypes = [C.c_int, C.c_int, i64p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]

@@ -513,3 +513,52 @@ extern "C" int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *a, double
     return a->dtype == TVDN_F32 ? iterate_fused_impl<float>(ctx, a, sums_out, (hipStream_t)stream)
                                 : iterate_fused_impl<double>(ctx, a, sums_out, (hipStream_t)stream);
 }
+
+// Many iterations behind one call: the loop of cyTVDN/cyTVDN.py:148-242 for a state that already lives in HBM.  The
+// host side of an iteration -- which of the rotating arrays plays which role, tk, the sums slot -- is a few dozen
+// instructions here against ~25 us of Python per iteration, which is what bounds small cubes (a 1 M-voxel sweep
+// takes ~15 us); the launches are the same tvdn_iterate_fused launches, so the bits are the same.
+extern "C" int tvdn_iterate_many(tvdn_ctx *ctx, tvdn_many_args *st, int32_t n_fista, const double *ratios, int32_t n_plain,
+                                 double *sums_out, void *stream)
+{
+    TVDN_REQUIRE(ctx && st && sums_out, "NULL argument");
+    TVDN_REQUIRE(n_fista >= 0 && n_plain >= 0, "negative iteration count");
+    TVDN_REQUIRE(n_fista == 0 || ratios != nullptr, "ratios is NULL");
+    TVDN_REQUIRE(n_fista == 0 || st->d_form, "a FISTA iteration cannot follow an unaccelerated one (nor does it upstream)");
+    const int nd = st->base.ndim;
+    TVDN_REQUIRE(nd == 3 || nd == 4, "ndim must be 3 or 4, got %d", nd);
+    tvdn_iter_args it = st->base;
+    for (int i = 0; i < n_fista + n_plain; ++i) {
+        const bool use_fista = i < n_fista;
+        it.recon_in = st->recon[st->cur];
+        it.recon_out = st->recon[st->cur ^ 1];
+        it.tk = use_fista ? ratios[i] : 0.0;
+        it.tk_prev = st->tk_prev;
+        for (int q = 0; q < nd; ++q) {
+            it.b_in[q] = it.d_in[q] = it.dprev_in[q] = nullptr;
+            it.b_out[q] = it.d_out[q] = nullptr;
+            if (use_fista) {
+                it.d_in[q] = st->S[q][st->i_d]; it.dprev_in[q] = st->S[q][st->i_prev]; it.d_out[q] = st->S[q][st->i_out];
+            } else if (st->d_form) {
+                it.d_in[q] = st->S[q][st->i_d]; it.dprev_in[q] = st->S[q][st->i_prev]; it.b_out[q] = st->S[q][st->i_out];
+            } else {
+                it.b_in[q] = st->S[q][st->i_b]; it.b_out[q] = st->S[q][st->i_bout];
+            }
+        }
+        it.mode = use_fista ? TVDN_ITER_FISTA_D : (st->d_form ? TVDN_ITER_FISTA_D_TO_PLAIN : TVDN_ITER_PLAIN);
+        it.sweep_lo = it.sweep_hi = 0;
+        it.accumulate = 0;
+        const int rc = tvdn_iterate_fused(ctx, &it, sums_out + 3 * (size_t)i, stream);
+        if (rc) return rc;
+        st->cur ^= 1;
+        if (use_fista) {
+            const int t = st->i_prev; st->i_prev = st->i_d; st->i_d = st->i_out; st->i_out = t;
+            st->tk_prev = ratios[i];
+        } else if (st->d_form) {
+            st->i_b = st->i_out; st->i_bout = st->i_prev; st->d_form = 0;
+        } else {
+            const int t = st->i_b; st->i_b = st->i_bout; st->i_bout = t;
+        }
+    }
+    return TVDN_OK;
+}

@@ -143,8 +143,14 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
                 return True
         return False
 
+    # nothing to do between iterations (no MSE trace, no stopping rule, no progress bar): the loop runs natively
+    watched = calculate_MSE or stopping_relative_change is not None or (_tqdm is not None and not quiet)
+
     def phase(n, tk_phase, desc):
         if n <= 0:
+            return
+        if not watched:
+            runner.run(n if tk_phase else 0, 0 if tk_phase else n, None)
             return
         if _tqdm is not None:
             bars.append(_tqdm(total=n, desc=desc, leave=not quiet))

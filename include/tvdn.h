@@ -174,6 +174,30 @@ typedef struct tvdn_iter_args {
 int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *args, double *sums_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Many iterations on a state that already lives in HBM (compact d-rotation form): the loop of
+ * cyTVDN/cyTVDN.py:148-242 without a host language round trip per iteration.  `base` carries what stays
+ * fixed (dtype, shape, own rows, edge modes, bc_mode, clip, lambda_mu, orig, wrap_recon; its state
+ * pointers, mode, tk and sweep fields are ignored); recon[] and S[axis][0..2] are the arrays the
+ * iterations rotate through, and cur / i_* / d_form / tk_prev say which plays which role -- read on
+ * entry, updated on return, so calls can be chained.  n_fista iterations with momentum ratios[i]
+ * ((tk-1)/tk_new of cyTVDN.py:153-156, float64 on the host), then n_plain unaccelerated ones; iteration i
+ * writes its three sums to sums_out[3*i .. 3*i+2] (device).  Asynchronous like tvdn_iterate_fused.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct tvdn_many_args {
+    tvdn_iter_args base;
+    void *recon[2];      /* recon[cur] is current                                              */
+    void *S[4][3];       /* per axis: d_k / d_k-1 / next (d-form) or b / next (b-form)          */
+    int32_t cur;
+    int32_t i_d, i_prev, i_out; /* roles inside S[axis][] while the state is in d-form          */
+    int32_t i_b, i_bout;        /* ... in b-form                                                */
+    int32_t d_form;             /* 1: (d_k, d_k-1) pairs; 0: b                                  */
+    double tk_prev;             /* momentum ratio of the last FISTA iteration run               */
+} tvdn_many_args;
+
+int tvdn_iterate_many(tvdn_ctx *ctx, tvdn_many_args *state, int32_t n_fista, const double *ratios,
+                      int32_t n_plain, double *sums_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Whole-loop entry point on HOST arrays: what denoise4D / denoise3D do between their argument
  * checks and their return (cyTVDN/cyTVDN.py:122-247, :345-435), for callers that are not Python.
  * Copies `data` to HBM once (pinned multi-lane staging, tvdn_copy_to_device), runs n_fista FISTA

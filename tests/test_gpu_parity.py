@@ -408,3 +408,24 @@ def test_c_abi_error_paths_and_timing(tv):
     ms, n = C.c_double(), C.c_int64()
     assert L.tvdn_ctx_timing_read(ctx, C.byref(ms), C.byref(n)) == 0 and n.value == 1 and ms.value > 0
     assert L.tvdn_ctx_timing_enable(ctx, 0) == 0
+
+
+@pytest.mark.parametrize("shape,dtype,its,fista", [
+    ((6, 5, 8, 12), np.float32, 9, True), ((7, 6, 16), np.float64, [4, 3], True), ((5, 3, 7, 9), np.float32, 6, False),
+    ((9, 4, 4, 8), np.float64, [0, 5], True), ((9, 4, 4, 8), np.float32, [5, 0], True),
+])
+def test_native_loop_equals_python_loop(tv, monkeypatch, shape, dtype, its, fista):
+    """tvdn_iterate_many (the whole schedule behind one library call, used whenever nothing watches the iterations)
+    against the per-iteration Python loop: same launches, so the same bits, traces included."""
+    from cytvdn_amd import synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=43, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    fn = tv.denoise4D if nd == 4 else tv.denoise3D
+    monkeypatch.setenv("TVDN_LOOP", "native")
+    a = fn(x, mu, its, FISTA=fista, quiet=True)
+    monkeypatch.setenv("TVDN_LOOP", "python")
+    b = fn(x, mu, its, FISTA=fista, quiet=True)
+    for u, v in zip(a, b):
+        assert bits_equal(u, v)
