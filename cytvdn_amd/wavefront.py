@@ -18,6 +18,7 @@ fall back to the trapezoid engine with k = 1).
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -34,6 +35,9 @@ def _write_or_copy(own: np.ndarray, out):
     for a in range(0, own.shape[0], step):
         out.write_rows(a, own[a:a + step])
     return None
+
+
+IO_STREAMS = 1      # HIP streams per PCIe direction of the wavefront engine (TVDN_IO_STREAMS overrides)
 
 
 class _Window:
@@ -176,8 +180,12 @@ class WavefrontRunner:
         n_out = 1 + 2 * self.nd
         self.inbox = [[torch.empty((self.R,) + tuple(plane), dtype=tdt, device=dev) for _ in range(n_in)] for _ in range(2)]
         self.outbox = [[torch.empty((self.R,) + tuple(plane), dtype=tdt, device=dev) for _ in range(n_out)] for _ in range(2)]
-        self.up = torch.cuda.Stream(device=dev)
-        self.down = torch.cuda.Stream(device=dev)
+        # HIP streams per PCIe direction.  One each is best: up and down together already hold the link at 32 + 29 GB/s
+        # (256 MiB planes, 32x1024x256x256, 2 rows x k = 24: 19.1 Gvoxel-iters/s with 1 stream per direction, 18.4
+        # with 2, 13.9 with 4); the knob stays for other hosts.
+        n_io = max(1, int(os.environ.get("TVDN_IO_STREAMS", str(IO_STREAMS))))
+        self.ups = [torch.cuda.Stream(device=dev) for _ in range(n_io)]
+        self.downs = [torch.cuda.Stream(device=dev) for _ in range(n_io)]
         self._args = _lib.IterArgs()
         # Jia-Zhao, `exact_wrap` (single process): the sweeps at the cube's top face form the wrapped axis-0 accumulator
         # from the recon of global row 0 AT THEIR OWN LEVEL (TVDN_EDGE_WRAP) instead of taking it as zero, which it is
@@ -299,24 +307,27 @@ class WavefrontRunner:
             if self._swap is not None and u1 > g1:
                 self._swap.finish()                          # this chunk reads the neighbour's rows above my slab
             box = self.inbox[c % 2]
-            with torch.cuda.stream(self.up):
-                if in_free[c % 2] is not None:
-                    self.up.wait_event(in_free[c % 2])
-                n = u1 - u0
-                box[0][:n].copy_(self.orig_h[u0 - hb:u1 - hb], non_blocking=True)
-                box[1][:n].copy_(self.recon_h[old][u0 - hb:u1 - hb], non_blocking=True)
-                i = 2
-                for q in range(nd):
-                    for s in range(n_in_state):
-                        box[i][:n].copy_(self.state_h[old][q][s][u0 - hb:u1 - hb], non_blocking=True)
-                        i += 1
-                if self.ref_h is not None:
-                    box[-1][:n].copy_(self.ref_h[u0 - hb:u1 - hb], non_blocking=True)
+            n = u1 - u0
+            pairs = [(box[0], self.orig_h), (box[1], self.recon_h[old])]
+            i = 2
+            for q in range(nd):
+                for s in range(n_in_state):
+                    pairs.append((box[i], self.state_h[old][q][s]))
                     i += 1
-                self.bytes_h2d += i * n * self.row_bytes
-                ev = torch.cuda.Event()
-                ev.record(self.up)
-                in_ready[c % 2] = ev
+            if self.ref_h is not None:
+                pairs.append((box[-1], self.ref_h))
+            evs = []
+            for si, st in enumerate(self.ups):
+                with torch.cuda.stream(st):
+                    if in_free[c % 2] is not None:
+                        st.wait_event(in_free[c % 2])
+                    for dst, src in pairs[si::len(self.ups)]:
+                        dst[:n].copy_(src[u0 - hb:u1 - hb], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    evs.append(ev)
+            self.bytes_h2d += len(pairs) * n * self.row_bytes
+            in_ready[c % 2] = evs
 
         upload(0)
         for c in range(n_chunks):
@@ -335,7 +346,8 @@ class WavefrontRunner:
             if u0 < u1:
                 n = u1 - u0
                 box = self.inbox[c % 2]
-                main.wait_event(in_ready[c % 2])
+                for ev in in_ready[c % 2]:
+                    main.wait_event(ev)
                 self.Ow.rows(u0, u1).copy_(box[0][:n])
                 self.Rw[0].rows(u0, u1).copy_(box[1][:n])
                 if self.row0 is not None and u0 == 0:
@@ -383,8 +395,8 @@ class WavefrontRunner:
             if a < b:
                 n = b - a
                 box = self.outbox[c % 2]
-                if out_free[c % 2] is not None:
-                    main.wait_event(out_free[c % 2])
+                for ev in out_free[c % 2] or ():
+                    main.wait_event(ev)
                 box[0][:n].copy_(self.Rw[kk].rows(a, b))
                 i = 1
                 for q in range(nd):
@@ -395,19 +407,25 @@ class WavefrontRunner:
                         i += 1
                 ev = torch.cuda.Event()
                 ev.record(main)
-                with torch.cuda.stream(self.down):
-                    self.down.wait_event(ev)
-                    self.recon_h[new][a - hb:b - hb].copy_(box[0][:n], non_blocking=True)
-                    i = 1
-                    for q in range(nd):
-                        for s in range(n_out_state):
-                            self.state_h[new][q][s][a - hb:b - hb].copy_(box[i][:n], non_blocking=True)
-                            i += 1
-                    self.bytes_d2h += i * n * self.row_bytes
-                    ev2 = torch.cuda.Event()
-                    ev2.record(self.down)
-                    out_free[c % 2] = ev2
-        self.down.synchronize()
+                pairs = [(self.recon_h[new], box[0])]
+                i = 1
+                for q in range(nd):
+                    for s in range(n_out_state):
+                        pairs.append((self.state_h[new][q][s], box[i]))
+                        i += 1
+                evs = []
+                for si, st in enumerate(self.downs):
+                    with torch.cuda.stream(st):
+                        st.wait_event(ev)
+                        for dst, src in pairs[si::len(self.downs)]:
+                            dst[a - hb:b - hb].copy_(src[:n], non_blocking=True)
+                        ev2 = torch.cuda.Event()
+                        ev2.record(st)
+                        evs.append(ev2)
+                self.bytes_d2h += len(pairs) * n * self.row_bytes
+                out_free[c % 2] = evs
+        for st in self.downs:
+            st.synchronize()
         main.synchronize()
         if self._swap is not None:
             self._swap.finish()
