@@ -71,3 +71,82 @@ def test_one_pass_kernels_random(oracle, shape, f64, bc, fista, seed, data):
         getattr(tv, f"datacube_update_{nd}D")(orig, recon, *bs, lm, BC_mode=bc)
         oracle.recon_update(orig, r2, bs, lm, bc)
         assert bits_equal(recon, r2)
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(rows=st.integers(2, 14), plane=st.one_of(st.tuples(st.integers(1, 4), st.integers(1, 5), st.sampled_from([1, 3, 4, 8, 12])),
+                                                st.tuples(st.integers(1, 6), st.sampled_from([2, 4, 7, 8, 16]))),
+       f64=st.booleans(), bc=st.sampled_from([0, 2]), sched=st.sampled_from(["fista", "plain", "hybrid"]),
+       seed=st.integers(0, 2 ** 31 - 1), world=st.integers(2, 5), split=st.booleans(), bad_row0=st.booleans(),
+       uneven=st.booleans())
+def test_slab_layouts_random(oracle, rows, plane, f64, bc, sched, seed, world, split, bad_row0, uneven):
+    """Random cubes cut into random slab layouts on one GPU (balanced or explicit uneven bounds, whole sweeps or
+    edge-blocks-first, chain or ring, with the exact Jia-Zhao wrap row when the first row is not finite): the gathered
+    result must equal the oracle's single-cube result bit for bit, and the summed scalars its f64 yardsticks."""
+    from cytvdn_amd.engine import HipBackend, LocalSlabs, SlabLayout
+    world = min(world, rows)
+    shape = (rows,) + tuple(plane)
+    dt = np.dtype(np.float64 if f64 else np.float32)
+    nd = len(shape)
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(shape) * 2 + rng.poisson(3.0, shape)).astype(dt)
+    wrap_row = False
+    if bad_row0 and bc == 2:
+        x[(0,) + tuple(int(rng.integers(s)) for s in shape[1:])] = np.inf
+        wrap_row = True
+    mu = np.array([1.0, 0.7, 0.5, 1.3][:nd], dt)
+    lam = mu / dt.type(32.0 if nd == 4 else 16.0)
+    n_f, n_p = {"fista": (5, 0), "plain": (0, 4), "hybrid": (3, 2)}[sched]
+    bounds = None
+    if uneven and rows > world:
+        cuts = sorted(rng.choice(np.arange(1, rows), size=world - 1, replace=False).tolist())
+        bounds = tuple([0] + cuts + [rows])
+    bes = []
+    for r in range(world):
+        lay = SlabLayout(shape, r, world, bc, bounds=bounds, wrap_row=wrap_row)
+        be = HipBackend(lay, dt, n_f > 0, device=0, max_iters=n_f + n_p)
+        be.set_params(1.0 / lam, (lam / mu).astype(dt))
+        be.set_input(x[lay.local_rows_global()])
+        bes.append(be)
+    grp = LocalSlabs(bes, split_sweeps=split)
+    grp.run(n_f, n_p)
+    its = [n_f, n_p] if (n_f and n_p) else (n_f or n_p)
+    ref = oracle.denoise(x, mu, its, n_f > 0, BC_mode=bc)
+    assert bits_equal(grp.gather_recon().cpu().numpy(), ref["recon"])
+    if not wrap_row:
+        s = grp.global_sums().cpu().numpy()
+        np.testing.assert_allclose(s[:, 0], ref["b_norm64"], rtol=1e-12)
+        np.testing.assert_allclose(s[:, 1], ref["delta64"], rtol=1e-12)
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(rows=st.integers(2, 12), plane=st.tuples(st.integers(1, 4), st.integers(1, 5), st.sampled_from([1, 4, 8, 12])),
+       f64=st.booleans(), bc=st.sampled_from([0, 2]), n_f=st.integers(0, 5), n_p=st.integers(0, 4),
+       seed=st.integers(0, 2 ** 31 - 1), slabs=st.integers(1, 5), bad_row0=st.booleans())
+def test_tvdn_run_device_list_random(oracle, rows, plane, f64, bc, n_f, n_p, seed, slabs, bad_row0):
+    """The C whole-loop entry with a random number of slabs on device 0 against the oracle."""
+    import ctypes as C
+    from cytvdn_amd import _lib
+    if n_f + n_p == 0:
+        n_f = 1
+    slabs = min(slabs, rows)
+    shape = (rows,) + tuple(plane)
+    dt = np.dtype(np.float64 if f64 else np.float32)
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(shape) * 2 + rng.poisson(3.0, shape)).astype(dt)
+    if bad_row0:
+        x[(0,) + tuple(int(rng.integers(s)) for s in shape[1:])] = np.nan
+    mu = np.array([1.0, 0.7, 0.5, 1.3], dt)
+    lam = mu / dt.type(32.0)
+    a = _lib.RunArgs(dtype=_lib.dtype_code(dt), ndim=4, bc_mode=bc, device=0, n_fista=n_f, n_plain=n_p, n_devices=slabs)
+    for i, s in enumerate(shape):
+        a.shape[i] = s
+    for q in range(4):
+        a.clip[q] = float((1.0 / lam)[q])
+        a.lambda_mu[q] = float((lam / mu).astype(dt)[q])
+    recon, sums = np.empty_like(x), np.zeros((n_f + n_p, 3))
+    a.data, a.recon_out, a.sums_out = x.ctypes.data, recon.ctypes.data, sums.ctypes.data
+    _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+    its = [n_f, n_p] if (n_f and n_p) else (n_f or n_p)
+    ref = oracle.denoise(x, mu, its, n_f > 0, BC_mode=bc)
+    assert bits_equal(recon, ref["recon"])
