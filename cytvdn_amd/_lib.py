@@ -28,7 +28,7 @@ EXPORTS = (
     "tvdn_abi_version", "tvdn_last_error", "tvdn_device_count", "tvdn_ctx_create", "tvdn_ctx_destroy",
     "tvdn_ctx_timing_enable", "tvdn_ctx_timing_read",
     "tvdn_accumulator_update", "tvdn_datacube_update", "tvdn_sum_square_error", "tvdn_iterate_fused",
-    "tvdn_synth_fill", "tvdn_run", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many",
+    "tvdn_synth_fill", "tvdn_run", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many", "tvdn_plan",
 )
 
 
@@ -58,6 +58,12 @@ class ManyArgs(C.Structure):
         ("cur", C.c_int32), ("i_d", C.c_int32), ("i_prev", C.c_int32), ("i_out", C.c_int32),
         ("i_b", C.c_int32), ("i_bout", C.c_int32), ("d_form", C.c_int32), ("tk_prev", C.c_double),
     ]
+
+
+class PlanOut(C.Structure):
+    """struct tvdn_plan_out (include/tvdn.h)."""
+    _fields_ = [("arrays", C.c_int64), ("bytes_per_slab", C.c_int64), ("free_bytes", C.c_int64),
+                ("fits", C.c_int32), ("min_slabs", C.c_int32)]
 
 
 class RunArgs(C.Structure):
@@ -111,6 +117,7 @@ def lib():
                                         C.c_void_p]
     L.tvdn_iterate_fused.argtypes = [C.c_void_p, C.POINTER(IterArgs), C.c_void_p, C.c_void_p]
     L.tvdn_run.argtypes = [C.POINTER(RunArgs)]
+    L.tvdn_plan.argtypes = [C.c_int, C.c_int, i64p, C.c_int, C.c_int, C.c_int, C.POINTER(PlanOut)]
     L.tvdn_iterate_many.argtypes = [C.c_void_p, C.POINTER(ManyArgs), C.c_int32, C.POINTER(C.c_double), C.c_int32,
                                     C.c_void_p, C.c_void_p]
     L.tvdn_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]

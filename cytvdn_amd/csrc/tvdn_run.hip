@@ -367,6 +367,39 @@ static int run_impl(const tvdn_run_args *a)
 
 }  // namespace tvdn
 
+// The HBM arithmetic of check_memory (cyTVDN.py:438-467) for this engine: arrays of the compact state, bytes of the
+// tallest slab of an n-way split with its halo rows, what the device has free, and the fewest slabs that would fit.
+extern "C" int tvdn_plan(int dtype, int ndim, const int64_t *shape, int fista, int n_slabs, int device, tvdn_plan_out *out)
+{
+    TVDN_REQUIRE(out != nullptr && shape != nullptr, "NULL argument");
+    TVDN_REQUIRE(dtype == TVDN_F32 || dtype == TVDN_F64, "bad dtype %d", dtype);
+    TVDN_REQUIRE(ndim == 3 || ndim == 4, "ndim must be 3 or 4, got %d", ndim);
+    for (int i = 0; i < ndim; ++i) TVDN_REQUIRE(shape[i] >= 1, "shape[%d] must be >= 1", i);
+    TVDN_REQUIRE(n_slabs >= 1 && n_slabs <= shape[0], "n_slabs must be 1..shape[0]");
+    const int64_t item = dtype == TVDN_F32 ? 4 : 8;
+    int64_t plane = item;
+    for (int i = 1; i < ndim; ++i) plane *= shape[i];
+    const int64_t arrays = 3 + (int64_t)ndim * (fista ? 3 : 2);
+    auto slab_bytes = [&](int64_t s) {
+        const int64_t rows = (shape[0] + s - 1) / s + (s > 1 ? 2 : 0);
+        return arrays * (rows * plane + 4096 + 255);
+    };
+    size_t free_b = 0, total_b = 0;
+    TVDN_HIP(hipSetDevice(device));
+    TVDN_HIP(hipMemGetInfo(&free_b, &total_b));
+    out->arrays = arrays;
+    out->bytes_per_slab = slab_bytes(n_slabs);
+    out->free_bytes = (int64_t)free_b;
+    out->fits = out->bytes_per_slab <= (int64_t)(0.9 * (double)free_b) ? 1 : 0;
+    out->min_slabs = 0;
+    for (int64_t s = 1; s <= shape[0]; ++s)
+        if (slab_bytes(s) <= (int64_t)(0.9 * (double)free_b)) {
+            out->min_slabs = (int32_t)s;
+            break;
+        }
+    return TVDN_OK;
+}
+
 extern "C" int tvdn_run(const tvdn_run_args *a)
 {
     TVDN_REQUIRE(a != nullptr, "args is NULL");
@@ -392,5 +425,21 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
         return TVDN_ERR_UNSUPPORTED;
     }
     TVDN_REQUIRE(a->bc_mode == 0 || a->bc_mode == 2, "bc_mode must be 0 or 2, got %d", a->bc_mode);
+    {   // say clearly when the slabs cannot fit, instead of failing somewhere inside hipMalloc
+        const int world = a->n_devices > 0 ? a->n_devices : 1;
+        TVDN_REQUIRE(a->shape[0] >= world, "axis 0 (%lld rows) cannot be cut into %d slabs", (long long)a->shape[0], world);
+        tvdn_plan_out pl;
+        const int rc = tvdn_plan(a->dtype, a->ndim, a->shape, a->n_fista > 0, world, a->n_devices > 0 ? a->devices[0] : a->device, &pl);
+        if (rc) return rc;
+        int same = 0;  // slabs sharing the first device share its HBM
+        for (int i = 0; i < world; ++i) same += (a->n_devices == 0 || a->devices[i] == a->devices[0]) ? 1 : 0;
+        if (pl.bytes_per_slab * same > pl.free_bytes) {
+            tvdn::set_error("state of %lld bytes per slab x %d slab(s) on device %d exceeds its %lld free bytes of HBM: use more "
+                            "devices (fewest slabs that fit one each: %d) or the streamed engines (cytvdn_amd.plan_run)",
+                            (long long)pl.bytes_per_slab, same, a->n_devices > 0 ? a->devices[0] : a->device,
+                            (long long)pl.free_bytes, pl.min_slabs);
+            return TVDN_ERR_UNSUPPORTED;
+        }
+    }
     return tvdn::run_impl(a);
 }

@@ -245,6 +245,22 @@ typedef struct tvdn_run_args {
 
 int tvdn_run(const tvdn_run_args *args);
 
+/* The HBM arithmetic of the reference's check_memory (cyTVDN/cyTVDN.py:438-467) for this engine: how many
+ * arrays the compact state has, how many bytes the tallest slab of an `n_slabs`-way split of axis 0 needs
+ * (halo rows and array stagger included), what `device` has free, whether that fits in 90 % of it, and the
+ * fewest slabs that would fit one per device of that size (0: none).  tvdn_run consults it and returns
+ * TVDN_ERR_UNSUPPORTED with this arithmetic in the message when its slabs cannot fit. */
+typedef struct tvdn_plan_out {
+    int64_t arrays;
+    int64_t bytes_per_slab;
+    int64_t free_bytes;
+    int32_t fits;
+    int32_t min_slabs;
+} tvdn_plan_out;
+
+int tvdn_plan(int dtype, int ndim, const int64_t *shape, int fista, int n_slabs, int device,
+              tvdn_plan_out *out);
+
 /* ------------------------------------------------------------------------------------------
  * Whole-array transfers between ordinary (pageable) host memory and HBM at PCIe speed: what
  * `recon = datacube.copy()` on the way in (cyTVDN/cyTVDN.py:145) and the returned array on the way
