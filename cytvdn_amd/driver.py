@@ -85,6 +85,13 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
         kind = "FISTA Accelerated" if FISTA else "Unaccelerated"
         print(f"{kind} TV denoising will keep {plan['arrays']} arrays = {_fmt_bytes(plan['bytes'])} in HBM...", flush=True)
 
+    if isinstance(device, (list, tuple)):
+        if len(device) > 1:
+            if hasattr(datacube, "read_rows") or out is not None:
+                raise NotImplementedError("file-to-file runs use one device")
+            return _run_device_list([int(d) for d in device], datacube, lambdaInv, lam_mu, n_fista, n_plain,
+                                    stopping_relative_change, reference_data, BC_mode, quiet)
+        device = int(device[0]) if len(device) else None
     if device is None:
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
     # engine choice (cytvdn_amd/planner.py): in-core when the state fits in the free HBM (or in TVDN_HBM_LIMIT),
@@ -185,6 +192,52 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
     return recon, b_norm, delta_recon
 
 
+def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, stop, reference_data, BC_mode, quiet):
+    """`device=[0, 1, ...]`: one slab of axis 0 per listed GPU inside THIS process -- the library's whole-loop entry
+    (tvdn_run, csrc/tvdn_run.hip): state in HBM of each device, halo rows by peer copies over xGMI under the interior
+    sweeps, global sums, global stopping rule.  No torchrun, no RCCL; every slab must fit its device (tvdn_plan says so
+    when not).  The process-per-GPU form over RCCL is cytvdn_amd.distributed.denoise_slabs."""
+    import ctypes as C
+    from . import _lib
+    dtype = datacube.dtype
+    nd = datacube.ndim
+    n = n_fista + n_plain
+    if not quiet:
+        print(f"Cutting axis 0 into {len(devices)} slabs on devices {devices} (one process, peer copies)", flush=True)
+    a = _lib.RunArgs(dtype=_lib.dtype_code(dtype), ndim=nd, bc_mode=int(BC_mode), device=devices[0], n_fista=n_fista,
+                     n_plain=n_plain, use_stop=int(stop is not None), stop=float(stop or 0.0), n_devices=len(devices))
+    if len(devices) > len(a.devices):
+        raise ValueError(f"at most {len(a.devices)} devices")
+    for i, d in enumerate(devices):
+        a.devices[i] = d
+    for i, s in enumerate(datacube.shape):
+        a.shape[i] = int(s)
+    for q in range(nd):
+        a.clip[q] = float(lambdaInv[q])
+        a.lambda_mu[q] = float(lam_mu[q])
+    x = np.ascontiguousarray(datacube)
+    recon = np.empty_like(x)
+    sums = np.zeros((max(n, 1), 3))
+    mse = np.zeros(n + 1)
+    ran = C.c_int32(0)
+    a.data, a.recon_out, a.sums_out = x.ctypes.data, recon.ctypes.data, sums.ctypes.data
+    if reference_data is not None:
+        ref = np.ascontiguousarray(reference_data)
+        a.reference, a.mse_out = ref.ctypes.data, mse.ctypes.data
+    a.iters_run = C.addressof(ran)
+    _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+    sums = sums[:n]
+    done = sums[:, 2] != 0                      # slots of iterations that never ran keep the reference's zero tail
+    b_norm = np.where(done, sums[:, 0], 0.0).astype(dtype)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        delta_recon = np.where(done, sums[:, 1].astype(dtype) / sums[:, 2].astype(dtype), dtype.type(0)).astype(dtype)
+    if stop is not None and not quiet and n_plain and not done[-1]:
+        print(f"Stopping condition reached after {int(np.nonzero(done)[0][-1])} iterations, stopping.")
+    if reference_data is not None:
+        return recon, b_norm, delta_recon, mse.astype(dtype)
+    return recon, b_norm, delta_recon
+
+
 def _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device, BC_mode=2,
                    reference_data=None, out=None, exact_wrap=False):
     """Host-resident state, wavefront schedule (cytvdn_amd/wavefront.py): anything but a stopping rule."""
@@ -255,12 +308,13 @@ def denoise4D(
     BC_mode: int = 2,
     lam: Optional[np.ndarray] = None,
     quiet: bool = False,
-    device: Optional[int] = None,
+    device=None,
 ) -> Tuple[np.ndarray, np.ndarray, np.ndarray, Optional[np.ndarray]]:
-    """Proximal anisotropic TV denoising of a 4-D datacube on one MI355X.
+    """Proximal anisotropic TV denoising of a 4-D datacube on one MI355X (or on several: `device=[0, 1, ...]`).
 
     Arguments, defaults and return value are those of the reference's denoise4D
-    (cyTVDN/cyTVDN.py:19-60); `device` (keyword only in practice) selects the GPU.
+    (cyTVDN/cyTVDN.py:19-60); `device` (keyword only in practice) selects the GPU -- or, given a list of
+    GPUs, cuts axis 0 into one slab per entry inside this process (peer copies over xGMI; `_run_device_list`).
 
     datacube  C-contiguous 4-D float32/float64 array (never modified)
     mu        4-element array, TV weight per axis, same dtype
@@ -303,7 +357,7 @@ def denoise4D(
     if (np.any(lam_mu > (1.0 / 32.0)) or np.any(lam_mu <= 0)) and not quiet:
         print("WARNING: Parameters must satisfy 0 < λ/μ <= 1/32 or result may diverge!")
     if not quiet:
-        fr = _hbm_free(0 if device is None else device)
+        fr = _hbm_free(0 if device is None else (device[0] if isinstance(device, (list, tuple)) else device))
         if fr:
             print(f"Available HBM: {_fmt_bytes(fr[0])} of {_fmt_bytes(fr[1])}", flush=True)
 
@@ -351,7 +405,7 @@ def denoise3D(
     assert np.all(lam_mu <= (1.0 / 16.0)) & np.all(lam_mu > 0), "Parameters must satisfy 0 < λ/μ <= 1/16"
     if not quiet:
         print("λ/μ ≈ [" + ", ".join(f"1/{m/l:.0f}" for m, l in zip(mu, lam)) + "]")
-        fr = _hbm_free(0 if device is None else device)
+        fr = _hbm_free(0 if device is None else (device[0] if isinstance(device, (list, tuple)) else device))
         if fr:
             print(f"Available HBM: {_fmt_bytes(fr[0])} of {_fmt_bytes(fr[1])}", flush=True)
 

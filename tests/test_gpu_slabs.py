@@ -72,3 +72,32 @@ def test_synth_device_matches_host():
         _lib.check(_lib.lib().tvdn_synth_fill(_lib.dtype_code(dt), nd, _lib.shape_arr(shape), seed, 1, 2,
                                               part.data_ptr(), _lib.current_stream(0)))
         assert bits_equal(part.cpu().numpy(), host[1:3])
+
+
+@pytest.mark.parametrize("shape,dtype,its,fista,stop,with_ref,bc", [
+    ((17, 4, 8, 16), np.float32, [4, 3], True, None, True, 2),
+    ((14, 6, 16), np.float64, 6, True, None, False, 0),
+    ((19, 3, 7, 9), np.float32, 40, False, 0.02, False, 2),
+])
+def test_denoise_with_a_device_list(oracle, shape, dtype, its, fista, stop, with_ref, bc):
+    """`denoise3D/4D(..., device=[...])`: several slabs inside one process (here all on device 0) through tvdn_run:
+    the reference's arguments and return tuple, the oracle's bits."""
+    import cytvdn_amd as tv
+    from cytvdn_amd import synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=19, dtype=dt) + dt.type(0.25)
+    refd = synth.cube(shape, seed=19, dtype=dt, kind="mean") if with_ref else None
+    mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
+    fn = tv.denoise4D if nd == 4 else tv.denoise3D
+    one = fn(x, mu, its, FISTA=fista, stopping_relative_change=stop, reference_data=refd, BC_mode=bc, quiet=True)
+    for devs in ([0, 0], [0, 0, 0, 0, 0]):
+        got = fn(x, mu, its, FISTA=fista, stopping_relative_change=stop, reference_data=refd, BC_mode=bc, quiet=True,
+                 device=devs)
+        assert len(got) == len(one) and bits_equal(got[0], one[0])
+        tol = 1e-6 if dt == np.float32 else 1e-12
+        for u, v in zip(got[1:], one[1:]):
+            assert u.dtype == v.dtype and np.array_equal(u == 0, v == 0)
+            np.testing.assert_allclose(u, v, rtol=tol)
+    ref = oracle.denoise(x, mu, its, fista, stopping_relative_change=stop, reference_data=refd, BC_mode=bc)
+    assert bits_equal(one[0], ref["recon"])
