@@ -388,6 +388,11 @@ def main():
     group, transport, fallback, preflight = None, None, False, None
     overlap = True
     if world > 1:
+        # libraries chat on stdout while the groups come up ("[Gloo] Rank 0 is connected to ..."): stdout is for the
+        # one JSON line, so file descriptor 1 points at stderr until the measurement starts
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         group, transport, fallback = init_groups(local_rank)
         if not a.no_preflight:
             from cytvdn_amd.distributed import selfcheck_exchange
@@ -396,6 +401,9 @@ def main():
                 overlap = False                  # keep measuring, visibly, with the blocking exchange
             if not preflight["blocking"] and rank == 0:
                 print(f"[bench] exchange self-check FAILED on {transport}: {preflight}", file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
 
     dtype_name = a.dtype
     if a.shape:
