@@ -79,7 +79,11 @@ class HaloSwap:
                 up.append(dist.P2POp(dist.irecv, self._rcv(t[lo - dl:lo], post_up), self.peer(self.left), self.group, tag=4 * i + 2))
         for i, t in enumerate(arrays):
             if self.left is not None:
-                down.append(dist.P2POp(dist.isend, self._snd(t[lo:lo + depth]), self.peer(self.left), self.group, tag=4 * i + 1))
+                # sent while the pass runs, and the pass may write its new state into these very rows (in-place host
+                # state of the wavefront engine): send a copy
+                low = t[lo:lo + depth]
+                down.append(dist.P2POp(dist.isend, self._snd(low) if self.via_dev else low.clone(), self.peer(self.left),
+                                       self.group, tag=4 * i + 1))
             if self.right is not None:
                 down.append(dist.P2POp(dist.irecv, self._rcv(t[hi:hi + dh], post_down), self.peer(self.right), self.group, tag=4 * i + 1))
         if up:

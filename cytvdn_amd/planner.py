@@ -136,7 +136,7 @@ def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int =
         need = wavefront_windows(nd, rows, k) * plane
         out.update(mode="wavefront" if s == 1 else "slabs+wavefront", n_slabs=s, chunk_rows=rows, k=k,
                    bytes_per_gpu=need,
-                   host_bytes_per_rank=(3 + 2 * nd * (2 if FISTA else 1)) * (rows_own + 2 * k) * plane,
+                   host_bytes_per_rank=(2 + nd * (2 if FISTA else 1)) * (rows_own + 2 * k) * plane,   # in-place host state
                    why=f"state of {out['state_bytes'] / 2 ** 30:.1f} GiB exceeds "
                        f"{s} x {avail / 2 ** 30:.1f} GiB of HBM: streamed from pinned host memory")
         if host_bytes is not None and out["host_bytes_per_rank"] > host_bytes:

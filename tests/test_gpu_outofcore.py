@@ -135,3 +135,32 @@ def test_planner_picks_the_streamed_engines_by_itself(oracle, monkeypatch, stop)
     monkeypatch.setenv("TVDN_HBM_LIMIT", "4G")
     again = tv.denoise4D(x, mu, its, FISTA=True, stopping_relative_change=stop, quiet=True)
     assert not calls and bits_equal(again[0], got[0])
+
+
+@pytest.mark.parametrize("shape,dtype,bc,rows,k,n_f,n_p", [
+    ((23, 3, 4, 8), "float32", 2, 4, 3, 7, 0),
+    ((23, 3, 4, 8), "float32", 2, 2, 5, 4, 3),        # hybrid: d -> b inside a pass, state arrays change count
+    ((17, 6, 16), "float64", 0, 3, 4, 6, 0),          # periodic: wrapped halo rows at both ends
+    ((9, 2, 5, 7), "float32", 2, 16, 8, 5, 2),        # chunk taller than the cube, k deeper than it
+])
+def test_wavefront_host_state_in_place(oracle, shape, dtype, bc, rows, k, n_f, n_p):
+    """The wavefront engine keeps ONE pinned copy of the state on the host (a pass writes the new state k rows behind
+    where it reads the old one): 10 arrays instead of 19 for 4-D FISTA.  Same bits as with separate old/new arrays."""
+    from cytvdn_amd import synth
+    from cytvdn_amd.wavefront import WavefrontRunner
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=71, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    lam = mu / dt.type(32.0 if nd == 4 else 16.0)
+    got = {}
+    for inplace in (True, False):
+        wr = WavefrontRunner(x, n_f > 0, 1.0 / lam, (lam / mu).astype(dt), device=0, chunk_rows=rows, k=k,
+                             max_iters=n_f + n_p, bc_mode=bc, host_inplace=inplace)
+        assert (wr.recon_h[0] is wr.recon_h[1]) == inplace
+        wr.run(n_f, n_p)
+        got[inplace] = (wr.recon(), wr.sums()[: n_f + n_p])
+    its = [n_f, n_p] if (n_f and n_p) else (n_f or n_p)
+    ref = oracle.denoise(x, mu, its, n_f > 0, BC_mode=bc)
+    assert bits_equal(got[True][0], ref["recon"]) and bits_equal(got[False][0], ref["recon"])
+    np.testing.assert_allclose(got[True][1], got[False][1], rtol=1e-12)

@@ -31,7 +31,7 @@ def test_baseline_configs():
     c5 = plan_run((1024, 1024, 256, 256), "float32", True, 8, hbm_bytes=HBM)
     assert c5["mode"] == "slabs+wavefront" and c5["n_slabs"] == 8 and c5["min_slabs_in_core"] > 8
     assert c5["state_bytes"] == 15 * 256 * GIB
-    assert c5["host_bytes_per_rank"] == 19 * (128 + 2 * c5["k"]) * 256 * 2 ** 20
+    assert c5["host_bytes_per_rank"] == 10 * (128 + 2 * c5["k"]) * 256 * 2 ** 20     # in-place host state: 10 arrays
 
 
 def test_stop_rule_selects_per_iteration_engine():
