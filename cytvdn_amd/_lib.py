@@ -28,7 +28,7 @@ EXPORTS = (
     "tvdn_abi_version", "tvdn_last_error", "tvdn_device_count", "tvdn_ctx_create", "tvdn_ctx_destroy",
     "tvdn_ctx_timing_enable", "tvdn_ctx_timing_read",
     "tvdn_accumulator_update", "tvdn_datacube_update", "tvdn_sum_square_error", "tvdn_iterate_fused",
-    "tvdn_synth_fill", "tvdn_run", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many", "tvdn_plan",
+    "tvdn_synth_fill", "tvdn_run", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many", "tvdn_plan", "tvdn_copy_many",
 )
 
 
@@ -122,6 +122,7 @@ def lib():
                                     C.c_void_p, C.c_void_p]
     L.tvdn_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     L.tvdn_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.tvdn_copy_many.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int64, C.c_void_p]
     L.tvdn_synth_fill.argtypes = [C.c_int, C.c_int, i64p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header and library out of step
@@ -196,6 +197,24 @@ def copy_to_host(src, dtype) -> np.ndarray:
     out = np.empty(tuple(src.shape), dtype=dtype)
     check(lib().tvdn_copy_to_host(C.c_void_p(out.ctypes.data), C.c_void_p(src.data_ptr()), out.nbytes, src.device.index))
     return out
+
+
+def copy_many(pairs, device: int) -> None:
+    """[(dst_tensor_view, src_tensor_view), ...] -> device copies on the current stream, batched by size into as few
+    launches as possible (tvdn_copy_many); views must be contiguous, equally shaped pairs and must not overlap."""
+    groups = {}
+    for dst, src in pairs:
+        nb = dst.numel() * dst.element_size()
+        if nb == 0:
+            continue
+        if nb % 16 or dst.data_ptr() % 16 or src.data_ptr() % 16 or not dst.is_contiguous() or not src.is_contiguous():
+            dst.copy_(src)                       # odd sizes: the runtime's copy
+            continue
+        groups.setdefault(nb, []).append((dst.data_ptr(), src.data_ptr()))
+    for nb, lst in groups.items():
+        d = (C.c_void_p * len(lst))(*[p[0] for p in lst])
+        s = (C.c_void_p * len(lst))(*[p[1] for p in lst])
+        check(lib().tvdn_copy_many(len(lst), d, s, nb, current_stream(device)))
 
 
 def current_stream(device: int) -> C.c_void_p:

@@ -62,7 +62,7 @@ def state_arrays(ndim: int, fista: bool) -> int:
 def wavefront_windows(ndim: int, rows: int, k: int) -> int:
     """Rows of HBM the wavefront engine keeps resident for chunk height `rows` and depth k (wavefront.py: recon
     windows for levels 0..k, accumulator windows for levels -1..k per axis, the input window, in/out boxes)."""
-    return ((k + 1) + (k + 2) * ndim) * (rows + 3) + (rows + k + 3) + 2 * (3 + 4 * ndim) * rows
+    return ((k + 1) + (k + 2) * ndim) * (rows + 2) + (rows + k + 3) + 2 * (3 + 4 * ndim) * rows
 
 
 def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int = None, stop: bool = False,

@@ -38,6 +38,7 @@ def _write_or_copy(own: np.ndarray, out):
 
 
 IO_STREAMS = 1      # HIP streams per PCIe direction of the wavefront engine (TVDN_IO_STREAMS overrides)
+WINDOW_SLACK = 2    # rows a level window holds beyond the chunk height (planner.wavefront_windows uses the same)
 
 
 class _Window:
@@ -48,15 +49,20 @@ class _Window:
         self.base = 0
         self.top = 0
 
-    def slide(self, new_base):
-        """Drop the rows below new_base (global index), keeping [new_base, top) at the front."""
+    def slide(self, new_base, pend=None):
+        """Drop the rows below new_base (global index), keeping [new_base, top) at the front.  With `pend` (a list) a
+        non-overlapping move is not performed but appended as a (dst, src) pair for one batched launch
+        (_lib.copy_many): per chunk some 150 windows slide, and as individual runtime copies they were 81 % of a pass."""
         if new_base <= self.base:
             return
         keep = max(0, self.top - new_base)
         shift = new_base - self.base
         if keep > 0:
             src = self.buf[shift:shift + keep]
-            self.buf[:keep].copy_(src.clone() if shift < keep else src)
+            if pend is not None and shift >= keep:
+                pend.append((self.buf[:keep], src))
+            else:
+                self.buf[:keep].copy_(src.clone() if shift < keep else src)
         self.base = new_base
         self.top = max(self.top, new_base)
 
@@ -178,7 +184,9 @@ class WavefrontRunner:
         self.bytes_h2d = 0
         self.bytes_d2h = 0
 
-        cap = self.R + 3
+        # a launch that brings rows [a, b) to level j+1 reads rows a-1 .. b of level j: R + 2 rows per window (round 1
+        # kept R + 3; one row less per window is 20 % less HBM at 2-row chunks, i.e. a deeper k for the same memory)
+        cap = self.R + WINDOW_SLACK
         K = self.k
         # levels -1 .. K: recon (levels 0..K) and one accumulator array per axis (levels -1..K)
         self.Rw = [_Window(cap, plane, tdt, dev) for _ in range(K + 1)]
@@ -343,33 +351,36 @@ class WavefrontRunner:
             upload(c + 1)                                   # next chunk crosses PCIe while this one is swept
             u0, u1 = E0 + c * R, min(E0 + (c + 1) * R, E1)
             # slide every window to what chunk c still needs: level j keeps rows >= E0 + cR - j - 2
+            pend = []
             for j in range(-1, kk + 1):
                 nb = max(0, E0 + c * R - j - 2)
                 if j >= 0:
-                    self.Rw[j].slide(nb)
+                    self.Rw[j].slide(nb, pend)
                 for q in range(nd):
-                    self.Aw[j + 1][q].slide(nb)
-            self.Ow.slide(max(0, E0 + c * R - kk - 1))
+                    self.Aw[j + 1][q].slide(nb, pend)
+            self.Ow.slide(max(0, E0 + c * R - kk - 1), pend)
             if self.Fw is not None:
-                self.Fw.slide(max(0, E0 + c * R - kk - 1))
+                self.Fw.slide(max(0, E0 + c * R - kk - 1), pend)
+            _lib.copy_many(pend, self.device)
             if u0 < u1:
                 n = u1 - u0
                 box = self.inbox[c % 2]
                 for ev in in_ready[c % 2]:
                     main.wait_event(ev)
-                self.Ow.rows(u0, u1).copy_(box[0][:n])
-                self.Rw[0].rows(u0, u1).copy_(box[1][:n])
-                if self.row0 is not None and u0 == 0:
-                    self.row0[0].copy_(self.Rw[0].rows(0, 1)[0])
+                pairs = [(self.Ow.rows(u0, u1), box[0][:n]), (self.Rw[0].rows(u0, u1), box[1][:n])]
                 i = 2
                 for q in range(nd):
-                    self.Aw[1][q].rows(u0, u1).copy_(box[i][:n])          # level 0: d_k (or b)
+                    pairs.append((self.Aw[1][q].rows(u0, u1), box[i][:n]))          # level 0: d_k (or b)
                     i += 1
                     if n_in_state == 2:
-                        self.Aw[0][q].rows(u0, u1).copy_(box[i][:n])      # level -1: d_k-1
+                        pairs.append((self.Aw[0][q].rows(u0, u1), box[i][:n]))      # level -1: d_k-1
                         i += 1
                 if self.Fw is not None:
-                    self.Fw.rows(u0, u1).copy_(box[-1][:n])
+                    pairs.append((self.Fw.rows(u0, u1), box[-1][:n]))
+                _lib.copy_many(pairs, self.device)
+                if self.row0 is not None and u0 == 0:
+                    self.row0[0].copy_(self.Rw[0].rows(0, 1)[0])
+                if self.Fw is not None:
                     self.Fw.top = u1
                     if self.iters_done == 0:   # MSE[0]: the input against the reference (cyTVDN.py:124-125), own rows
                         o0, o1 = max(u0, g0), min(u1, g1)
@@ -406,14 +417,15 @@ class WavefrontRunner:
                 box = self.outbox[c % 2]
                 for ev in out_free[c % 2] or ():
                     main.wait_event(ev)
-                box[0][:n].copy_(self.Rw[kk].rows(a, b))
+                pairs = [(box[0][:n], self.Rw[kk].rows(a, b))]
                 i = 1
                 for q in range(nd):
-                    box[i][:n].copy_(self.Aw[kk + 1][q].rows(a, b))
+                    pairs.append((box[i][:n], self.Aw[kk + 1][q].rows(a, b)))
                     i += 1
                     if n_out_state == 2:
-                        box[i][:n].copy_(self.Aw[kk][q].rows(a, b))
+                        pairs.append((box[i][:n], self.Aw[kk][q].rows(a, b)))
                         i += 1
+                _lib.copy_many(pairs, self.device)
                 ev = torch.cuda.Event()
                 ev.record(main)
                 pairs = [(self.recon_h[new], box[0])]

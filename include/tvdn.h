@@ -273,6 +273,11 @@ int tvdn_plan(int dtype, int ndim, const int64_t *shape, int fista, int n_slabs,
 int tvdn_copy_to_device(void *dst_device, const void *src_host, size_t bytes, int device);
 int tvdn_copy_to_host(void *dst_host, const void *src_device, size_t bytes, int device);
 
+/* `n` device-to-device copies of `bytes_each` bytes (a multiple of 16; 16-byte aligned, non-overlapping segments)
+ * behind one or a few launches.  `dst` / `src` are HOST arrays of device pointers.  For callers that shuffle many
+ * row blocks per step (the streamed engines' level windows): asynchronous on `stream`. */
+int tvdn_copy_many(int32_t n, void *const *dst, const void *const *src, int64_t bytes_each, void *stream);
+
 /* Synthetic input (cytvdn_amd/synth.py restated on the device, bit-identical): fills rows
  * [row0, row0+rows) of the GLOBAL cube `shape` into `out` (rows*prod(shape[1:]) elements). */
 int tvdn_synth_fill(int dtype, int ndim, const int64_t *shape, uint64_t seed, int64_t row0,
