@@ -48,6 +48,7 @@ class IterArgs(C.Structure):
         ("dprev_in", C.c_void_p * 4),
         ("sweep_lo", C.c_int64), ("sweep_hi", C.c_int64), ("accumulate", C.c_int32), ("reserved", C.c_int32),
         ("wrap_recon", C.c_void_p),
+        ("ring_rows", C.c_int64), ("orig_ring_rows", C.c_int64),
     ]
 
 
@@ -122,11 +123,11 @@ def lib():
                                     C.c_void_p, C.c_void_p]
     L.tvdn_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     L.tvdn_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    L.tvdn_copy_many.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int64, C.c_void_p]
+    L.tvdn_copy_many.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_void_p]
     L.tvdn_synth_fill.argtypes = [C.c_int, C.c_int, i64p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header and library out of step
-    if L.tvdn_abi_version() != 2:
+    if L.tvdn_abi_version() != 3:
         raise TvdnError("libtvdn_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -199,22 +200,23 @@ def copy_to_host(src, dtype) -> np.ndarray:
     return out
 
 
-def copy_many(pairs, device: int) -> None:
-    """[(dst_tensor_view, src_tensor_view), ...] -> device copies on the current stream, batched by size into as few
-    launches as possible (tvdn_copy_many); views must be contiguous, equally shaped pairs and must not overlap."""
+def copy_many(pairs, device: int, max_blocks: int = 0) -> None:
+    """[(dst_tensor_view, src_tensor_view), ...] -> copies on the current stream, batched by size into as few launches
+    as possible (tvdn_copy_many); views must be contiguous, equally shaped pairs and must not overlap.  Device tensors
+    or pinned host tensors; max_blocks caps the workgroups of a launch (PCIe transfers beside running sweeps)."""
     groups = {}
     for dst, src in pairs:
         nb = dst.numel() * dst.element_size()
         if nb == 0:
             continue
         if nb % 16 or dst.data_ptr() % 16 or src.data_ptr() % 16 or not dst.is_contiguous() or not src.is_contiguous():
-            dst.copy_(src)                       # odd sizes: the runtime's copy
+            dst.copy_(src, non_blocking=True)    # odd sizes: the runtime's copy
             continue
         groups.setdefault(nb, []).append((dst.data_ptr(), src.data_ptr()))
     for nb, lst in groups.items():
         d = (C.c_void_p * len(lst))(*[p[0] for p in lst])
         s = (C.c_void_p * len(lst))(*[p[1] for p in lst])
-        check(lib().tvdn_copy_many(len(lst), d, s, nb, current_stream(device)))
+        check(lib().tvdn_copy_many(len(lst), d, s, nb, int(max_blocks), current_stream(device)))
 
 
 def current_stream(device: int) -> C.c_void_p:

@@ -72,6 +72,8 @@ struct FusedParams {
     int xcd;          // 1: remap workgroup ids so each XCD sweeps a contiguous run of tiles
     // patch order of the tiles of a cross-section (0 = plain order): patches of patch_a A-rows x patch_t tiles
     long long patch_a, patch_t, tiles_per_arow;
+    // row rings (RING instantiations only): row m of recon / accumulators lives at slot m % ring, of orig at m % ring_orig
+    unsigned ring, ring_orig;
     double *partials;
 };
 
@@ -175,7 +177,15 @@ __device__ __forceinline__ void axis_contig(const Pack<T, VEC> &r_cur, const T *
     if (M::kOut2) stv<T, VEC>(s.out2 + x, o2);
 }
 
-template <typename T, int VEC, int NAX, int MODE>
+// RING: the arrays are rings of row-planes (tvdn.h, ring_rows): the only change is where a row starts.  Row numbers
+// are wave-uniform, so the modulo is scalar work per row step; a separate instantiation keeps the resident path as is.
+template <bool RING>
+__device__ __forceinline__ long long row_slot(long long m, unsigned ring)
+{
+    return RING ? (long long)((unsigned)m % ring) : m;
+}
+
+template <typename T, int VEC, int NAX, int MODE, bool RING>
 __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> p)
 {
     using P = Pack<T, VEC>;
@@ -230,7 +240,7 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
         const AxisState<T> sM = p.ax[iM];
 
         // ---- prologue: M-axis accumulator of row m0 -----------------------------------------------
-        P r_cur = ldv<T, VEC>(p.r_in + m0 * SM + xs);
+        P r_cur = ldv<T, VEC>(p.r_in + row_slot<RING>(m0, p.ring) * SM + xs);
         P bM_cur;
         {
             long long mp;  // the row that precedes m0
@@ -238,8 +248,8 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
                 mp = m0 - 1;
             else
                 mp = bc2 ? m0 : p.row_hi - 1;  // TVDN_EDGE_BC: Jia-Zhao -> itself, periodic -> last row
-            const long long x0 = m0 * SM + xs;
-            const P r_prev = ldv<T, VEC>(p.r_in + mp * SM + xs);
+            const long long x0 = row_slot<RING>(m0, p.ring) * SM + xs;
+            const P r_prev = ldv<T, VEC>(p.r_in + row_slot<RING>(mp, p.ring) * SM + xs);
             const P v1 = ldv_nt<T, VEC>(sM.in1 + x0);
             P v2, o1, o2;
             if (MT::kIn2) v2 = ldv_nt<T, VEC>(sM.in2 + x0);
@@ -255,7 +265,7 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
 
         // ---- march -------------------------------------------------------------------------------
         for (long long m = m0; m < m1; ++m) {
-            const long long x = m * SM + xs;
+            const long long x = row_slot<RING>(m, p.ring) * SM + xs;
             const bool last = (m + 1 == m1);
             const bool at_end = (m + 1 == p.row_hi);
 
@@ -270,8 +280,8 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
                 // is not (anisotropic.pyx:65-73).  p.wrap holds row 0's current recon; its state is that zero (the
                 // state loads below then land on the own row and are discarded).
                 const bool wrapz = at_end && p.hi_mode == TVDN_EDGE_WRAP;
-                const long long xn = (wrap ? p.row_lo : (wrapz ? m : m + 1)) * SM + xs;
-                const T *rbase = wrapz ? p.wrap - m * SM : p.r_in;  // wave-uniform: p.wrap + xs == rbase + xn
+                const long long xn = row_slot<RING>(wrap ? p.row_lo : (wrapz ? m : m + 1), p.ring) * SM + xs;
+                const T *rbase = wrapz ? p.wrap - (RING ? xn - xs : m * SM) : p.r_in;  // wave-uniform: p.wrap + xs == rbase + xn
                 r_next = ldv<T, VEC>(rbase + xn);
                 P v1 = ldv_nt<T, VEC>(sM.in1 + xn);
                 P v2, o1, o2;
@@ -312,7 +322,7 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
                                       acc[0]);
 
             // (3) reconstruction update at row m (utils.pyx:90-104)
-            const P og = ldv_nt<T, VEC>(p.orig + x);
+            const P og = ldv_nt<T, VEC>(p.orig + (RING ? row_slot<RING>(m, p.ring_orig) * SM + xs : x));
             P r_new;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
@@ -333,7 +343,10 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
 template <typename T, int VEC, int NAX, int MODE>
 static int launch_fused_t(const FusedParams<T> &p, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((fused_iter_kernel<T, VEC, NAX, MODE>), dim3(grid), dim3(kFusedBlock), 0, s, p);
+    if (p.ring)
+        hipLaunchKernelGGL((fused_iter_kernel<T, VEC, NAX, MODE, true>), dim3(grid), dim3(kFusedBlock), 0, s, p);
+    else
+        hipLaunchKernelGGL((fused_iter_kernel<T, VEC, NAX, MODE, false>), dim3(grid), dim3(kFusedBlock), 0, s, p);
     TVDN_HIP(hipGetLastError());
     return TVDN_OK;
 }
@@ -393,6 +406,10 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
     p.lo_mode = a->lo_mode; p.hi_mode = a->hi_mode; p.bc = a->bc_mode;
     if (a->hi_mode == TVDN_EDGE_WRAP)  // an explicit plane, or by convention the row that follows the own rows
         p.wrap = a->wrap_recon ? (const T *)a->wrap_recon : p.r_in + a->row_hi * (p.A * p.B * p.C);
+    p.ring = (unsigned)a->ring_rows;
+    p.ring_orig = (unsigned)(a->ring_rows ? (a->orig_ring_rows ? a->orig_ring_rows : a->shape[0]) : 0);
+    if (!p.ring && getenv("TVDN_FORCE_RING") && a->shape[0] < (1LL << 31))  // measurement knob: the ring instantiation on
+        p.ring = p.ring_orig = (unsigned)a->shape[0];                        // resident arrays (same rows, same bits)
     p.partials = ctx->partials;
 
     const int vec = (al && (p.C % VMAX == 0)) ? VMAX : 1;
@@ -492,6 +509,21 @@ extern "C" int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *a, double
     TVDN_REQUIRE(!(a->hi_mode == TVDN_EDGE_ZERO && a->bc_mode != TVDN_BC_JIA_ZHAO), "hi_mode ZERO is a Jia-Zhao property");
     TVDN_REQUIRE(!(a->lo_mode == TVDN_EDGE_BC && a->bc_mode == TVDN_BC_PERIODIC && a->hi_mode != TVDN_EDGE_BC),
                  "periodic BC with lo_mode BC needs the whole ring in this block (hi_mode BC)");
+    TVDN_REQUIRE(a->ring_rows >= 0 && a->orig_ring_rows >= 0, "negative ring size");
+    TVDN_REQUIRE(a->ring_rows > 0 || a->orig_ring_rows == 0, "orig_ring_rows without ring_rows");
+    if (a->ring_rows > 0) {
+        const long long s0 = (a->sweep_lo == 0 && a->sweep_hi == 0) ? a->row_lo : a->sweep_lo;
+        const long long s1 = (a->sweep_lo == 0 && a->sweep_hi == 0) ? a->row_hi : a->sweep_hi;
+        // rows of the level below that one launch reads: the swept rows, the row before and the row after
+        const long long need = (s1 - s0) + ((s0 > a->row_lo || a->lo_mode == TVDN_EDGE_HALO) ? 1 : 0) +
+                               ((s1 < a->row_hi || a->hi_mode == TVDN_EDGE_HALO) ? 1 : 0);
+        TVDN_REQUIRE(a->shape[0] < (1LL << 31) && a->ring_rows < (1LL << 31) && a->orig_ring_rows < (1LL << 31),
+                     "row rings index rows with 32 bits");
+        TVDN_REQUIRE(a->ring_rows >= need, "ring of %lld rows cannot hold the %lld rows this sweep reads",
+                     (long long)a->ring_rows, need);
+        TVDN_REQUIRE(a->orig_ring_rows == 0 || a->orig_ring_rows >= s1 - s0, "orig ring shorter than the sweep");
+        TVDN_REQUIRE(!(a->hi_mode == TVDN_EDGE_WRAP && !a->wrap_recon), "hi_mode WRAP on a ring needs wrap_recon");
+    }
     TVDN_REQUIRE(a->orig && a->recon_in && a->recon_out, "NULL state pointer");
     TVDN_REQUIRE(a->recon_in != a->recon_out, "the fused sweep is not in-place: recon_in == recon_out");
     for (int q = 0; q < a->ndim; ++q) {

@@ -146,7 +146,7 @@ extern "C" int tvdn_copy_to_host(void *dst_host, const void *src_device, size_t 
     return tvdn::transfer(false, dst_host, src_device, bytes, device);
 }
 
-// ---- many equal-sized device-to-device copies behind one launch -------------------------------------------------------
+// ---- many equal-sized copies behind one launch (HBM <-> HBM, or HBM <-> pinned host memory) ---------------------------
 // The wavefront engine (cytvdn_amd/wavefront.py) slides ~150 level windows and fills / drains ~20 staging boxes per
 // chunk.  As individual hipMemcpyAsync calls those are blit kernels of the runtime that reach ~1 TB/s on 512 MiB
 // (rocprofv3: 81 % of the GPU time of a pass on 256 MiB planes); batched here they are one streaming kernel per group.
@@ -165,31 +165,36 @@ struct CopyBatch {
 
 __global__ void __launch_bounds__(256) copy_many_kernel(CopyBatch b)
 {
-    const long long seg = blockIdx.x / b.pieces, piece = blockIdx.x % b.pieces;
-    const long long off = piece * kCopyPiece;
-    const long long len = (off + kCopyPiece < b.bytes) ? kCopyPiece : b.bytes - off;
     typedef float vec_t __attribute__((ext_vector_type(4)));
-    const vec_t *s = reinterpret_cast<const vec_t *>(b.src[seg] + off);
-    vec_t *d = reinterpret_cast<vec_t *>(b.dst[seg] + off);
-    const long long nv = len / 16;
-    long long i = threadIdx.x;
-    for (; i + 3 * 256 < nv; i += 4 * 256) {  // four 16-byte loads in flight per thread
-        const vec_t a0 = __builtin_nontemporal_load(s + i), a1 = __builtin_nontemporal_load(s + i + 256);
-        const vec_t a2 = __builtin_nontemporal_load(s + i + 512), a3 = __builtin_nontemporal_load(s + i + 768);
-        __builtin_nontemporal_store(a0, d + i);
-        __builtin_nontemporal_store(a1, d + i + 256);
-        __builtin_nontemporal_store(a2, d + i + 512);
-        __builtin_nontemporal_store(a3, d + i + 768);
+    const long long total = (long long)b.n * b.pieces;
+    for (long long idx = blockIdx.x; idx < total; idx += gridDim.x) {  // one trip unless the grid is capped
+        const long long seg = idx / b.pieces, piece = idx % b.pieces;
+        const long long off = piece * kCopyPiece;
+        const long long len = (off + kCopyPiece < b.bytes) ? kCopyPiece : b.bytes - off;
+        const vec_t *s = reinterpret_cast<const vec_t *>(b.src[seg] + off);
+        vec_t *d = reinterpret_cast<vec_t *>(b.dst[seg] + off);
+        const long long nv = len / 16;
+        long long i = threadIdx.x;
+        for (; i + 3 * 256 < nv; i += 4 * 256) {  // four 16-byte loads in flight per thread
+            const vec_t a0 = __builtin_nontemporal_load(s + i), a1 = __builtin_nontemporal_load(s + i + 256);
+            const vec_t a2 = __builtin_nontemporal_load(s + i + 512), a3 = __builtin_nontemporal_load(s + i + 768);
+            __builtin_nontemporal_store(a0, d + i);
+            __builtin_nontemporal_store(a1, d + i + 256);
+            __builtin_nontemporal_store(a2, d + i + 512);
+            __builtin_nontemporal_store(a3, d + i + 768);
+        }
+        for (; i < nv; i += 256) __builtin_nontemporal_store(__builtin_nontemporal_load(s + i), d + i);
     }
-    for (; i < nv; i += 256) __builtin_nontemporal_store(__builtin_nontemporal_load(s + i), d + i);
 }
 
 }  // namespace tvdn
 
-extern "C" int tvdn_copy_many(int32_t n, void *const *dst, const void *const *src, int64_t bytes_each, void *stream)
+extern "C" int tvdn_copy_many(int32_t n, void *const *dst, const void *const *src, int64_t bytes_each, int32_t max_blocks,
+                              void *stream)
 {
     using namespace tvdn;
     TVDN_REQUIRE(n >= 0 && (n == 0 || (dst && src)), "NULL argument");
+    TVDN_REQUIRE(max_blocks >= 0, "max_blocks must be >= 0");
     TVDN_REQUIRE(bytes_each >= 0 && bytes_each % 16 == 0, "bytes_each must be a non-negative multiple of 16");
     if (n == 0 || bytes_each == 0) return TVDN_OK;
     const long long pieces = (bytes_each + kCopyPiece - 1) / kCopyPiece;
@@ -204,8 +209,9 @@ extern "C" int tvdn_copy_many(int32_t n, void *const *dst, const void *const *sr
             b.dst[i] = (char *)dst[i0 + i];
             b.src[i] = (const char *)src[i0 + i];
         }
-        const long long grid = (long long)b.n * pieces;
+        long long grid = (long long)b.n * pieces;
         TVDN_REQUIRE(grid < (1LL << 31), "copy batch too large");
+        if (max_blocks > 0 && grid > max_blocks) grid = max_blocks;
         hipLaunchKernelGGL(copy_many_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, b);
         TVDN_HIP(hipGetLastError());
     }

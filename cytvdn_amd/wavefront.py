@@ -7,11 +7,11 @@ through the GPU once per pass, in chunks of R rows, and iteration level j+1 trai
 chunk c computes, for j = 0..k-1, rows [cR-(j+1), (c+1)R-(j+1)) of level j+1 from level j -- so every row of
 every level is computed exactly once and crosses PCIe once per k iterations (10 arrays up, 9 down).
 
-Each level keeps a sliding window of R+3 rows per state array in HBM (recon_j and one accumulator array per
-axis; in the compact FISTA state level j's `d_j` also serves as `d_prev` of level j+1's update), plus one
-window of the input.  The sweeps are the same `tvdn_iterate_fused` launches as everywhere else: windows are
-presented to the kernel as row ranges of virtual arrays by offsetting the base pointers, so the arithmetic
--- and the bits -- are those of the in-core engine.  Jia-Zhao and (single process) periodic BC; slabs across
+Each level keeps a ring of R+2 rows per state array in HBM (recon_j and one accumulator array per axis; in the
+compact FISTA state level j's `d_j` also serves as `d_prev` of level j+1's update), plus one ring of the input.
+The sweeps are the same `tvdn_iterate_fused` launches as everywhere else, told that row g of each array lives at
+slot g % ring_rows (tvdn.h): rows are never moved inside HBM, and the arithmetic -- and the bits -- are those of the
+in-core engine.  Jia-Zhao and (single process) periodic BC; slabs across
 ranks; `reference_data` traces; no per-iteration host decisions (a stopping rule makes `driver._run_staged`
 fall back to the trapezoid engine with k = 1).
 """
@@ -41,40 +41,23 @@ IO_STREAMS = 1      # HIP streams per PCIe direction of the wavefront engine (TV
 WINDOW_SLACK = 2    # rows a level window holds beyond the chunk height (planner.wavefront_windows uses the same)
 
 
-class _Window:
-    """Sliding window of rows [base, top) of one array, stored from buffer row 0."""
+class _Ring:
+    """Ring of `cap` row-planes of one array: global row g lives at slot g % cap (tvdn.h, ring_rows).  A level keeps
+    the R+2 rows the next level's launch reads; nothing is ever moved (round 2's first version slid the windows
+    down by copying: 2/R of a sweep's traffic on top of it, 40 % at 2-row chunks)."""
 
     def __init__(self, cap, plane, tdt, dev):
         self.buf = torch.zeros((cap,) + tuple(plane), dtype=tdt, device=dev)
-        self.base = 0
-        self.top = 0
+        self.cap = int(cap)
 
-    def slide(self, new_base, pend=None):
-        """Drop the rows below new_base (global index), keeping [new_base, top) at the front.  With `pend` (a list) a
-        non-overlapping move is not performed but appended as a (dst, src) pair for one batched launch
-        (_lib.copy_many): per chunk some 150 windows slide, and as individual runtime copies they were 81 % of a pass."""
-        if new_base <= self.base:
-            return
-        keep = max(0, self.top - new_base)
-        shift = new_base - self.base
-        if keep > 0:
-            src = self.buf[shift:shift + keep]
-            if pend is not None and shift >= keep:
-                pend.append((self.buf[:keep], src))
-            else:
-                self.buf[:keep].copy_(src.clone() if shift < keep else src)
-        self.base = new_base
-        self.top = max(self.top, new_base)
+    def row(self, g):
+        return self.buf[g % self.cap]
 
     def rows(self, g0, g1):
-        """View of global rows [g0, g1)."""
-        assert self.base <= g0 and g1 - self.base <= self.buf.shape[0], (self.base, g0, g1, self.buf.shape[0])
-        return self.buf[g0 - self.base:g1 - self.base]
+        return [self.buf[g % self.cap] for g in range(g0, g1)]
 
-    def ptr(self, ref, row_bytes):
-        """Base pointer of a virtual array whose row 0 is global row `ref` (may lie outside the buffer;
-        only rows inside the window are ever dereferenced)."""
-        return self.buf.data_ptr() + (ref - self.base) * row_bytes
+    def ptr(self):
+        return self.buf.data_ptr()
 
 
 class WavefrontRunner:
@@ -189,10 +172,11 @@ class WavefrontRunner:
         cap = self.R + WINDOW_SLACK
         K = self.k
         # levels -1 .. K: recon (levels 0..K) and one accumulator array per axis (levels -1..K)
-        self.Rw = [_Window(cap, plane, tdt, dev) for _ in range(K + 1)]
-        self.Aw = [[_Window(cap, plane, tdt, dev) for _ in range(self.nd)] for _ in range(K + 2)]  # index level + 1
-        self.Ow = _Window(self.R + K + 3, plane, tdt, dev)
-        self.Fw = _Window(self.R + K + 3, plane, tdt, dev) if reference is not None else None   # reference_data rows
+        self.cap = cap
+        self.Rw = [_Ring(cap, plane, tdt, dev) for _ in range(K + 1)]
+        self.Aw = [[_Ring(cap, plane, tdt, dev) for _ in range(self.nd)] for _ in range(K + 2)]  # index level + 1
+        self.Ow = _Ring(self.R + K + 3, plane, tdt, dev)
+        self.Fw = _Ring(self.R + K + 3, plane, tdt, dev) if reference is not None else None   # reference_data rows
         n_in = 3 + 2 * self.nd
         n_out = 1 + 2 * self.nd
         self.inbox = [[torch.empty((self.R,) + tuple(plane), dtype=tdt, device=dev) for _ in range(n_in)] for _ in range(2)]
@@ -200,6 +184,12 @@ class WavefrontRunner:
         # HIP streams per PCIe direction.  One each is best: up and down together already hold the link at 32 + 29 GB/s
         # (256 MiB planes, 32x1024x256x256, 2 rows x k = 24: 19.1 Gvoxel-iters/s with 1 stream per direction, 18.4
         # with 2, 13.9 with 4); the knob stays for other hosts.
+        # Downloads: the runtime's DMA copies by default.  TVDN_WF_DOWN=kernel sends a chunk's rows home with ONE capped
+        # copy launch writing pinned memory instead (tvdn_copy_many, TVDN_WF_IO_BLOCKS workgroups): it never falls into
+        # the 4x slower mode whole bursts of DMA downloads show on some boxes (profiles/r02_wavefront_rings.txt) but
+        # slows the sweeps beside it by a third -- better at 2-4 row chunks, worse at 16; uploads by kernel are always worse.
+        self.down_kernel = os.environ.get("TVDN_WF_DOWN", "dma") == "kernel"
+        self.io_blocks = int(os.environ.get("TVDN_WF_IO_BLOCKS", "16"))
         n_io = max(1, int(os.environ.get("TVDN_IO_STREAMS", str(IO_STREAMS))))
         self.ups = [torch.cuda.Stream(device=dev) for _ in range(n_io)]
         self.downs = [torch.cuda.Stream(device=dev) for _ in range(n_io)]
@@ -232,39 +222,40 @@ class WavefrontRunner:
 
     # ---- one launch: level j -> j+1 for global rows [a, b) ---------------------------------------------------
     def _launch(self, j, a, b, tk, tk_prev, mode, slot):
-        N0, rb = self.N0, self.row_bytes
-        ref = 0 if a == 0 else a - 1
-        at_top = (b == N0)
-        row_hi = (b - ref) if at_top else (b - ref + 1)
+        """Rows are global row numbers of a virtual N0-row array of which each level's ring holds the R+2 current ones."""
+        N0 = self.N0
         A = self._args
         A.dtype, A.ndim = self.code, self.nd
-        A.shape[0] = row_hi
+        A.shape[0] = N0
         for i, s in enumerate(self.shape[1:]):
             A.shape[i + 1] = s
-        A.row_lo, A.row_hi = 0, row_hi
-        A.sweep_lo, A.sweep_hi = a - ref, b - ref
+        A.row_lo, A.row_hi = 0, N0
+        A.sweep_lo, A.sweep_hi = a, b
+        A.ring_rows, A.orig_ring_rows = self.cap, self.Ow.cap
         A.lo_mode = _lib.EDGE_BC
-        A.hi_mode = _lib.EDGE_ZERO if at_top else _lib.EDGE_BC
+        # the top face is reached only where it is the cube's own (Jia-Zhao: wrapped accumulator zero, or exact from the
+        # stashed row 0); periodic runs extend the cube instead and never sweep a row next to row_hi
+        A.hi_mode = _lib.EDGE_BC if self.periodic else _lib.EDGE_ZERO
         A.wrap_recon = None
-        if at_top and self.row0 is not None:
+        if self.row0 is not None:
             A.hi_mode, A.wrap_recon = _lib.EDGE_WRAP, self.row0[j].data_ptr()
         A.bc_mode = self.bc
         A.mode = mode
         A.tk, A.tk_prev = float(tk or 0.0), float(tk_prev)
         A.accumulate = 1
-        A.orig = self.Ow.ptr(ref, rb)
-        A.recon_in = self.Rw[j].ptr(ref, rb)
-        A.recon_out = self.Rw[j + 1].ptr(ref, rb)
+        A.orig = self.Ow.ptr()
+        A.recon_in = self.Rw[j].ptr()
+        A.recon_out = self.Rw[j + 1].ptr()
         for q in range(self.nd):
-            cur, prv, nxt = self.Aw[j + 1][q], self.Aw[j][q], self.Aw[j + 2][q]
+            cur, prv, nxt = self.Aw[j + 1][q].ptr(), self.Aw[j][q].ptr(), self.Aw[j + 2][q].ptr()
             A.b_in[q] = A.b_out[q] = A.d_in[q] = A.d_out[q] = A.dprev_in[q] = None
             A.clip[q], A.lambda_mu[q] = self.clip[q], self.lam_mu[q]
             if mode == _lib.ITER_FISTA_D:
-                A.d_in[q], A.dprev_in[q], A.d_out[q] = cur.ptr(ref, rb), prv.ptr(ref, rb), nxt.ptr(ref, rb)
+                A.d_in[q], A.dprev_in[q], A.d_out[q] = cur, prv, nxt
             elif mode == _lib.ITER_FISTA_D_TO_PLAIN:
-                A.d_in[q], A.dprev_in[q], A.b_out[q] = cur.ptr(ref, rb), prv.ptr(ref, rb), nxt.ptr(ref, rb)
+                A.d_in[q], A.dprev_in[q], A.b_out[q] = cur, prv, nxt
             else:
-                A.b_in[q], A.b_out[q] = cur.ptr(ref, rb), nxt.ptr(ref, rb)
+                A.b_in[q], A.b_out[q] = cur, nxt
         _lib.check(_lib.lib().tvdn_iterate_fused(self.ctx, C.byref(A), C.c_void_p(self.sums_dev[slot].data_ptr()),
                                                  _lib.current_stream(self.device)))
 
@@ -305,8 +296,6 @@ class WavefrontRunner:
                 prev_ratio = tk
         n_in_state = 2 if forms[0] else 1
         n_out_state = 2 if forms[kk] else 1
-        for w in self.Rw[:kk + 1] + [x for lvl in self.Aw[:kk + 2] for x in lvl] + [self.Ow] + ([self.Fw] if self.Fw else []):
-            w.base = w.top = 0
         n_chunks = (E1 - E0 + kk + R - 1) // R
 
         def lo_bound(level):    # lowest row that can be brought to `level` (an artificial face loses a row per level)
@@ -316,6 +305,12 @@ class WavefrontRunner:
             return E1 - level if art_hi else N0
         in_ready, in_free = [None, None], [None, None]
         out_ready, out_free = [None, None], [None, None]
+        trace = [] if os.environ.get("TVDN_WF_TRACE") else None   # (kind, chunk, start event, end event) per phase
+
+        def mark(stream):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)
+            return ev
 
         def upload(c):
             u0, u1 = E0 + c * R, min(E0 + (c + 1) * R, E1)
@@ -338,11 +333,14 @@ class WavefrontRunner:
                 with torch.cuda.stream(st):
                     if in_free[c % 2] is not None:
                         st.wait_event(in_free[c % 2])
+                    t0 = mark(st) if trace is not None else None
                     for dst, src in pairs[si::len(self.ups)]:
                         dst[:n].copy_(src[u0 - hb:u1 - hb], non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(st)
                     evs.append(ev)
+                    if trace is not None:
+                        trace.append(("up", c, t0, mark(st)))
             self.bytes_h2d += len(pairs) * n * self.row_bytes
             in_ready[c % 2] = evs
 
@@ -350,49 +348,32 @@ class WavefrontRunner:
         for c in range(n_chunks):
             upload(c + 1)                                   # next chunk crosses PCIe while this one is swept
             u0, u1 = E0 + c * R, min(E0 + (c + 1) * R, E1)
-            # slide every window to what chunk c still needs: level j keeps rows >= E0 + cR - j - 2
-            pend = []
-            for j in range(-1, kk + 1):
-                nb = max(0, E0 + c * R - j - 2)
-                if j >= 0:
-                    self.Rw[j].slide(nb, pend)
-                for q in range(nd):
-                    self.Aw[j + 1][q].slide(nb, pend)
-            self.Ow.slide(max(0, E0 + c * R - kk - 1), pend)
-            if self.Fw is not None:
-                self.Fw.slide(max(0, E0 + c * R - kk - 1), pend)
-            _lib.copy_many(pend, self.device)
             if u0 < u1:
                 n = u1 - u0
                 box = self.inbox[c % 2]
                 for ev in in_ready[c % 2]:
                     main.wait_event(ev)
-                pairs = [(self.Ow.rows(u0, u1), box[0][:n]), (self.Rw[0].rows(u0, u1), box[1][:n])]
-                i = 2
+                rings = [self.Ow, self.Rw[0]]
                 for q in range(nd):
-                    pairs.append((self.Aw[1][q].rows(u0, u1), box[i][:n]))          # level 0: d_k (or b)
-                    i += 1
+                    rings.append(self.Aw[1][q])                                    # level 0: d_k (or b)
                     if n_in_state == 2:
-                        pairs.append((self.Aw[0][q].rows(u0, u1), box[i][:n]))      # level -1: d_k-1
-                        i += 1
+                        rings.append(self.Aw[0][q])                                # level -1: d_k-1
+                srcs = list(box[:len(rings)])
                 if self.Fw is not None:
-                    pairs.append((self.Fw.rows(u0, u1), box[-1][:n]))
-                _lib.copy_many(pairs, self.device)
+                    rings.append(self.Fw)
+                    srcs.append(box[-1])
+                _lib.copy_many([(rg.row(g), src[g - u0]) for rg, src in zip(rings, srcs) for g in range(u0, u1)], self.device)
                 if self.row0 is not None and u0 == 0:
-                    self.row0[0].copy_(self.Rw[0].rows(0, 1)[0])
-                if self.Fw is not None:
-                    self.Fw.top = u1
-                    if self.iters_done == 0:   # MSE[0]: the input against the reference (cyTVDN.py:124-125), own rows
-                        o0, o1 = max(u0, g0), min(u1, g1)
-                        if o0 < o1:
-                            self._sse(self.Rw[0].rows(o0, o1), self.Fw.rows(o0, o1), 0)
+                    self.row0[0].copy_(self.Rw[0].row(0))
+                if self.Fw is not None and self.iters_done == 0:
+                    # MSE[0]: the input against the reference (cyTVDN.py:124-125), own rows
+                    for g in range(max(u0, g0), min(u1, g1)):
+                        self._sse(self.Rw[0].row(g)[None], self.Fw.row(g)[None], 0)
                 ev = torch.cuda.Event()
                 ev.record(main)
                 in_free[c % 2] = ev
-                self.Ow.top = self.Rw[0].top = u1
-                for q in range(nd):
-                    self.Aw[1][q].top = self.Aw[0][q].top = u1
             # the wavefront: level j+1 trails level j by one row
+            t0 = mark(main) if trace is not None else None
             for j in range(kk):
                 a = max(lo_bound(j + 1), E0 + c * R - (j + 1))
                 b = min(hi_bound(j + 1), E0 + (c + 1) * R - (j + 1))
@@ -403,12 +384,12 @@ class WavefrontRunner:
                     if x0 < x1:
                         self._launch(j, x0, x1, ratios[j], tkp[j], modes[j], slot)
                         if self.row0 is not None and x0 == 0:
-                            self.row0[j + 1].copy_(self.Rw[j + 1].rows(0, 1)[0])
+                            self.row0[j + 1].copy_(self.Rw[j + 1].row(0))
                         if self.Fw is not None and slot != discard:
-                            self._sse(self.Fw.rows(x0, x1), self.Rw[j + 1].rows(x0, x1), slot + 1)
-                self.Rw[j + 1].top = b
-                for q in range(nd):
-                    self.Aw[j + 2][q].top = b
+                            for g in range(x0, x1):
+                                self._sse(self.Fw.row(g)[None], self.Rw[j + 1].row(g)[None], slot + 1)
+            if trace is not None:
+                trace.append(("sweep", c, t0, mark(main)))
             # own rows that have reached the last level go home
             a = max(g0, E0 + c * R - kk)
             b = min(g1, E0 + (c + 1) * R - kk)
@@ -417,15 +398,12 @@ class WavefrontRunner:
                 box = self.outbox[c % 2]
                 for ev in out_free[c % 2] or ():
                     main.wait_event(ev)
-                pairs = [(box[0][:n], self.Rw[kk].rows(a, b))]
-                i = 1
+                rings = [self.Rw[kk]]
                 for q in range(nd):
-                    pairs.append((box[i][:n], self.Aw[kk + 1][q].rows(a, b)))
-                    i += 1
+                    rings.append(self.Aw[kk + 1][q])
                     if n_out_state == 2:
-                        pairs.append((box[i][:n], self.Aw[kk][q].rows(a, b)))
-                        i += 1
-                _lib.copy_many(pairs, self.device)
+                        rings.append(self.Aw[kk][q])
+                _lib.copy_many([(box[i][g - a], rg.row(g)) for i, rg in enumerate(rings) for g in range(a, b)], self.device)
                 ev = torch.cuda.Event()
                 ev.record(main)
                 pairs = [(self.recon_h[new], box[0])]
@@ -438,16 +416,29 @@ class WavefrontRunner:
                 for si, st in enumerate(self.downs):
                     with torch.cuda.stream(st):
                         st.wait_event(ev)
-                        for dst, src in pairs[si::len(self.downs)]:
-                            dst[a - hb:b - hb].copy_(src[:n], non_blocking=True)
+                        t0 = mark(st) if trace is not None else None
+                        mine = [(dst[a - hb:b - hb], src[:n]) for dst, src in pairs[si::len(self.downs)]]
+                        if self.down_kernel:
+                            _lib.copy_many(mine, self.device, self.io_blocks)   # posted writes into pinned memory, one launch
+                        else:
+                            for dst, src in mine:
+                                dst.copy_(src, non_blocking=True)
                         ev2 = torch.cuda.Event()
                         ev2.record(st)
                         evs.append(ev2)
+                        if trace is not None:
+                            trace.append(("down", c, t0, mark(st)))
                 self.bytes_d2h += len(pairs) * n * self.row_bytes
                 out_free[c % 2] = evs
         for st in self.downs:
             st.synchronize()
         main.synchronize()
+        if trace:
+            # timeline of the pass relative to its first event (ms): start-end of every phase, to see what overlaps what
+            ref = trace[0][2]
+            import sys
+            for kind, c, e0, e1 in sorted(trace, key=lambda t: ref.elapsed_time(t[2])):
+                print(f"wf-trace {kind:5s} chunk {c:4d}  {ref.elapsed_time(e0):9.2f} -> {ref.elapsed_time(e1):9.2f} ms", file=sys.stderr)
         if self._swap is not None:
             self._swap.finish()
         self.h_old = new

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TVDN_ABI_VERSION 2
+#define TVDN_ABI_VERSION 3
 
 typedef enum tvdn_dtype { TVDN_F32 = 0, TVDN_F64 = 1 } tvdn_dtype;
 
@@ -169,6 +169,15 @@ typedef struct tvdn_iter_args {
     int32_t accumulate;
     int32_t reserved;
     const void *wrap_recon; /* TVDN_EDGE_WRAP: one plane, current recon of global row 0 (NULL: row row_hi) */
+    /* Row rings (ABI 3; 0 = rows are contiguous, the normal case).  With ring_rows > 0 every recon / accumulator
+     * pointer is the base of a ring buffer of ring_rows row-planes in which row m of the block lives at slot
+     * m % ring_rows; orig_ring_rows is the same for `orig`.  shape[0], row_lo/row_hi and the sweep rows keep their
+     * meaning (row indices of a virtual array that is only partly resident): the caller keeps every row the sweep
+     * touches -- [sweep_lo-1, sweep_hi] and, where an edge mode wraps, its target -- in the ring.  This is how the
+     * out-of-core wavefront schedule keeps R+2 rows per iteration level without ever moving them (the host-side
+     * block loop it replaces upstream: cyTVDN/cyTVDN.py:148-242 on a cube that does not fit). */
+    int64_t ring_rows;
+    int64_t orig_ring_rows;
 } tvdn_iter_args;
 
 int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *args, double *sums_out, void *stream);
@@ -273,10 +282,14 @@ int tvdn_plan(int dtype, int ndim, const int64_t *shape, int fista, int n_slabs,
 int tvdn_copy_to_device(void *dst_device, const void *src_host, size_t bytes, int device);
 int tvdn_copy_to_host(void *dst_host, const void *src_device, size_t bytes, int device);
 
-/* `n` device-to-device copies of `bytes_each` bytes (a multiple of 16; 16-byte aligned, non-overlapping segments)
- * behind one or a few launches.  `dst` / `src` are HOST arrays of device pointers.  For callers that shuffle many
- * row blocks per step (the streamed engines' level windows): asynchronous on `stream`. */
-int tvdn_copy_many(int32_t n, void *const *dst, const void *const *src, int64_t bytes_each, void *stream);
+/* `n` copies of `bytes_each` bytes (a multiple of 16; 16-byte aligned, non-overlapping segments) behind one or a
+ * few launches.  `dst` / `src` are HOST arrays of pointers the device can dereference: HBM, or pinned host memory
+ * (hipHostMalloc / a pinned torch tensor) -- the streamed engines move a chunk's rows of all state arrays across
+ * PCIe with one launch per direction.  max_blocks > 0 caps the workgroups of a launch (they loop over the pieces):
+ * a transfer that waits on PCIe must not occupy the wave slots the sweeps running beside it need; 0 = one
+ * workgroup per 64 KiB piece (HBM to HBM).  Asynchronous on `stream`. */
+int tvdn_copy_many(int32_t n, void *const *dst, const void *const *src, int64_t bytes_each, int32_t max_blocks,
+                   void *stream);
 
 /* Synthetic input (cytvdn_amd/synth.py restated on the device, bit-identical): fills rows
  * [row0, row0+rows) of the GLOBAL cube `shape` into `out` (rows*prod(shape[1:]) elements). */

@@ -30,12 +30,12 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/tvdn.h but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert _lib.lib().tvdn_abi_version() == 2
+    assert _lib.lib().tvdn_abi_version() == 3
 
 
 def test_iter_args_struct_matches_header_layout():
-    # 2 int32 + 4 int64 + 2 int64 + 4 int32 + 2 double + 8 doubles + 3 ptr + 20 ptr + 2 int64 + 2 int32 + 1 ptr (ABI v2)
-    assert ctypes.sizeof(_lib.IterArgs) == 8 + 32 + 16 + 16 + 16 + 64 + 24 + 160 + 16 + 8 + 8
+    # 2 int32 + 4 int64 + 2 int64 + 4 int32 + 2 double + 8 doubles + 3 ptr + 20 ptr + 2 int64 + 2 int32 + 1 ptr (ABI v2) + 2 int64 (ABI v3: row rings)
+    assert ctypes.sizeof(_lib.IterArgs) == 8 + 32 + 16 + 16 + 16 + 64 + 24 + 160 + 16 + 8 + 8 + 16
     assert _lib.IterArgs.shape.offset == 8 and _lib.IterArgs.tk.offset == 72 and _lib.IterArgs.orig.offset == 152
     assert _lib.IterArgs.dprev_in.offset == 304 and _lib.IterArgs.sweep_lo.offset == 336
 

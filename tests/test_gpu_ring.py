@@ -1,0 +1,175 @@
+"""Row rings of tvdn_iterate_fused (tvdn.h, ring_rows / orig_ring_rows): a sweep over arrays of which only a ring of
+row-planes is resident gives the bits of the same sweep over the whole arrays -- every mode, dtype, vector width, both
+boundary conditions, edge rows included.  The out-of-core wavefront schedule is built on exactly this."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tv():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import cytvdn_amd
+    return cytvdn_amd
+
+
+def _fill(a, tensors, mode, _lib, ptr_of):
+    """Point the state fields of `a` at tensors for `mode`; tensors = dict name -> list per axis / tensor."""
+    nd = a.ndim
+    a.orig, a.recon_in, a.recon_out = ptr_of(tensors["orig"]), ptr_of(tensors["r_in"]), ptr_of(tensors["r_out"])
+    for q in range(nd):
+        a.b_in[q] = a.b_out[q] = a.d_in[q] = a.d_out[q] = a.dprev_in[q] = None
+        s1, s2, o1, o2 = (tensors[k][q] for k in ("s1", "s2", "o1", "o2"))
+        if mode == _lib.ITER_PLAIN:
+            a.b_in[q], a.b_out[q] = ptr_of(s1), ptr_of(o1)
+        elif mode == _lib.ITER_FISTA:
+            a.b_in[q], a.d_in[q], a.b_out[q], a.d_out[q] = ptr_of(s1), ptr_of(s2), ptr_of(o1), ptr_of(o2)
+        elif mode == _lib.ITER_FISTA_D:
+            a.dprev_in[q], a.d_in[q], a.d_out[q] = ptr_of(s1), ptr_of(s2), ptr_of(o2)
+        else:
+            a.dprev_in[q], a.d_in[q], a.b_out[q] = ptr_of(s1), ptr_of(s2), ptr_of(o1)
+
+
+@pytest.mark.parametrize("shape,dtype,bc,R", [
+    ((23, 4, 6, 16), np.float32, 2, 4), ((17, 5, 8), np.float64, 2, 3), ((19, 3, 5, 7), np.float32, 2, 5),
+    ((16, 4, 6, 8), np.float64, 0, 4), ((21, 6, 12), np.float32, 0, 2),
+])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_ring_sweeps_equal_the_resident_sweep(shape, dtype, bc, R, mode):
+    import torch
+    from cytvdn_amd import _lib
+    L, ctx = _lib.lib(), _lib.ctx(0)
+    nd, N0 = len(shape), shape[0]
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    rng = np.random.default_rng(5 + mode)
+
+    def rand(scale=1.0):
+        return torch.from_numpy((rng.standard_normal(shape) * scale).astype(dtype)).cuda()
+
+    full = {"orig": rand(4), "r_in": rand(4), "r_out": torch.zeros(shape, dtype=tdt, device="cuda"),
+            "s1": [rand(0.4) for _ in range(nd)], "s2": [rand(0.4) for _ in range(nd)],
+            "o1": [torch.zeros(shape, dtype=tdt, device="cuda") for _ in range(nd)],
+            "o2": [torch.zeros(shape, dtype=tdt, device="cuda") for _ in range(nd)]}
+
+    for k in ("s1", "s2"):          # Jia-Zhao: the axis-0 accumulator of row 0 is identically zero in any real state
+        full[k][0][0].zero_()
+
+    def args():
+        a = _lib.IterArgs(dtype=_lib.dtype_code(np.dtype(dtype)), ndim=nd, row_lo=0, row_hi=N0, lo_mode=_lib.EDGE_BC,
+                          hi_mode=_lib.EDGE_BC, bc_mode=bc, mode=mode, tk=0.37, tk_prev=0.21, accumulate=1)
+        for i, s in enumerate(shape):
+            a.shape[i] = s
+        for q in range(nd):
+            a.clip[q], a.lambda_mu[q] = 0.5 + 0.1 * q, 0.3 - 0.05 * q
+        return a
+
+    # the whole cube in one resident sweep
+    a = args()
+    _fill(a, full, mode, _lib, lambda t: t.data_ptr())
+    sums_full = torch.zeros(3, dtype=torch.float64, device="cuda")
+    _lib.check(L.tvdn_iterate_fused(ctx, C.byref(a), sums_full.data_ptr(), _lib.current_stream(0)))
+    torch.cuda.synchronize()
+
+    # the same cube streamed through rings of R+2 rows (orig: R+1), chunk by chunk.  A periodic wrap needs both ends
+    # resident at once, so periodic cubes are swept away from the two faces only (as the wavefront engine does).
+    lo, hi = (1, N0 - 1) if bc == 0 else (0, N0)
+    cap, ocap = R + 2, R + 1
+    plane = shape[1:]
+
+    def ring(n):
+        return torch.full((n,) + plane, float("nan"), dtype=tdt, device="cuda")
+
+    rings = {"orig": ring(ocap), "r_in": ring(cap), "r_out": ring(cap), "s1": [ring(cap) for _ in range(nd)],
+             "s2": [ring(cap) for _ in range(nd)], "o1": [ring(cap) for _ in range(nd)], "o2": [ring(cap) for _ in range(nd)]}
+    got = {"r_out": torch.zeros(shape, dtype=tdt, device="cuda"), "o1": [torch.zeros(shape, dtype=tdt, device="cuda") for _ in range(nd)],
+           "o2": [torch.zeros(shape, dtype=tdt, device="cuda") for _ in range(nd)]}
+    sums_ring = torch.zeros(3, dtype=torch.float64, device="cuda")
+    for c0 in range(lo, hi, R):
+        c1 = min(c0 + R, hi)
+        for g in range(max(0, c0 - 1), min(N0, c1 + 1)):           # rows the launch reads
+            rings["r_in"][g % cap].copy_(full["r_in"][g])
+            for q in range(nd):
+                rings["s1"][q][g % cap].copy_(full["s1"][q][g])
+                rings["s2"][q][g % cap].copy_(full["s2"][q][g])
+        for g in range(c0, c1):
+            rings["orig"][g % ocap].copy_(full["orig"][g])
+        a = args()
+        a.sweep_lo, a.sweep_hi = c0, c1
+        a.ring_rows, a.orig_ring_rows = cap, ocap
+        if bc == 2:
+            a.hi_mode = _lib.EDGE_ZERO            # what a Jia-Zhao cube whose first row is finite has at its top face
+        _fill(a, rings, mode, _lib, lambda t: t.data_ptr())
+        _lib.check(L.tvdn_iterate_fused(ctx, C.byref(a), sums_ring.data_ptr(), _lib.current_stream(0)))
+        for g in range(c0, c1):
+            got["r_out"][g].copy_(rings["r_out"][g % cap])
+            for q in range(nd):
+                got["o1"][q][g].copy_(rings["o1"][q][g % cap])
+                got["o2"][q][g].copy_(rings["o2"][q][g % cap])
+    torch.cuda.synchronize()
+
+    sl = slice(lo, hi)
+    assert torch.equal(got["r_out"][sl].view(torch.uint8), full["r_out"][sl].view(torch.uint8))
+    writes1 = mode in (_lib.ITER_PLAIN, _lib.ITER_FISTA, _lib.ITER_FISTA_D_TO_PLAIN)
+    writes2 = mode in (_lib.ITER_FISTA, _lib.ITER_FISTA_D)
+    for q in range(nd):
+        if writes1:
+            assert torch.equal(got["o1"][q][sl].view(torch.uint8), full["o1"][q][sl].view(torch.uint8)), ("out1", q)
+        if writes2:
+            assert torch.equal(got["o2"][q][sl].view(torch.uint8), full["o2"][q][sl].view(torch.uint8)), ("out2", q)
+    if bc == 2:     # the sums cover the same rows only then
+        np.testing.assert_allclose(sums_ring.cpu().numpy(), sums_full.cpu().numpy(), rtol=1e-12)
+
+
+def test_ring_argument_checks():
+    import torch
+    from cytvdn_amd import _lib
+    L, ctx = _lib.lib(), _lib.ctx(0)
+    shape = (12, 3, 4, 8)
+    t = [torch.zeros((6,) + shape[1:], dtype=torch.float32, device="cuda") for _ in range(12)]
+    out = torch.zeros(3, dtype=torch.float64, device="cuda")
+    a = _lib.IterArgs(dtype=0, ndim=4, row_lo=0, row_hi=12, lo_mode=0, hi_mode=_lib.EDGE_ZERO, bc_mode=2, mode=_lib.ITER_PLAIN)
+    for i, s in enumerate(shape):
+        a.shape[i] = s
+    a.orig, a.recon_in, a.recon_out = t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr()
+    for q in range(4):
+        a.b_in[q], a.b_out[q] = t[3 + q].data_ptr(), t[7 + q].data_ptr()
+        a.clip[q], a.lambda_mu[q] = 1.0, 0.1
+    a.sweep_lo, a.sweep_hi = 3, 8
+
+    def err():
+        return L.tvdn_last_error().decode()
+
+    a.ring_rows = 6                       # 5 swept rows + the row before + the row after = 7
+    assert L.tvdn_iterate_fused(ctx, C.byref(a), out.data_ptr(), None) == -1 and "cannot hold" in err()
+    a.ring_rows, a.orig_ring_rows = 0, 6
+    assert L.tvdn_iterate_fused(ctx, C.byref(a), out.data_ptr(), None) == -1 and "orig_ring_rows" in err()
+    a.ring_rows, a.orig_ring_rows = 6, 3
+    a.sweep_lo, a.sweep_hi = 3, 7
+    assert L.tvdn_iterate_fused(ctx, C.byref(a), out.data_ptr(), None) == -1 and "orig ring" in err()
+    a.orig_ring_rows = 6
+    a.hi_mode = _lib.EDGE_WRAP
+    assert L.tvdn_iterate_fused(ctx, C.byref(a), out.data_ptr(), None) == -1 and "wrap_recon" in err()
+    a.hi_mode = _lib.EDGE_ZERO
+    assert L.tvdn_iterate_fused(ctx, C.byref(a), out.data_ptr(), _lib.current_stream(0)) == 0
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("shape,dtype,its", [((9, 6, 8, 16), np.float32, [5, 3]), ((11, 10, 12), np.float64, 6)])
+def test_ring_instantiation_on_resident_arrays(tv, monkeypatch, shape, dtype, its):
+    """TVDN_FORCE_RING runs the ring instantiation with a ring as long as the array: the same rows, so the same
+    result as the resident instantiation for a whole denoise."""
+    from cytvdn_amd import synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=3, dtype=dt)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    fn = tv.denoise4D if nd == 4 else tv.denoise3D
+    a = fn(x, mu, its, FISTA=True, quiet=True)
+    monkeypatch.setenv("TVDN_FORCE_RING", "1")
+    b = fn(x, mu, its, FISTA=True, quiet=True)
+    for u, v in zip(a, b):
+        assert np.asarray(u).tobytes() == np.asarray(v).tobytes()

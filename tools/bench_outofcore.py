@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--stages", type=int, default=3)
     ap.add_argument("--engine", default="trapezoid", choices=["trapezoid", "wavefront"])
     ap.add_argument("--check", action="store_true", help="also run in-core and compare bit for bit")
+    ap.add_argument("--no-inplace", action="store_true", help="wavefront: separate old/new host state (19 arrays, not 10)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -48,7 +49,8 @@ def main():
     t0 = time.perf_counter()
     if a.engine == "wavefront":
         from cytvdn_amd.wavefront import WavefrontRunner
-        sr = WavefrontRunner(x, True, 1.0 / lam, (lam / mu).astype(dt), device=0, chunk_rows=a.rows, k=a.k, max_iters=a.iters)
+        sr = WavefrontRunner(x, True, 1.0 / lam, (lam / mu).astype(dt), device=0, chunk_rows=a.rows, k=a.k, max_iters=a.iters,
+                             host_inplace=not a.no_inplace)
     else:
         sr = StagedRunner(x, True, 1.0 / lam, (lam / mu).astype(dt), device=0, block_rows=a.rows, k=a.k, max_iters=a.iters, n_stages=a.stages)
     t_alloc = time.perf_counter() - t0
