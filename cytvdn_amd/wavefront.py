@@ -86,7 +86,7 @@ class WavefrontRunner:
         self.fista = bool(fista)
         self.device = int(device)
         self.k = max(1, int(k))
-        self.R = max(2, int(chunk_rows))
+        self.R = max(1, int(chunk_rows))
         if self.periodic:
             k = min(int(k), own_shape[0])
         self.k = max(1, int(k))

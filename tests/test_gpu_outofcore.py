@@ -54,6 +54,7 @@ def test_staged_early_stop_matches(monkeypatch):
     ((23, 3, 4, 8), "float32", 9, True, 5, 3, 0),             # periodic BC: the cube's two ends are each other's halo
     ((17, 6, 16), "float64", [4, 3], True, 4, 6, 0),
     ((6, 3, 4, 8), "float32", 7, True, 2, 9, 0),              # k capped at the cube height
+    ((15, 3, 4, 8), "float32", 8, True, 1, 5, 0),             # one-row chunks
 ])
 def test_wavefront_periodic(oracle, monkeypatch, shape, dtype, its, fista, rows, k, bc):
     import cytvdn_amd as tv
@@ -81,6 +82,8 @@ def test_wavefront_periodic(oracle, monkeypatch, shape, dtype, its, fista, rows,
     ((9, 2, 5, 7), "float32", 6, True, 2, 8),                 # more levels than rows in the cube
     ((40, 3, 4, 8), "float32", 11, True, 7, 4),
     ((5, 3, 4, 8), "float32", 12, True, 16, 5),               # chunk taller than the cube
+    ((19, 3, 4, 8), "float32", [6, 3], True, 1, 7),           # one-row chunks: rings of three rows per level
+    ((13, 5, 12), "float64", 8, True, 1, 4),
 ])
 def test_wavefront_equals_in_core(oracle, monkeypatch, shape, dtype, its, fista, rows, k):
     """The wavefront (parallelogram) schedule: every row of every iteration level computed once, still bit-identical
