@@ -77,6 +77,7 @@ class RunArgs(C.Structure):
         ("data", C.c_void_p), ("reference", C.c_void_p), ("recon_out", C.c_void_p),
         ("sums_out", C.c_void_p), ("mse_out", C.c_void_p), ("iters_run", C.c_void_p),
         ("devices", C.c_int32 * 16),
+        ("stream_rows", C.c_int32), ("stream_k", C.c_int32),
     ]
 
 

@@ -122,6 +122,10 @@ __device__ __forceinline__ void block_store_partials(const double (&v)[NV], doub
 
 // Makes room for `nblocks` partial rows (grows the scratch buffer; a growth synchronises the device once).
 int ensure_partials(tvdn_ctx *ctx, long long nblocks);
+// tvdn_stream.hip: the out-of-core branch of tvdn_run
+int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_bytes, bool mse, bool wrap, int64_t *rows_out,
+                        int64_t *k_out);
+int run_streamed(const tvdn_run_args *a, int64_t rows, int64_t k);
 int launch_finalize(tvdn_ctx *ctx, int nblocks, int nv, double *out, hipStream_t s, bool accumulate = false);
 
 // ---- 16-byte packs ---------------------------------------------------------------------------

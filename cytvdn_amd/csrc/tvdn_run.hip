@@ -425,6 +425,12 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
         return TVDN_ERR_UNSUPPORTED;
     }
     TVDN_REQUIRE(a->bc_mode == 0 || a->bc_mode == 2, "bc_mode must be 0 or 2, got %d", a->bc_mode);
+    TVDN_REQUIRE(a->stream_rows >= 0 && a->stream_k >= 0 && (a->stream_rows > 0) == (a->stream_k > 0),
+                 "stream_rows and stream_k must both be 0 or both be positive");
+    if (a->stream_rows > 0) {
+        TVDN_REQUIRE(a->n_devices <= 1, "a streamed run uses one device (slabs x streaming: cytvdn_amd.denoise_slabs(staged=...))");
+        return tvdn::run_streamed(a, a->stream_rows, a->stream_k);
+    }
     {   // say clearly when the slabs cannot fit, instead of failing somewhere inside hipMalloc
         const int world = a->n_devices > 0 ? a->n_devices : 1;
         TVDN_REQUIRE(a->shape[0] >= world, "axis 0 (%lld rows) cannot be cut into %d slabs", (long long)a->shape[0], world);
@@ -433,6 +439,16 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
         if (rc) return rc;
         int same = 0;  // slabs sharing the first device share its HBM
         for (int i = 0; i < world; ++i) same += (a->n_devices == 0 || a->devices[i] == a->devices[0]) ? 1 : 0;
+        if (pl.bytes_per_slab * same > (int64_t)(0.9 * (double)pl.free_bytes) && world == 1 && a->bc_mode == TVDN_BC_JIA_ZHAO) {
+            // one device, state beyond its HBM: stream it (tvdn_stream.hip)
+            size_t row_bytes = a->dtype == TVDN_F32 ? 4 : 8;
+            for (int i = 1; i < a->ndim; ++i) row_bytes *= (size_t)a->shape[i];
+            int64_t rows = 0, k = 0;
+            const int rc2 = tvdn::choose_stream_shape(a->ndim, a->shape[0], row_bytes, (size_t)pl.free_bytes,
+                                                      a->mse_out && a->reference, true, &rows, &k);
+            if (rc2) return rc2;
+            return tvdn::run_streamed(a, rows, k);
+        }
         if (pl.bytes_per_slab * same > pl.free_bytes) {
             tvdn::set_error("state of %lld bytes per slab x %d slab(s) on device %d exceeds its %lld free bytes of HBM: use more "
                             "devices (fewest slabs that fit one each: %d) or the streamed engines (cytvdn_amd.plan_run)",

@@ -192,20 +192,26 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
     return recon, b_norm, delta_recon
 
 
-def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, stop, reference_data, BC_mode, quiet):
+def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, stop, reference_data, BC_mode, quiet,
+                     stream=None):
     """`device=[0, 1, ...]`: one slab of axis 0 per listed GPU inside THIS process -- the library's whole-loop entry
     (tvdn_run, csrc/tvdn_run.hip): state in HBM of each device, halo rows by peer copies over xGMI under the interior
     sweeps, global sums, global stopping rule.  No torchrun, no RCCL; every slab must fit its device (tvdn_plan says so
-    when not).  The process-per-GPU form over RCCL is cytvdn_amd.distributed.denoise_slabs."""
+    when not).  The process-per-GPU form over RCCL is cytvdn_amd.distributed.denoise_slabs.
+    `stream=(rows, k)` (one device): the library's out-of-core branch instead (csrc/tvdn_stream.hip) -- the cube and the
+    result page-locked in place, the wavefront schedule in C++."""
     import ctypes as C
     from . import _lib
     dtype = datacube.dtype
     nd = datacube.ndim
     n = n_fista + n_plain
-    if not quiet:
+    if not quiet and stream is None:
         print(f"Cutting axis 0 into {len(devices)} slabs on devices {devices} (one process, peer copies)", flush=True)
     a = _lib.RunArgs(dtype=_lib.dtype_code(dtype), ndim=nd, bc_mode=int(BC_mode), device=devices[0], n_fista=n_fista,
-                     n_plain=n_plain, use_stop=int(stop is not None), stop=float(stop or 0.0), n_devices=len(devices))
+                     n_plain=n_plain, use_stop=int(stop is not None), stop=float(stop or 0.0),
+                     n_devices=len(devices) if stream is None else 0)
+    if stream is not None:
+        a.stream_rows, a.stream_k = int(stream[0]), int(stream[1])
     if len(devices) > len(a.devices):
         raise ValueError(f"at most {len(a.devices)} devices")
     for i, d in enumerate(devices):
@@ -240,11 +246,19 @@ def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, sto
 
 def _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device, BC_mode=2,
                    reference_data=None, out=None, exact_wrap=False):
-    """Host-resident state, wavefront schedule (cytvdn_amd/wavefront.py): anything but a stopping rule."""
+    """Host-resident state, wavefront schedule: anything but a stopping rule.  An in-memory cube with Jia-Zhao
+    boundaries goes through the library's own streamed loop (tvdn_run, csrc/tvdn_stream.hip: no interpreter between
+    the launches -- 87 against 69 Gvoxel-iters/s on the config-2 cube); cubes on disk, periodic boundaries and
+    TVDN_STREAM_ENGINE=python take cytvdn_amd/wavefront.py, the same schedule driven from Python."""
     from .wavefront import WavefrontRunner
     dtype = datacube.dtype
     n_total = n_fista + n_plain
     rows, k = plan
+    if isinstance(datacube, np.ndarray) and out is None and int(BC_mode) == 2 \
+            and os.environ.get("TVDN_STREAM_ENGINE", "native") == "native":
+        return _run_device_list([device], datacube, lambdaInv, lam_mu, n_fista if FISTA else 0,
+                                n_plain if unaccelerated else 0, None, reference_data, BC_mode, True,
+                                stream=(max(1, rows), max(1, k)))
     wr = WavefrontRunner(datacube, FISTA, lambdaInv, lam_mu, device=device, chunk_rows=rows, k=k, max_iters=n_total,
                          bc_mode=int(BC_mode), reference=reference_data, exact_wrap=exact_wrap)
     wr.run(n_fista if FISTA else 0, n_plain if unaccelerated else 0)

@@ -250,6 +250,15 @@ typedef struct tvdn_run_args {
     double *mse_out;
     int32_t *iters_run;
     int32_t devices[TVDN_MAX_DEVICES];
+    /* Out-of-core (ABI 3).  A cube whose state does not fit its ONE device is streamed through it from pinned host
+     * memory with the wavefront schedule: chunks of stream_rows rows, stream_k iterations per PCIe round trip, every
+     * row of every iteration swept once (row rings, tvdn_iter_args.ring_rows); bit-identical to the resident run.
+     * 0 / 0: decided here -- resident when it fits, else the deepest stream_k whose rings fit 70 % of the free HBM;
+     * both > 0: stream with exactly these (testing, tuning).  Jia-Zhao boundaries; with use_stop one iteration per
+     * pass.  `data` / `recon_out` / `reference` are page-locked in place for the duration of the call when the
+     * runtime allows it (else staged through pinned copies); recon_out doubles as the host copy of the state. */
+    int32_t stream_rows;
+    int32_t stream_k;
 } tvdn_run_args;
 
 int tvdn_run(const tvdn_run_args *args);

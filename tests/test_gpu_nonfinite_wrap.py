@@ -132,11 +132,13 @@ def test_tvdn_run_device_list_nonfinite_first_row(oracle, devices):
 
 @pytest.mark.parametrize("env,val", [("TVDN_WAVEFRONT", "3,2"), ("TVDN_WAVEFRONT", "16,8"), ("TVDN_STAGED", "4,2"),
                                      ("TVDN_STAGED", "5,1"), ("TVDN_HBM_LIMIT", "2M")])
-def test_streamed_engines_nonfinite_first_row(oracle, monkeypatch, env, val):
+@pytest.mark.parametrize("engine", ["native", "python"])
+def test_streamed_engines_nonfinite_first_row(oracle, monkeypatch, env, val, engine):
     import cytvdn_amd as tv
     for k in ("TVDN_WAVEFRONT", "TVDN_STAGED", "TVDN_HBM_LIMIT"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv(env, val)
+    monkeypatch.setenv("TVDN_STREAM_ENGINE", engine)   # wavefront schedule: the library's loop, or the Python one
     for shape, dtype in (((14, 3, 4, 8), np.float32), ((11, 6, 16), np.float64)):
         dt = np.dtype(dtype)
         nd = len(shape)

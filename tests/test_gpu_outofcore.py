@@ -85,9 +85,12 @@ def test_wavefront_periodic(oracle, monkeypatch, shape, dtype, its, fista, rows,
     ((19, 3, 4, 8), "float32", [6, 3], True, 1, 7),           # one-row chunks: rings of three rows per level
     ((13, 5, 12), "float64", 8, True, 1, 4),
 ])
-def test_wavefront_equals_in_core(oracle, monkeypatch, shape, dtype, its, fista, rows, k):
+@pytest.mark.parametrize("engine", ["native", "python"])
+def test_wavefront_equals_in_core(oracle, monkeypatch, shape, dtype, its, fista, rows, k, engine):
     """The wavefront (parallelogram) schedule: every row of every iteration level computed once, still bit-identical
-    (recon and the b_norm / delta_recon / MSE traces)."""
+    (recon and the b_norm / delta_recon / MSE traces) -- driven by the library's own loop (tvdn_run, stream_rows /
+    stream_k) and by cytvdn_amd/wavefront.py."""
+    monkeypatch.setenv("TVDN_STREAM_ENGINE", engine)
     import cytvdn_amd as tv
     from cytvdn_amd import synth
     dt = np.dtype(dtype)

@@ -1,0 +1,115 @@
+"""tvdn_run's out-of-core branch (csrc/tvdn_stream.hip): a cube streamed through the GPU from pinned host memory with the
+wavefront schedule gives the bits of the resident run -- recon and the b_norm / delta_recon traces -- for every schedule
+(FISTA, hybrid, unaccelerated, stopping rule), dtype, rank, chunk height and depth, with non-finite first rows, and the
+MSE trace within summation-order tolerance."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from golden_util import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(x, mu, n_f, n_p, stop=None, ref=None, stream=None, device=0):
+    from cytvdn_amd import _lib
+    dt = x.dtype
+    nd = x.ndim
+    lam = mu / dt.type(32.0 if nd == 4 else 16.0)
+    n = n_f + n_p
+    a = _lib.RunArgs(dtype=_lib.dtype_code(dt), ndim=nd, bc_mode=2, device=device, n_fista=n_f, n_plain=n_p,
+                     use_stop=int(stop is not None), stop=float(stop or 0.0))
+    if stream:
+        a.stream_rows, a.stream_k = stream
+    for i, s in enumerate(x.shape):
+        a.shape[i] = s
+    for q in range(nd):
+        a.clip[q] = float((1.0 / lam)[q])
+        a.lambda_mu[q] = float((lam / mu).astype(dt)[q])
+    recon = np.empty_like(x)
+    sums = np.zeros((max(n, 1), 3))
+    mse = np.zeros(n + 1)
+    ran = C.c_int32(0)
+    a.data, a.recon_out, a.sums_out = x.ctypes.data, recon.ctypes.data, sums.ctypes.data
+    if ref is not None:
+        a.reference, a.mse_out = ref.ctypes.data, mse.ctypes.data
+    a.iters_run = C.addressof(ran)
+    _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+    return recon, sums[:n], mse, ran.value
+
+
+@pytest.mark.parametrize("shape,dtype,n_f,n_p,rows,k", [
+    ((23, 3, 4, 8), np.float32, 9, 0, 5, 3),
+    ((23, 3, 4, 8), np.float32, 9, 0, 2, 9),          # deeper than a chunk
+    ((23, 3, 4, 8), np.float32, 5, 4, 4, 4),          # hybrid: the d -> b transition between passes and inside one
+    ((23, 3, 4, 8), np.float32, 5, 4, 3, 9),
+    ((17, 6, 16), np.float64, 0, 7, 3, 5),            # unaccelerated, 3-D, f64
+    ((17, 6, 16), np.float64, 7, 0, 17, 2),
+    ((9, 2, 5, 7), np.float32, 6, 0, 2, 8),           # scalar packs; more levels than rows
+    ((5, 3, 4, 8), np.float32, 12, 0, 16, 5),         # chunk taller than the cube
+    ((19, 3, 4, 8), np.float32, 6, 3, 1, 7),          # one-row chunks
+    ((40, 4, 8, 16), np.float32, 11, 0, 8, 128),      # k beyond the iteration count: one pass
+])
+def test_streamed_run_equals_resident_run(shape, dtype, n_f, n_p, rows, k):
+    from cytvdn_amd import synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=61, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    want = _run(x, mu, n_f, n_p)
+    x_before = x.copy()
+    got = _run(x, mu, n_f, n_p, stream=(rows, k))
+    assert bits_equal(x, x_before)                       # the input is page-locked in place, never written
+    assert bits_equal(got[0], want[0])
+    assert got[3] == want[3] == n_f + n_p
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-12)   # f64 sums: per-launch partials added in another order
+
+
+@pytest.mark.parametrize("shape,dtype,n_f,n_p,stop,rows,k", [
+    ((12, 5, 8, 12), np.float32, 0, 40, 0.02, 4, 6),
+    ((11, 3, 7, 9), np.float64, 30, 6, 0.03, 3, 4),
+])
+def test_streamed_run_with_stopping_rule(shape, dtype, n_f, n_p, stop, rows, k):
+    """With a stopping rule every pass is one iteration deep; both phases and the zero tails as the resident run."""
+    from cytvdn_amd import synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=31, dtype=dt)
+    mu = np.array([1.0, 1.0, 0.5, 0.5][:nd], dt)
+    want = _run(x, mu, n_f, n_p, stop=stop)
+    got = _run(x, mu, n_f, n_p, stop=stop, stream=(rows, k))
+    assert 0 < want[3] < n_f + n_p                     # the rule did cut the run short
+    assert got[3] == want[3]
+    assert bits_equal(got[0], want[0])
+    assert np.array_equal(got[1][:, 2] != 0, want[1][:, 2] != 0)
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-12)
+
+
+def test_streamed_run_mse_trace_and_nonfinite_first_row():
+    from cytvdn_amd import synth
+    dt = np.dtype(np.float32)
+    shape = (14, 3, 6, 8)
+    x = synth.cube(shape, seed=7, dtype=dt) + dt.type(0.5)
+    ref = synth.cube(shape, seed=7, dtype=dt, kind="mean")
+    mu = np.array([1.0, 0.8, 0.5, 0.6], dt)
+    want = _run(x, mu, 6, 2, ref=ref)
+    got = _run(x, mu, 6, 2, ref=ref, stream=(3, 4))
+    assert bits_equal(got[0], want[0])
+    np.testing.assert_allclose(got[2], want[2], rtol=1e-6)
+    # an Inf in the cube's first row turns the wrapped axis-0 accumulator into NaN upstream (anisotropic.pyx:65-73):
+    # the streamed run keeps row 0 of every level aside and must reproduce the resident run's NaN pattern
+    x[0, 1, 2, 3] = np.inf
+    want = _run(x, mu, 5, 0)
+    got = _run(x, mu, 5, 0, stream=(4, 3))
+    assert np.isnan(want[0]).any()
+    assert bits_equal(got[0], want[0])
+
+
+def test_streamed_run_argument_checks():
+    from cytvdn_amd import _lib, synth
+    dt = np.dtype(np.float32)
+    x = synth.cube((6, 3, 4, 8), seed=1, dtype=dt)
+    mu = np.array([1.0, 0.8, 0.5, 0.6], dt)
+    with pytest.raises(ValueError, match="both be 0 or both"):
+        _run(x, mu, 2, 0, stream=(4, 0))
