@@ -6,6 +6,7 @@
 // tvdn_iterate_fused launches, so the bits are those of the resident engine.  Upstream has no counterpart: its
 // arrays never leave the host (cyTVDN/cyTVDN.py:148-242 is the loop this replaces for cubes beyond HBM).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <memory>
 #include <thread>
@@ -160,6 +161,7 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
 
 int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
 {
+    const auto t_start = std::chrono::steady_clock::now();
     const int nd = a->ndim;
     const size_t item = a->dtype == TVDN_F32 ? 4 : 8;
     size_t plane = 1;
@@ -301,6 +303,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
     };
 
     // ---- one pass: `kk` iteration levels over the whole cube ------------------------------------------------------------
+    const int down_blocks = getenv("TVDN_STREAM_DOWN_BLOCKS") ? atoi(getenv("TVDN_STREAM_DOWN_BLOCKS")) : 0;
     bool d_form = fista;
     double tk_prev = 0.0;
     int done = 0;
@@ -429,10 +432,24 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
                 TVDN_HIP(hipStreamWaitEvent(st.down, out_ready[h], 0));
                 const size_t off = (size_t)lo * row_bytes, len = (size_t)(hi - lo) * row_bytes;
                 i = 0;
-                TVDN_HIP(hipMemcpyAsync(recon_h.p + off, outbox[h][i++], len, hipMemcpyDeviceToHost, st.down));
-                for (int q = 0; q < nd; ++q)
-                    for (int s = 0; s < n_out_state; ++s)
-                        TVDN_HIP(hipMemcpyAsync(state_h[(size_t)q * 2 + s].p + off, outbox[h][i++], len, hipMemcpyDeviceToHost, st.down));
+                if (down_blocks > 0 && len % 16 == 0) {  // measurement knob: one capped copy launch writing pinned memory
+                    cdst.clear();
+                    csrc.clear();
+                    cdst.push_back(recon_h.p + off);
+                    csrc.push_back(outbox[h][i++]);
+                    for (int q = 0; q < nd; ++q)
+                        for (int s = 0; s < n_out_state; ++s) {
+                            cdst.push_back(state_h[(size_t)q * 2 + s].p + off);
+                            csrc.push_back(outbox[h][i++]);
+                        }
+                    rc2 = tvdn_copy_many((int32_t)cdst.size(), cdst.data(), csrc.data(), (int64_t)len, down_blocks, st.down);
+                    if (rc2) return rc2;
+                } else {
+                    TVDN_HIP(hipMemcpyAsync(recon_h.p + off, outbox[h][i++], len, hipMemcpyDeviceToHost, st.down));
+                    for (int q = 0; q < nd; ++q)
+                        for (int s = 0; s < n_out_state; ++s)
+                            TVDN_HIP(hipMemcpyAsync(state_h[(size_t)q * 2 + s].p + off, outbox[h][i++], len, hipMemcpyDeviceToHost, st.down));
+                }
                 TVDN_HIP(hipEventRecord(out_free[h], st.down));
                 out_free_set[h] = true;
             }
@@ -465,6 +482,8 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
         stop = delta < a->stop;
         return TVDN_OK;
     };
+    TVDN_HIP(hipStreamSynchronize(st.main));
+    const auto t_passes = std::chrono::steady_clock::now();
     if (!a->use_stop) {
         for (int i = 0; i < n_total;) {  // a pass may hold the last FISTA iterations and the first unaccelerated ones
             const int kk = (int)std::min<int64_t>(K, n_total - i);
@@ -488,6 +507,11 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
         }
     }
 
+    if (getenv("TVDN_STREAM_TIMING")) {  // measurement aid: set-up (page-locking, first touch, rings) apart from the passes
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "tvdn_run streamed: rows %lld k %lld, set-up %.3f s, passes %.3f s\n", (long long)R, (long long)K,
+                std::chrono::duration<double>(t_passes - t_start).count(), std::chrono::duration<double>(now - t_passes).count());
+    }
     // ---- results home -------------------------------------------------------------------------------------------------------
     if (recon_h.owned) parallel_copy(a->recon_out, recon_h.p, cube_bytes);
     if (n_total > 0) TVDN_HIP(hipMemcpy(a->sums_out, sums_d.p, sizeof(double) * 3 * (size_t)n_total, hipMemcpyDeviceToHost));

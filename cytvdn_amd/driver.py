@@ -247,9 +247,9 @@ def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, sto
 def _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device, BC_mode=2,
                    reference_data=None, out=None, exact_wrap=False):
     """Host-resident state, wavefront schedule: anything but a stopping rule.  An in-memory cube with Jia-Zhao
-    boundaries goes through the library's own streamed loop (tvdn_run, csrc/tvdn_stream.hip: no interpreter between
-    the launches -- 87 against 69 Gvoxel-iters/s on the config-2 cube); cubes on disk, periodic boundaries and
-    TVDN_STREAM_ENGINE=python take cytvdn_amd/wavefront.py, the same schedule driven from Python."""
+    boundaries goes through the library's own streamed loop (tvdn_run, csrc/tvdn_stream.hip; same rate as the
+    Python-driven one, measured); cubes on disk, periodic boundaries and TVDN_STREAM_ENGINE=python take
+    cytvdn_amd/wavefront.py, the same schedule driven from Python."""
     from .wavefront import WavefrontRunner
     dtype = datacube.dtype
     n_total = n_fista + n_plain
