@@ -18,6 +18,7 @@ namespace tvdn {
 namespace {
 
 constexpr int kHostThreads = 8;
+constexpr size_t kPinInPlaceMin = size_t(256) << 20;  // bytes from which a caller's array is page-locked in place
 
 void parallel_copy(void *dst, const void *src, size_t bytes)  // src == nullptr: zero fill
 {
@@ -43,6 +44,9 @@ struct HostArr {
     bool registered = false, owned = false;
     int pin_in_place(void *user, size_t bytes)
     {
+        // Only arrays big enough to own their pages: page-locking works on whole pages, and two small arrays of the
+        // caller may share one (overlapping registrations).  Small cubes are staged through pinned copies instead.
+        if (bytes < kPinInPlaceMin) return alloc(bytes);
         const hipError_t e = hipHostRegister(user, bytes, hipHostRegisterDefault);
         if (e == hipSuccess) {
             p = (char *)user;

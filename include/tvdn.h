@@ -255,8 +255,9 @@ typedef struct tvdn_run_args {
      * row of every iteration swept once (row rings, tvdn_iter_args.ring_rows); bit-identical to the resident run.
      * 0 / 0: decided here -- resident when it fits, else the deepest stream_k whose rings fit 70 % of the free HBM;
      * both > 0: stream with exactly these (testing, tuning).  Jia-Zhao boundaries; with use_stop one iteration per
-     * pass.  `data` / `recon_out` / `reference` are page-locked in place for the duration of the call when the
-     * runtime allows it (else staged through pinned copies); recon_out doubles as the host copy of the state. */
+     * pass.  `data` / `recon_out` / `reference` are page-locked in place for the duration of the call when they are
+     * large (>= 256 MiB) and the runtime allows it, else staged through pinned copies; recon_out then doubles as
+     * the host copy of the state. */
     int32_t stream_rows;
     int32_t stream_k;
 } tvdn_run_args;
