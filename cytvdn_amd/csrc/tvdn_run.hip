@@ -425,8 +425,9 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
         return TVDN_ERR_UNSUPPORTED;
     }
     TVDN_REQUIRE(a->bc_mode == 0 || a->bc_mode == 2, "bc_mode must be 0 or 2, got %d", a->bc_mode);
-    TVDN_REQUIRE(a->stream_rows >= 0 && a->stream_k >= 0 && (a->stream_rows > 0) == (a->stream_k > 0),
-                 "stream_rows and stream_k must both be 0 or both be positive");
+    const bool stream_auto = a->stream_rows == -1 && a->stream_k == -1;
+    TVDN_REQUIRE(stream_auto || (a->stream_rows >= 0 && a->stream_k >= 0 && (a->stream_rows > 0) == (a->stream_k > 0)),
+                 "stream_rows and stream_k must both be 0 (never stream), both be -1 (stream when needed) or both be positive");
     if (a->stream_rows > 0) {
         TVDN_REQUIRE(a->n_devices <= 1, "a streamed run uses one device (slabs x streaming: cytvdn_amd.denoise_slabs(staged=...))");
         return tvdn::run_streamed(a, a->stream_rows, a->stream_k);
@@ -439,8 +440,10 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
         if (rc) return rc;
         int same = 0;  // slabs sharing the first device share its HBM
         for (int i = 0; i < world; ++i) same += (a->n_devices == 0 || a->devices[i] == a->devices[0]) ? 1 : 0;
-        if (pl.bytes_per_slab * same > (int64_t)(0.9 * (double)pl.free_bytes) && world == 1 && a->bc_mode == TVDN_BC_JIA_ZHAO) {
-            // one device, state beyond its HBM: stream it (tvdn_stream.hip)
+        if (stream_auto && pl.bytes_per_slab * same > (int64_t)(0.9 * (double)pl.free_bytes) && world == 1 &&
+            a->bc_mode == TVDN_BC_JIA_ZHAO) {
+            // asked to decide: one device, state beyond its HBM -> stream it (tvdn_stream.hip; it refuses, before it
+            // touches the caller's arrays, what the host cannot hold either)
             size_t row_bytes = a->dtype == TVDN_F32 ? 4 : 8;
             for (int i = 1; i < a->ndim; ++i) row_bytes *= (size_t)a->shape[i];
             int64_t rows = 0, k = 0;
@@ -451,7 +454,7 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
         }
         if (pl.bytes_per_slab * same > pl.free_bytes) {
             tvdn::set_error("state of %lld bytes per slab x %d slab(s) on device %d exceeds its %lld free bytes of HBM: use more "
-                            "devices (fewest slabs that fit one each: %d) or the streamed engines (cytvdn_amd.plan_run)",
+                            "devices (fewest slabs that fit one each: %d) or the streamed engines (stream_rows / stream_k; cytvdn_amd.plan_run)",
                             (long long)pl.bytes_per_slab, same, a->n_devices > 0 ? a->devices[0] : a->device,
                             (long long)pl.free_bytes, pl.min_slabs);
             return TVDN_ERR_UNSUPPORTED;

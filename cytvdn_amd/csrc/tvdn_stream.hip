@@ -11,6 +11,8 @@
 #include <memory>
 #include <thread>
 
+#include <unistd.h>
+
 #include "tvdn_common.hpp"
 
 namespace tvdn {
@@ -119,6 +121,42 @@ struct DevMem {
     }
 };
 
+// Host memory a streamed run may count on: what the kernel calls available, never more than the machine has, and
+// never more than the control group of the process still allows.  0 = could not be determined.
+size_t host_available_bytes()
+{
+    size_t avail = 0;
+    const long pages = sysconf(_SC_PHYS_PAGES), page = sysconf(_SC_PAGE_SIZE);
+    const size_t physical = (pages > 0 && page > 0) ? (size_t)pages * (size_t)page : 0;
+    if (FILE *f = fopen("/proc/meminfo", "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f)) {
+            unsigned long long kb = 0;
+            if (sscanf(line, "MemAvailable: %llu kB", &kb) == 1) {
+                avail = (size_t)kb * 1024;
+                break;
+            }
+        }
+        fclose(f);
+    }
+    if (avail == 0 || (physical && avail > physical)) avail = physical;
+    auto read_num = [](const char *path, unsigned long long *v) -> bool {
+        FILE *f = fopen(path, "r");
+        if (!f) return false;
+        char buf[64] = {0};
+        const bool ok = fgets(buf, sizeof buf, f) != nullptr && sscanf(buf, "%llu", v) == 1;  // "max" does not parse: no limit
+        fclose(f);
+        return ok;
+    };
+    unsigned long long lim = 0, cur = 0;
+    if ((read_num("/sys/fs/cgroup/memory.max", &lim) && read_num("/sys/fs/cgroup/memory.current", &cur)) ||
+        (read_num("/sys/fs/cgroup/memory/memory.limit_in_bytes", &lim) && read_num("/sys/fs/cgroup/memory/memory.usage_in_bytes", &cur))) {
+        const size_t room = lim > cur ? (size_t)(lim - cur) : 0;
+        if (room < avail) avail = room;
+    }
+    return avail;
+}
+
 // n row-plane copies inside HBM: one streaming launch when the rows are 16-byte multiples, the runtime's copies otherwise
 int copy_rows(std::vector<void *> &dst, std::vector<void *> &src, size_t row_bytes, hipStream_t s)
 {
@@ -183,6 +221,16 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
     TVDN_REQUIRE(R >= 1 && K >= 1, "stream_rows and stream_k must be >= 1");
     if (a->use_stop) K = 1;  // the stopping rule needs a decision after every iteration: one level per pass
     K = std::min<int64_t>(K, std::max<int64_t>(1, n_total));
+    {   // BEFORE anything of the caller's is touched: can the host hold the state at all?  (page-locked: it cannot swap)
+        const double need = (double)((size_t)nd * n_state + 3) * (double)cube_bytes;
+        const size_t avail = host_available_bytes();
+        if (avail == 0 || need > 0.8 * (double)avail) {
+            set_error("a streamed run of this cube needs %.0f bytes of page-locked host memory, which exceeds what the host has "
+                      "available (%zu bytes, of which 80 %% are used at most): cut it into slabs over several nodes (cytvdn_amd.plan_run)",
+                      need, avail);
+            return TVDN_ERR_UNSUPPORTED;
+        }
+    }
     TVDN_HIP(hipSetDevice(device));
 
     // Jia-Zhao wrap at the top face: exact (TVDN_EDGE_WRAP, row 0 of every level kept aside) when row 0 is not finite

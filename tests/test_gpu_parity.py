@@ -454,3 +454,9 @@ def test_tvdn_plan_and_the_misfit_message(tv):
     assert L.tvdn_run(C.byref(a)) == -2
     msg = L.tvdn_last_error().decode()
     assert "exceeds" in msg and "plan_run" in msg
+    # asked to stream when needed (-1 / -1), the same cube is refused as well -- its 5.6 TiB of state exceed the host's
+    # memory -- and again before any of the caller's arrays is touched (x has four elements)
+    a.stream_rows = a.stream_k = -1
+    assert L.tvdn_run(C.byref(a)) == -2
+    msg = L.tvdn_last_error().decode()
+    assert "host memory" in msg and "exceeds" in msg

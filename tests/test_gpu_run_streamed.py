@@ -111,5 +111,11 @@ def test_streamed_run_argument_checks():
     dt = np.dtype(np.float32)
     x = synth.cube((6, 3, 4, 8), seed=1, dtype=dt)
     mu = np.array([1.0, 0.8, 0.5, 0.6], dt)
-    with pytest.raises(ValueError, match="both be 0 or both"):
+    with pytest.raises(ValueError, match="must both be 0"):
         _run(x, mu, 2, 0, stream=(4, 0))
+    with pytest.raises(ValueError, match="must both be 0"):
+        _run(x, mu, 2, 0, stream=(-1, 3))
+    # -1 / -1 = "stream when needed": this cube fits, so the resident engine runs
+    want = _run(x, mu, 3, 0)
+    got = _run(x, mu, 3, 0, stream=(-1, -1))
+    assert bits_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
