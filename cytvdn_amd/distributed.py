@@ -10,6 +10,8 @@ global stopping criterion.  Launch with torchrun (RCCL over xGMI); every rank ca
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -130,6 +132,13 @@ def _denoise_slabs_staged(my_rows, lay, dtype, mu, lam, FISTA, unacc, n_f, n_p, 
     rows, k = int(staged[0]), int(staged[1])
     n = n_f + n_p
     own = my_rows.cpu().numpy() if isinstance(my_rows, torch.Tensor) else np.ascontiguousarray(my_rows)
+    # every rank keeps its slab's state (plus k halo rows per side) page-locked: refuse what this host cannot hold for
+    # the ranks it runs, before anything is allocated
+    from .planner import check_host_fits
+    nd = own.ndim
+    per_rank = (3 + 2 * nd * (2 if FISTA else 1)) * (own.shape[0] + 2 * k) * int(np.prod(own.shape[1:])) * own.dtype.itemsize
+    check_host_fits(dict(mode="slabs+staged", k=k, host_bytes_per_rank=per_rank),
+                    ranks_on_host=int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if stop is None and lay.bc_mode == 2 and not (len(staged) > 2 and staged[2] == "trapezoid"):
         # no per-iteration host decision: the wavefront schedule (every row of every level swept once)
         wr = WavefrontRunner(own, FISTA, 1.0 / lam, (lam / mu).astype(dtype), device=device, chunk_rows=rows,

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from .engine import HipBackend, SlabLayout, SlabRunner, hbm_plan
-from .planner import plan_run
+from .planner import check_host_fits, plan_run
 
 try:  # tqdm is what upstream shows (cyTVDN.py:148-152); it is optional here
     from tqdm import tqdm as _tqdm
@@ -106,6 +106,14 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
     if plan["mode"] == "does-not-fit" and not (wf or st):
         raise MemoryError(f"cube of shape {datacube.shape} cannot be streamed through {_fmt_bytes(plan['hbm_bytes'])} "
                           f"of HBM: {plan['why']}")
+    if wf or st or plan["mode"] in ("wavefront", "trapezoid"):
+        # the streamed engines keep the whole state page-locked on the host: refuse what the host cannot hold BEFORE
+        # anything is allocated (a host driven out of memory takes every process on it down)
+        forced = dict(plan)
+        if plan.get("host_bytes_per_rank") is None:     # engine forced by TVDN_WAVEFRONT / TVDN_STAGED on a cube that fits
+            forced.update(mode="streamed (forced)", k=None,
+                          host_bytes_per_rank=(3 + 2 * nd * (2 if FISTA else 1)) * int(np.prod(datacube.shape)) * dtype.itemsize)
+        check_host_fits(forced)
     if stop is None and (wf or (plan["mode"] == "wavefront" and not st)):
         rows_k = tuple(int(v) for v in wf.split(",")) if wf else (plan["chunk_rows"], plan["k"])
         if not quiet:

@@ -54,6 +54,65 @@ def hbm_available(device: int = 0, hbm_bytes: int = None):
     return free
 
 
+def host_available():
+    """Bytes of host memory a streamed run may pin: what the kernel calls available, never more than the machine has,
+    never more than the process's control group still allows; TVDN_HOST_LIMIT caps it (tests).  None: unknown.
+    Same arithmetic as the library's own check (csrc/tvdn_stream.hip, host_available_bytes)."""
+    avail = None
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    avail = int(line.split()[1]) * 1024
+                    break
+    except OSError:
+        pass
+    try:
+        physical = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+        if physical > 0 and (avail is None or avail > physical):
+            avail = physical
+    except (ValueError, OSError):
+        pass
+
+    def num(path):
+        try:
+            with open(path) as f:
+                return int(f.read().split()[0])
+        except (OSError, ValueError, IndexError):        # "max" does not parse: no limit
+            return None
+
+    for lim_p, cur_p in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                         ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        lim, cur = num(lim_p), num(cur_p)
+        if lim is not None and cur is not None:
+            room = max(0, lim - cur)
+            avail = room if avail is None else min(avail, room)
+            break
+    cap = os.environ.get("TVDN_HOST_LIMIT")
+    if cap:
+        cap = _parse_bytes(cap)
+        avail = cap if avail is None else min(avail, cap)
+    return avail
+
+
+HOST_FRACTION = 0.8       # of host_available() a streamed run's pinned state may take
+
+
+def check_host_fits(plan: dict, ranks_on_host: int = 1) -> None:
+    """Raise MemoryError when the pinned host state of a streamed plan cannot fit this host: page-locked memory
+    cannot swap, and a host driven out of memory takes every process on it down.  In-core plans always pass."""
+    need = plan.get("host_bytes_per_rank")
+    if not need:
+        return
+    need *= max(1, int(ranks_on_host))
+    avail = host_available()
+    if avail is not None and need > HOST_FRACTION * avail:
+        raise MemoryError(f"streaming this cube needs {need / 2 ** 30:.1f} GiB of page-locked host memory "
+                          f"({plan['mode']}, k = {plan['k']}), which exceeds {HOST_FRACTION:.0%} of the "
+                          f"{avail / 2 ** 30:.1f} GiB this host has available: use more nodes (more slabs), or a "
+                          f"shallower k")
+
+
 def state_arrays(ndim: int, fista: bool) -> int:
     """Arrays of the fused engine's state: orig, recon x2, and per axis three rotating d arrays (FISTA) or two b."""
     return 3 + ndim * (3 if fista else 2)
@@ -147,4 +206,4 @@ def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int =
     return out
 
 
-__all__ = ["plan_run", "hbm_available", "state_arrays", "wavefront_windows"]
+__all__ = ["plan_run", "hbm_available", "host_available", "check_host_fits", "state_arrays", "wavefront_windows"]

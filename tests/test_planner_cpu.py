@@ -53,3 +53,29 @@ def test_limit_knob_and_misfits(monkeypatch):
     assert plan_run((40, 8, 32, 64), "float32", True, 1)["mode"] == "does-not-fit"
     with pytest.raises(TypeError):
         plan_run((4, 4), "float32")
+
+
+def test_host_available_and_the_streamed_run_guard(monkeypatch):
+    """A streamed plan whose pinned host state exceeds 80 % of what the host has available is refused before anything is
+    allocated (page-locked memory cannot swap; a host out of memory takes every process on it down)."""
+    from cytvdn_amd import planner
+    real = planner.host_available()
+    assert real is not None and 2 ** 28 < real < 2 ** 46              # this machine has between 256 MiB and 64 TiB
+    monkeypatch.setenv("TVDN_HOST_LIMIT", "1G")
+    assert planner.host_available() == 2 ** 30
+    plan = planner.plan_run((64, 64, 128, 128), "float32", True, 1, hbm_bytes=2 ** 30)   # 256 MiB per array, 15 arrays
+    assert plan["mode"] == "wavefront" and plan["host_bytes_per_rank"] > 2 ** 30
+    with pytest.raises(MemoryError, match="page-locked host memory"):
+        planner.check_host_fits(plan)
+    monkeypatch.setenv("TVDN_HOST_LIMIT", "64G")
+    if real > 8 * 2 ** 30:
+        planner.check_host_fits(plan)                                  # 2.5-3.5 GiB of state: fine
+    planner.check_host_fits(planner.plan_run((8, 8, 16, 16), "float32", True, 1, hbm_bytes=2 ** 30))   # in-core: nothing to check
+    # eight ranks of BASELINE config 5 on one 3 TB node do not fit with k = 30 halos (3.7 TiB); the check says so
+    monkeypatch.delenv("TVDN_HOST_LIMIT")
+    c5 = planner.plan_run((1024, 1024, 256, 256), "float32", True, 8, hbm_bytes=288 * 10 ** 9)
+    assert c5["mode"] == "slabs+wavefront"
+    monkeypatch.setattr(planner, "host_available", lambda: 3 * 10 ** 12)
+    with pytest.raises(MemoryError):
+        planner.check_host_fits(c5, ranks_on_host=8)
+    planner.check_host_fits(c5, ranks_on_host=4)                       # two such nodes hold it
