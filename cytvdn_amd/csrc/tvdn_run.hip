@@ -410,6 +410,9 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
     TVDN_REQUIRE(a->data && a->recon_out, "data / recon_out is NULL");
     TVDN_REQUIRE(a->sums_out || a->n_fista + a->n_plain == 0, "sums_out is NULL");
     TVDN_REQUIRE(a->n_devices >= 0 && a->n_devices <= TVDN_MAX_DEVICES, "n_devices must be 0..%d", TVDN_MAX_DEVICES);
+    const bool stream_auto = a->stream_rows == -1 && a->stream_k == -1;
+    TVDN_REQUIRE(stream_auto || (a->stream_rows >= 0 && a->stream_k >= 0 && (a->stream_rows > 0) == (a->stream_k > 0)),
+                 "stream_rows and stream_k must both be 0 (never stream), both be -1 (stream when needed) or both be positive");
     {
         int n = 0;
         if (hipGetDeviceCount(&n) != hipSuccess || n < 1) {
@@ -425,9 +428,6 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
         return TVDN_ERR_UNSUPPORTED;
     }
     TVDN_REQUIRE(a->bc_mode == 0 || a->bc_mode == 2, "bc_mode must be 0 or 2, got %d", a->bc_mode);
-    const bool stream_auto = a->stream_rows == -1 && a->stream_k == -1;
-    TVDN_REQUIRE(stream_auto || (a->stream_rows >= 0 && a->stream_k >= 0 && (a->stream_rows > 0) == (a->stream_k > 0)),
-                 "stream_rows and stream_k must both be 0 (never stream), both be -1 (stream when needed) or both be positive");
     if (a->stream_rows > 0) {
         TVDN_REQUIRE(a->n_devices <= 1, "a streamed run uses one device (slabs x streaming: cytvdn_amd.denoise_slabs(staged=...))");
         return tvdn::run_streamed(a, a->stream_rows, a->stream_k);

@@ -148,3 +148,47 @@ def test_empty_cube_needs_no_gpu():
     y = np.zeros((0, 5, 6), np.float64)
     out = tv.denoise3D(y, np.ones(3), [2, 1], reference_data=y.copy(), quiet=True)
     assert len(out) == 4 and out[3].shape == (4,) and out[0].shape == y.shape
+
+
+def test_struct_layouts_match_the_c_header(tmp_path):
+    """The ctypes mirrors against the real thing: a C program built with gcc from include/tvdn.h prints size and field
+    offsets of every struct that crosses the boundary."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "tvdn.h"\n'
+                   '#define P(s, f) printf(#s "." #f " %zu\\n", offsetof(s, f))\n'
+                   'int main(void) {\n'
+                   '  printf("tvdn_iter_args %zu\\n", sizeof(tvdn_iter_args)); P(tvdn_iter_args, wrap_recon); P(tvdn_iter_args, ring_rows);\n'
+                   '  P(tvdn_iter_args, orig_ring_rows); P(tvdn_iter_args, accumulate);\n'
+                   '  printf("tvdn_many_args %zu\\n", sizeof(tvdn_many_args)); P(tvdn_many_args, recon); P(tvdn_many_args, S); P(tvdn_many_args, tk_prev);\n'
+                   '  printf("tvdn_run_args %zu\\n", sizeof(tvdn_run_args)); P(tvdn_run_args, stop); P(tvdn_run_args, data); P(tvdn_run_args, devices);\n'
+                   '  P(tvdn_run_args, stream_rows); P(tvdn_run_args, stream_k); P(tvdn_run_args, n_devices);\n'
+                   '  printf("tvdn_plan_out %zu\\n", sizeof(tvdn_plan_out)); P(tvdn_plan_out, fits); P(tvdn_plan_out, min_slabs);\n'
+                   '  return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    got = dict(line.rsplit(" ", 1) for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    mirrors = {"tvdn_iter_args": _lib.IterArgs, "tvdn_many_args": _lib.ManyArgs, "tvdn_run_args": _lib.RunArgs,
+               "tvdn_plan_out": _lib.PlanOut}
+    for key, val in got.items():
+        name, _, field = key.partition(".")
+        want = getattr(mirrors[name], field).offset if field else ctypes.sizeof(mirrors[name])
+        assert int(val) == want, (key, val, want)
+
+
+@pytest.mark.skipif(not NO_GPU, reason="only meaningful on a box without a GPU")
+def test_tvdn_run_checks_its_arguments_before_it_looks_for_a_device():
+    a = _lib.RunArgs(dtype=0, ndim=4, bc_mode=2, n_fista=1, stream_rows=4, stream_k=0)
+    for i, s in enumerate((4, 3, 4, 8)):
+        a.shape[i] = s
+    x = np.zeros((4, 3, 4, 8), np.float32)
+    sums = np.zeros((1, 3))
+    a.data, a.recon_out, a.sums_out = x.ctypes.data, x.ctypes.data, sums.ctypes.data
+    L = _lib.lib()
+    assert L.tvdn_run(ctypes.byref(a)) == -1 and "must both be 0" in L.tvdn_last_error().decode()
+    a.stream_rows = a.stream_k = -1
+    assert L.tvdn_run(ctypes.byref(a)) == -4 and "no CPU fallback" in L.tvdn_last_error().decode()
