@@ -122,7 +122,9 @@ struct DevMem {
 };
 
 // Host memory a streamed run may count on: what the kernel calls available, never more than the machine has, and
-// never more than the control group of the process still allows.  0 = could not be determined.
+// never more than the memory limit of the process's control group (the limit itself, not limit minus usage: the
+// usage counts page cache the kernel would give back, and a false refusal helps nobody; the check is there to stop
+// requests that are wrong by factors).  0 = could not be determined.
 size_t host_available_bytes()
 {
     size_t avail = 0;
@@ -148,12 +150,9 @@ size_t host_available_bytes()
         fclose(f);
         return ok;
     };
-    unsigned long long lim = 0, cur = 0;
-    if ((read_num("/sys/fs/cgroup/memory.max", &lim) && read_num("/sys/fs/cgroup/memory.current", &cur)) ||
-        (read_num("/sys/fs/cgroup/memory/memory.limit_in_bytes", &lim) && read_num("/sys/fs/cgroup/memory/memory.usage_in_bytes", &cur))) {
-        const size_t room = lim > cur ? (size_t)(lim - cur) : 0;
-        if (room < avail) avail = room;
-    }
+    unsigned long long lim = 0;
+    if (read_num("/sys/fs/cgroup/memory.max", &lim) || read_num("/sys/fs/cgroup/memory/memory.limit_in_bytes", &lim))
+        if (lim > 0 && (size_t)lim < avail) avail = (size_t)lim;
     return avail;
 }
 

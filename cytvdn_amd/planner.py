@@ -56,7 +56,8 @@ def hbm_available(device: int = 0, hbm_bytes: int = None):
 
 def host_available():
     """Bytes of host memory a streamed run may pin: what the kernel calls available, never more than the machine has,
-    never more than the process's control group still allows; TVDN_HOST_LIMIT caps it (tests).  None: unknown.
+    never more than the memory limit of the process's control group (the limit, not limit minus usage: usage counts
+    page cache the kernel would give back); TVDN_HOST_LIMIT caps it (tests).  None: unknown.
     Same arithmetic as the library's own check (csrc/tvdn_stream.hip, host_available_bytes)."""
     avail = None
     try:
@@ -81,12 +82,10 @@ def host_available():
         except (OSError, ValueError, IndexError):        # "max" does not parse: no limit
             return None
 
-    for lim_p, cur_p in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
-                         ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
-        lim, cur = num(lim_p), num(cur_p)
-        if lim is not None and cur is not None:
-            room = max(0, lim - cur)
-            avail = room if avail is None else min(avail, room)
+    for lim_p in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        lim = num(lim_p)
+        if lim is not None and lim > 0:
+            avail = lim if avail is None else min(avail, lim)
             break
     cap = os.environ.get("TVDN_HOST_LIMIT")
     if cap:
