@@ -117,3 +117,59 @@ def test_no_undefined_names_in_the_tree():
     assert len(files) > 40
     problems = [p for f in files for p in undefined_names(f)]
     assert not problems, "\n".join(problems)
+
+
+def test_attributes_used_on_the_binding_module_exist():
+    """Every `_lib.<name>` the package, the bench, the tools and the tests mention is something cytvdn_amd/_lib.py defines
+    (functions, constants, ctypes mirrors): a typo in GPU-only code would otherwise wait for a GPU box to show."""
+    from cytvdn_amd import _lib
+    files = sorted(glob.glob(os.path.join(ROOT, "cytvdn_amd", "*.py")) + glob.glob(os.path.join(ROOT, "tools", "*.py")) +
+                   glob.glob(os.path.join(ROOT, "tests", "*.py")) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")])
+    missing = []
+    for path in files:
+        tree = ast.parse(open(path).read(), filename=path)
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Attribute) and isinstance(node.value, ast.Name) and node.value.id == "_lib" \
+                    and isinstance(node.ctx, ast.Load) and not hasattr(_lib, node.attr):
+                missing.append(f"{os.path.relpath(path, ROOT)}:{node.lineno}: _lib.{node.attr}")
+    assert not missing, "\n".join(missing)
+
+
+def test_fields_set_on_the_argument_structs_exist():
+    """`a.<field> = ...` on an IterArgs / RunArgs / ManyArgs instance silently creates a Python attribute when the field
+    name is wrong (ctypes structures accept it) -- and the library then sees zero.  Keyword arguments of the
+    constructors and attribute stores on names bound to them are checked against the declared fields."""
+    from cytvdn_amd import _lib
+    structs = {"IterArgs": _lib.IterArgs, "RunArgs": _lib.RunArgs, "ManyArgs": _lib.ManyArgs, "PlanOut": _lib.PlanOut}
+    fields = {k: {f[0] for f in v._fields_} for k, v in structs.items()}
+    files = sorted(glob.glob(os.path.join(ROOT, "cytvdn_amd", "*.py")) + glob.glob(os.path.join(ROOT, "tools", "*.py")) +
+                   glob.glob(os.path.join(ROOT, "tests", "*.py")) + [os.path.join(ROOT, "bench.py")])
+    bad = []
+    for path in files:
+        tree = ast.parse(open(path).read(), filename=path)
+        for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+            bindings = []                                 # (line, variable, struct kind or None) in this function
+            for node in ast.walk(fn):
+                if isinstance(node, ast.Assign):
+                    kind = None
+                    if isinstance(node.value, ast.Call):
+                        f = node.value.func
+                        kind = f.attr if isinstance(f, ast.Attribute) else (f.id if isinstance(f, ast.Name) else None)
+                        if kind in structs:
+                            for kw in node.value.keywords:
+                                if kw.arg and kw.arg not in fields[kind]:
+                                    bad.append(f"{os.path.relpath(path, ROOT)}:{node.lineno}: {kind}({kw.arg}=...)")
+                        else:
+                            kind = None
+                    if isinstance(node.value, ast.Attribute) and node.value.attr == "_args":
+                        kind = "IterArgs"                  # `A = self._args`: the engines' persistent argument block
+                    for tgt in node.targets:
+                        if isinstance(tgt, ast.Name):
+                            bindings.append((node.lineno, tgt.id, kind))
+            for node in ast.walk(fn):
+                if isinstance(node, ast.Attribute) and isinstance(node.ctx, ast.Store) and isinstance(node.value, ast.Name):
+                    before = [b for b in bindings if b[1] == node.value.id and b[0] <= node.lineno]
+                    kind = max(before)[2] if before else None      # the binding in force: the latest one above this line
+                    if kind and node.attr not in fields[kind]:
+                        bad.append(f"{os.path.relpath(path, ROOT)}:{node.lineno}: {kind}.{node.attr} = ...")
+    assert not bad, "\n".join(bad)
