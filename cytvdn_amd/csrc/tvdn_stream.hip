@@ -153,6 +153,20 @@ size_t host_available_bytes()
     unsigned long long lim = 0;
     if (read_num("/sys/fs/cgroup/memory.max", &lim) || read_num("/sys/fs/cgroup/memory/memory.limit_in_bytes", &lim))
         if (lim > 0 && (size_t)lim < avail) avail = (size_t)lim;
+    if (const char *e = getenv("TVDN_HOST_LIMIT")) {  // a cap from outside, "64G" / "512M" / bytes (the test-suite sets one)
+        char *end = nullptr;
+        double v = strtod(e, &end);
+        if (end != e && v > 0) {
+            switch (*end) {
+            case 'K': case 'k': v *= 1024.0; break;
+            case 'M': case 'm': v *= 1024.0 * 1024.0; break;
+            case 'G': case 'g': v *= 1024.0 * 1024.0 * 1024.0; break;
+            case 'T': case 't': v *= 1024.0 * 1024.0 * 1024.0 * 1024.0; break;
+            default: break;
+            }
+            if (v < (double)avail) avail = (size_t)v;
+        }
+    }
     return avail;
 }
 
