@@ -29,6 +29,7 @@ EXPORTS = (
     "tvdn_ctx_timing_enable", "tvdn_ctx_timing_read",
     "tvdn_accumulator_update", "tvdn_datacube_update", "tvdn_sum_square_error", "tvdn_iterate_fused",
     "tvdn_synth_fill", "tvdn_run", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many", "tvdn_plan", "tvdn_copy_many",
+    "tvdn_stream_host_need", "tvdn_fista_ratios", "tvdn_iter_mode", "tvdn_roles_bind", "tvdn_roles_advance",
 )
 
 
@@ -126,9 +127,14 @@ def lib():
     L.tvdn_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     L.tvdn_copy_many.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_void_p]
     L.tvdn_synth_fill.argtypes = [C.c_int, C.c_int, i64p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    L.tvdn_stream_host_need.argtypes = [C.POINTER(RunArgs), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.tvdn_fista_ratios.argtypes = [C.c_int32, C.POINTER(C.c_double)]
+    L.tvdn_iter_mode.argtypes = [C.c_int32, C.c_int32]
+    L.tvdn_roles_bind.argtypes = [C.POINTER(ManyArgs), C.c_int32, C.c_double, C.POINTER(IterArgs)]
+    L.tvdn_roles_advance.argtypes = [C.POINTER(ManyArgs), C.c_int32, C.c_double]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header and library out of step
-    if L.tvdn_abi_version() != 3:
+    if L.tvdn_abi_version() != 4:
         raise TvdnError("libtvdn_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -142,6 +148,24 @@ def check(rc: int) -> None:
         if rc == -1:
             raise ValueError(msg)
         raise TvdnError(f"libtvdn_hip status {rc}: {msg}")
+
+
+def fista_ratios(n: int) -> np.ndarray:
+    """(tk-1)/tk_new for iterations 0..n-1: the float64 recurrence of cyTVDN.py:153-156, computed by the library
+    (csrc/tvdn_common.hpp fista_ratios, the one definition every loop in the tree uses).  Host arithmetic: no GPU needed."""
+    n = int(n)
+    out = np.empty(n, np.float64)
+    if n:
+        check(lib().tvdn_fista_ratios(n, out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def iter_mode(use_fista: bool, d_form: bool) -> int:
+    """TVDN_ITER_* of an iteration on the compact state (csrc/tvdn_common.hpp iter_mode)."""
+    m = lib().tvdn_iter_mode(int(bool(use_fista)), int(bool(d_form)))
+    if m < 0:
+        check(m)
+    return m
 
 
 def dtype_code(dt) -> int:

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -66,6 +67,73 @@ inline Geom make_geom(int ndim, const int64_t *shape)
 
 // reference axis -> canonical axis
 inline int canon_axis(int ndim, int ax) { return (ndim == 4 || ax == 0) ? ax : ax + 1; }
+
+// ---- the host side of an iteration, defined ONCE ---------------------------------------------------
+// Every loop in the tree -- tvdn_iterate_many, tvdn_run (resident and streamed), and through the exported
+// tvdn_fista_ratios / tvdn_roles_bind / tvdn_roles_advance the Python engines -- takes its schedule from here.
+
+// (tk-1)/tk_new of iterations 0..n-1: the float64 recurrence of cyTVDN.py:153-156, tk starting at 1.
+inline void fista_ratios(int n, double *out)
+{
+    double tk = 1.0;
+    for (int i = 0; i < n; ++i) {
+        const double tk_new = (1.0 + std::sqrt(1.0 + 4.0 * (tk * tk))) / 2.0;
+        out[i] = (tk - 1.0) / tk_new;
+        tk = tk_new;
+    }
+}
+
+// Which sweep form an iteration takes: FISTA iterations keep the d-form; the first unaccelerated iteration after
+// them converts it to b (hybrid schedule, cyTVDN.py:99-108); later ones ping-pong b.
+inline int iter_mode(bool use_fista, bool d_form)
+{
+    return use_fista ? TVDN_ITER_FISTA_D : (d_form ? TVDN_ITER_FISTA_D_TO_PLAIN : TVDN_ITER_PLAIN);
+}
+
+// Point `it` at the arrays of the iteration about to run (compact state: three rotating arrays per axis).
+inline void roles_bind(const tvdn_many_args &st, bool use_fista, double ratio, tvdn_iter_args &it)
+{
+    it.recon_in = st.recon[st.cur];
+    it.recon_out = st.recon[st.cur ^ 1];
+    it.tk = use_fista ? ratio : 0.0;
+    it.tk_prev = st.tk_prev;
+    for (int q = 0; q < 4; ++q) {
+        it.b_in[q] = it.d_in[q] = it.dprev_in[q] = nullptr;
+        it.b_out[q] = it.d_out[q] = nullptr;
+        if (q >= it.ndim) continue;
+        if (use_fista) {
+            it.d_in[q] = st.S[q][st.i_d]; it.dprev_in[q] = st.S[q][st.i_prev]; it.d_out[q] = st.S[q][st.i_out];
+        } else if (st.d_form) {
+            it.d_in[q] = st.S[q][st.i_d]; it.dprev_in[q] = st.S[q][st.i_prev]; it.b_out[q] = st.S[q][st.i_out];
+        } else {
+            it.b_in[q] = st.S[q][st.i_b]; it.b_out[q] = st.S[q][st.i_bout];
+        }
+    }
+    it.mode = iter_mode(use_fista, st.d_form != 0);
+}
+
+// Make the freshly written arrays current: the role rotation after an iteration of the form roles_bind chose.
+inline void roles_advance(tvdn_many_args &st, bool use_fista, double ratio)
+{
+    st.cur ^= 1;
+    if (use_fista) {
+        const int t = st.i_prev; st.i_prev = st.i_d; st.i_d = st.i_out; st.i_out = t;
+        st.tk_prev = ratio;
+    } else if (st.d_form) {
+        st.i_b = st.i_out; st.i_bout = st.i_prev; st.d_form = 0;  // b now lives where d_k+1 would have gone
+    } else {
+        const int t = st.i_b; st.i_b = st.i_bout; st.i_bout = t;
+    }
+}
+
+inline void roles_reset(tvdn_many_args &st, bool d_form)
+{
+    st.cur = 0;
+    st.i_d = 0; st.i_prev = 1; st.i_out = 2;
+    st.i_b = 0; st.i_bout = 1;
+    st.d_form = d_form ? 1 : 0;
+    st.tk_prev = 0.0;
+}
 
 // ---- context ---------------------------------------------------------------------------------
 // Per-workgroup partial sums of one launch: `partial_cap` rows of kPartialWidth doubles.  The buffer starts at

@@ -562,35 +562,45 @@ extern "C" int tvdn_iterate_many(tvdn_ctx *ctx, tvdn_many_args *st, int32_t n_fi
     tvdn_iter_args it = st->base;
     for (int i = 0; i < n_fista + n_plain; ++i) {
         const bool use_fista = i < n_fista;
-        it.recon_in = st->recon[st->cur];
-        it.recon_out = st->recon[st->cur ^ 1];
-        it.tk = use_fista ? ratios[i] : 0.0;
-        it.tk_prev = st->tk_prev;
-        for (int q = 0; q < nd; ++q) {
-            it.b_in[q] = it.d_in[q] = it.dprev_in[q] = nullptr;
-            it.b_out[q] = it.d_out[q] = nullptr;
-            if (use_fista) {
-                it.d_in[q] = st->S[q][st->i_d]; it.dprev_in[q] = st->S[q][st->i_prev]; it.d_out[q] = st->S[q][st->i_out];
-            } else if (st->d_form) {
-                it.d_in[q] = st->S[q][st->i_d]; it.dprev_in[q] = st->S[q][st->i_prev]; it.b_out[q] = st->S[q][st->i_out];
-            } else {
-                it.b_in[q] = st->S[q][st->i_b]; it.b_out[q] = st->S[q][st->i_bout];
-            }
-        }
-        it.mode = use_fista ? TVDN_ITER_FISTA_D : (st->d_form ? TVDN_ITER_FISTA_D_TO_PLAIN : TVDN_ITER_PLAIN);
+        const double ratio = use_fista ? ratios[i] : 0.0;
+        tvdn::roles_bind(*st, use_fista, ratio, it);
         it.sweep_lo = it.sweep_hi = 0;
         it.accumulate = 0;
         const int rc = tvdn_iterate_fused(ctx, &it, sums_out + 3 * (size_t)i, stream);
         if (rc) return rc;
-        st->cur ^= 1;
-        if (use_fista) {
-            const int t = st->i_prev; st->i_prev = st->i_d; st->i_d = st->i_out; st->i_out = t;
-            st->tk_prev = ratios[i];
-        } else if (st->d_form) {
-            st->i_b = st->i_out; st->i_bout = st->i_prev; st->d_form = 0;
-        } else {
-            const int t = st->i_b; st->i_b = st->i_bout; st->i_bout = t;
-        }
+        tvdn::roles_advance(*st, use_fista, ratio);
     }
+    return TVDN_OK;
+}
+
+// The schedule's host side for callers that drive tvdn_iterate_fused themselves (cytvdn_amd/engine.py): the same three
+// functions tvdn_iterate_many and tvdn_run use (csrc/tvdn_common.hpp).  Pure host arithmetic: no device needed.
+extern "C" int tvdn_fista_ratios(int32_t n, double *out)
+{
+    TVDN_REQUIRE(n >= 0 && (n == 0 || out != nullptr), "bad argument");
+    tvdn::fista_ratios(n, out);
+    return TVDN_OK;
+}
+
+extern "C" int tvdn_iter_mode(int32_t use_fista, int32_t d_form)
+{
+    TVDN_REQUIRE(!use_fista || d_form, "a FISTA iteration cannot follow an unaccelerated one (nor does it upstream)");
+    return tvdn::iter_mode(use_fista != 0, d_form != 0);
+}
+
+extern "C" int tvdn_roles_bind(const tvdn_many_args *st, int32_t use_fista, double ratio, tvdn_iter_args *it)
+{
+    TVDN_REQUIRE(st && it, "NULL argument");
+    TVDN_REQUIRE(it->ndim == 3 || it->ndim == 4, "ndim must be 3 or 4, got %d", it->ndim);
+    TVDN_REQUIRE(!use_fista || st->d_form, "a FISTA iteration cannot follow an unaccelerated one (nor does it upstream)");
+    tvdn::roles_bind(*st, use_fista != 0, ratio, *it);
+    return TVDN_OK;
+}
+
+extern "C" int tvdn_roles_advance(tvdn_many_args *st, int32_t use_fista, double ratio)
+{
+    TVDN_REQUIRE(st != nullptr, "NULL argument");
+    TVDN_REQUIRE(!use_fista || st->d_form, "a FISTA iteration cannot follow an unaccelerated one (nor does it upstream)");
+    tvdn::roles_advance(*st, use_fista != 0, ratio);
     return TVDN_OK;
 }

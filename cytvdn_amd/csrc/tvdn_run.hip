@@ -38,10 +38,9 @@ struct Slab {
     hipEvent_t edge_done = nullptr, halo_done = nullptr;
     DevBuf state;  // ONE allocation: per axis 2-3 rotating arrays, recon x2, orig
     DevBuf ref, sums, mse;
-    char *S[4][3] = {};
-    char *recon[2] = {nullptr, nullptr};
+    tvdn_many_args roles;  // arrays and who plays which role (tvdn_common.hpp roles_bind / roles_advance); .base = the sweep's fixed arguments
     char *orig = nullptr;
-    tvdn_iter_args it;
+    char *recon(int i) const { return (char *)roles.recon[i]; }
     int64_t rows() const { return halo_lo + (g1 - g0) + halo_hi; }
     int64_t row_lo() const { return halo_lo; }
     int64_t row_hi() const { return halo_lo + (g1 - g0); }
@@ -120,11 +119,13 @@ static int run_impl(const tvdn_run_args *a)
         TVDN_HIP(hipMemsetAsync(s.state.p, 0, stride * (size_t)(n_arr - 2), s.main));
         char *base = (char *)s.state.p;
         int k = 0;
+        std::memset(&s.roles, 0, sizeof s.roles);
+        roles_reset(s.roles, fista);
         for (int q = 0; q < nd; ++q)
-            for (int j = 0; j < per_axis; ++j) s.S[q][j] = base + stride * (size_t)(k++);
-        s.recon[1] = base + stride * (size_t)(k++);
+            for (int j = 0; j < per_axis; ++j) s.roles.S[q][j] = base + stride * (size_t)(k++);
+        s.roles.recon[1] = base + stride * (size_t)(k++);
         s.orig = base + stride * (size_t)(k++);
-        s.recon[0] = base + stride * (size_t)(k++);
+        s.roles.recon[0] = base + stride * (size_t)(k++);
         s.sums.device = s.device;
         TVDN_HIP(hipMalloc(&s.sums.p, sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1)));
         TVDN_HIP(hipMemsetAsync(s.sums.p, 0, sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1), s.main));
@@ -158,7 +159,7 @@ static int run_impl(const tvdn_run_args *a)
         Slab &s = sl[r];
         int rc = rows_to_device(s, s.orig, a->data);
         if (rc) return rc;
-        TVDN_HIP(hipMemcpyAsync(s.recon[0], s.orig, (size_t)s.rows() * row_bytes, hipMemcpyDeviceToDevice, s.main));
+        TVDN_HIP(hipMemcpyAsync(s.recon(0), s.orig, (size_t)s.rows() * row_bytes, hipMemcpyDeviceToDevice, s.main));
         if (want_mse) {
             s.ref.device = s.mse.device = s.device;
             TVDN_HIP(hipMalloc(&s.ref.p, (size_t)s.rows() * row_bytes));
@@ -167,8 +168,7 @@ static int run_impl(const tvdn_run_args *a)
             TVDN_HIP(hipMalloc(&s.mse.p, sizeof(double) * (size_t)(n_total + 1)));
             TVDN_HIP(hipMemsetAsync(s.mse.p, 0, sizeof(double) * (size_t)(n_total + 1), s.main));
         }
-        tvdn_iter_args &it = s.it;
-        std::memset(&it, 0, sizeof it);
+        tvdn_iter_args &it = s.roles.base;
         it.dtype = a->dtype;
         it.ndim = nd;
         it.shape[0] = s.rows();
@@ -194,7 +194,7 @@ static int run_impl(const tvdn_run_args *a)
             shp[0] = s.g1 - s.g0;
             for (int i = 1; i < nd; ++i) shp[i] = a->shape[i];
             const size_t off = (size_t)s.row_lo() * row_bytes;
-            int rc = tvdn_sum_square_error(s.ctx, a->dtype, nd, shp, (char *)s.ref.p + off, s.recon[cur] + off,
+            int rc = tvdn_sum_square_error(s.ctx, a->dtype, nd, shp, (char *)s.ref.p + off, s.recon(cur) + off,
                                            (double *)s.mse.p + slot, s.main);
             if (rc) return rc;
         }
@@ -205,30 +205,13 @@ static int run_impl(const tvdn_run_args *a)
         if (rc) return rc;
     }
 
-    int cur = 0, i_d = 0, i_prev = 1, i_out = 2, i_b = 0, i_bout = 1;
-    bool d_form = fista;
-    double tk = 1.0, tk_prev_ratio = 0.0;
     int ran = 0;
+    auto cur_of = [&]() { return (int)sl[0].roles.cur; };  // every slab rotates in lockstep
 
     // one launch on slab s over rows [lo, hi) of its own rows (0, 0 = all)
     auto sweep = [&](Slab &s, int slot, bool use_fista, double ratio, int64_t lo, int64_t hi, bool accumulate) -> int {
-        tvdn_iter_args &it = s.it;
-        it.recon_in = s.recon[cur];
-        it.recon_out = s.recon[cur ^ 1];
-        it.tk = use_fista ? ratio : 0.0;
-        it.tk_prev = tk_prev_ratio;
-        for (int q = 0; q < nd; ++q) {
-            it.b_in[q] = it.d_in[q] = it.dprev_in[q] = nullptr;
-            it.b_out[q] = it.d_out[q] = nullptr;
-            if (use_fista) {
-                it.d_in[q] = s.S[q][i_d]; it.dprev_in[q] = s.S[q][i_prev]; it.d_out[q] = s.S[q][i_out];
-            } else if (d_form) {
-                it.d_in[q] = s.S[q][i_d]; it.dprev_in[q] = s.S[q][i_prev]; it.b_out[q] = s.S[q][i_out];
-            } else {
-                it.b_in[q] = s.S[q][i_b]; it.b_out[q] = s.S[q][i_bout];
-            }
-        }
-        it.mode = use_fista ? TVDN_ITER_FISTA_D : (d_form ? TVDN_ITER_FISTA_D_TO_PLAIN : TVDN_ITER_PLAIN);
+        tvdn_iter_args &it = s.roles.base;
+        roles_bind(s.roles, use_fista, ratio, it);
         it.sweep_lo = lo;
         it.sweep_hi = hi;
         it.accumulate = accumulate ? 1 : 0;
@@ -237,7 +220,7 @@ static int run_impl(const tvdn_run_args *a)
     };
 
     auto one = [&](int slot, bool use_fista, double ratio) -> int {
-        const int nxt = cur ^ 1;
+        const int nxt = cur_of() ^ 1;
         if (world == 1) {
             int r = sweep(sl[0], slot, use_fista, ratio, 0, 0, false);
             if (r) return r;
@@ -247,6 +230,9 @@ static int run_impl(const tvdn_run_args *a)
                 Slab &s = sl[r];
                 TVDN_HIP(hipSetDevice(s.device));
                 TVDN_HIP(hipStreamWaitEvent(s.main, s.halo_done, 0));  // last iteration's halo rows have arrived
+                // exact wrap: the last slab's copy stream READ my row 0 of the buffer these sweeps are about to rewrite
+                // (two iterations later it is `nxt` again); nothing else orders that read before this write
+                if (exact_wrap && r == 0) TVDN_HIP(hipStreamWaitEvent(s.main, sl[world - 1].halo_done, 0));
                 const int64_t lo = s.row_lo(), hi = s.row_hi();
                 if (hi - lo < 3) {
                     int rc = sweep(s, slot, use_fista, ratio, 0, 0, false);
@@ -268,14 +254,14 @@ static int run_impl(const tvdn_run_args *a)
                 if (s.halo_lo) {
                     Slab &l = sl[(r + world - 1) % world];
                     TVDN_HIP(hipStreamWaitEvent(s.copy, l.edge_done, 0));
-                    TVDN_HIP(hipMemcpyPeerAsync(s.recon[nxt] + (size_t)(s.row_lo() - 1) * row_bytes, s.device,
-                                                l.recon[nxt] + (size_t)(l.row_hi() - 1) * row_bytes, l.device, row_bytes, s.copy));
+                    TVDN_HIP(hipMemcpyPeerAsync(s.recon(nxt) + (size_t)(s.row_lo() - 1) * row_bytes, s.device,
+                                                l.recon(nxt) + (size_t)(l.row_hi() - 1) * row_bytes, l.device, row_bytes, s.copy));
                 }
                 if (s.halo_hi) {
                     Slab &h = sl[(r + 1) % world];
                     TVDN_HIP(hipStreamWaitEvent(s.copy, h.edge_done, 0));
-                    TVDN_HIP(hipMemcpyPeerAsync(s.recon[nxt] + (size_t)s.row_hi() * row_bytes, s.device,
-                                                h.recon[nxt] + (size_t)h.row_lo() * row_bytes, h.device, row_bytes, s.copy));
+                    TVDN_HIP(hipMemcpyPeerAsync(s.recon(nxt) + (size_t)s.row_hi() * row_bytes, s.device,
+                                                h.recon(nxt) + (size_t)h.row_lo() * row_bytes, h.device, row_bytes, s.copy));
                 }
                 TVDN_HIP(hipEventRecord(s.halo_done, s.copy));
                 const int64_t lo = s.row_lo(), hi = s.row_hi();
@@ -288,17 +274,9 @@ static int run_impl(const tvdn_run_args *a)
                 }
             }
         }
-        cur ^= 1;
-        if (use_fista) {
-            const int t = i_prev; i_prev = i_d; i_d = i_out; i_out = t;
-            tk_prev_ratio = ratio;
-        } else if (d_form) {
-            i_b = i_out; i_bout = i_prev; d_form = false;
-        } else {
-            const int t = i_b; i_b = i_bout; i_bout = t;
-        }
+        for (int r = 0; r < world; ++r) roles_advance(sl[r].roles, use_fista, ratio);
         ++ran;
-        if (want_mse) return sse_all(cur, slot + 1);
+        if (want_mse) return sse_all(cur_of(), slot + 1);
         return TVDN_OK;
     };
 
@@ -318,11 +296,10 @@ static int run_impl(const tvdn_run_args *a)
         return TVDN_OK;
     };
 
+    std::unique_ptr<double[]> ratios(new double[(size_t)(a->n_fista > 0 ? a->n_fista : 1)]);
+    fista_ratios(a->n_fista, ratios.get());  // float64 on the host, cyTVDN.py:153-156
     for (int i = 0; i < a->n_fista; ++i) {
-        // float64 recurrence on the host, exactly cyTVDN.py:153-156
-        const double tk_new = (1.0 + std::sqrt(1.0 + 4.0 * (tk * tk))) / 2.0;
-        const double ratio = (tk - 1.0) / tk_new;
-        tk = tk_new;
+        const double ratio = ratios[i];
         int rc = one(i, true, ratio);
         if (rc) return rc;
         bool st;
@@ -349,7 +326,7 @@ static int run_impl(const tvdn_run_args *a)
         TVDN_HIP(hipSetDevice(s.device));
         TVDN_HIP(hipStreamSynchronize(s.main));
         TVDN_HIP(hipStreamSynchronize(s.copy));
-        int rc = tvdn_copy_to_host((char *)a->recon_out + (size_t)s.g0 * row_bytes, s.recon[cur] + (size_t)s.row_lo() * row_bytes,
+        int rc = tvdn_copy_to_host((char *)a->recon_out + (size_t)s.g0 * row_bytes, s.recon(cur_of()) + (size_t)s.row_lo() * row_bytes,
                                    (size_t)(s.g1 - s.g0) * row_bytes, s.device);
         if (rc) return rc;
         if (n_total > 0) {
@@ -440,7 +417,9 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
         if (rc) return rc;
         int same = 0;  // slabs sharing the first device share its HBM
         for (int i = 0; i < world; ++i) same += (a->n_devices == 0 || a->devices[i] == a->devices[0]) ? 1 : 0;
-        if (stream_auto && pl.bytes_per_slab * same > (int64_t)(0.9 * (double)pl.free_bytes) && world == 1 &&
+        // ONE threshold (tvdn_plan's `fits`): a state beyond 90 % of the free HBM streams when asked to decide, else is refused
+        const bool over = pl.bytes_per_slab * same > (int64_t)(0.9 * (double)pl.free_bytes);
+        if (stream_auto && over && world == 1 &&
             a->bc_mode == TVDN_BC_JIA_ZHAO) {
             // asked to decide: one device, state beyond its HBM -> stream it (tvdn_stream.hip; it refuses, before it
             // touches the caller's arrays, what the host cannot hold either)
@@ -452,8 +431,8 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
             if (rc2) return rc2;
             return tvdn::run_streamed(a, rows, k);
         }
-        if (pl.bytes_per_slab * same > pl.free_bytes) {
-            tvdn::set_error("state of %lld bytes per slab x %d slab(s) on device %d exceeds its %lld free bytes of HBM: use more "
+        if (over) {
+            tvdn::set_error("state of %lld bytes per slab x %d slab(s) on device %d exceeds 90 %% of its %lld free bytes of HBM: use more "
                             "devices (fewest slabs that fit one each: %d) or the streamed engines (stream_rows / stream_k; cytvdn_amd.plan_run)",
                             (long long)pl.bytes_per_slab, same, a->n_devices > 0 ? a->devices[0] : a->device,
                             (long long)pl.free_bytes, pl.min_slabs);

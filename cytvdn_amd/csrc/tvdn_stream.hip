@@ -170,6 +170,12 @@ size_t host_available_bytes()
     return avail;
 }
 
+bool arrays_overlap(const void *x, const void *y, size_t bytes)
+{
+    const uintptr_t a0 = (uintptr_t)x, b0 = (uintptr_t)y;
+    return a0 < b0 + bytes && b0 < a0 + bytes;
+}
+
 // n row-plane copies inside HBM: one streaming launch when the rows are 16-byte multiples, the runtime's copies otherwise
 int copy_rows(std::vector<void *> &dst, std::vector<void *> &src, size_t row_bytes, hipStream_t s)
 {
@@ -214,6 +220,43 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
     return TVDN_OK;
 }
 
+}  // namespace tvdn
+
+// Host side of a streamed run, as arithmetic only (no HIP call, no device needed, nothing of the caller's dereferenced):
+// the page-locked bytes it would hold -- the data term, recon (= recon_out), the reference when an MSE trace is asked
+// for, one or two accumulator-state arrays per axis, and one more cube when `data` overlaps `recon_out` (the data term
+// then needs its own copy) -- against what the host may give (MemAvailable, physical memory, the control group's
+// limit, TVDN_HOST_LIMIT), of which a streamed run takes 80 % at most.
+extern "C" int tvdn_stream_host_need(const tvdn_run_args *a, int64_t *need_bytes, int64_t *avail_bytes)
+{
+    TVDN_REQUIRE(a != nullptr, "args is NULL");
+    TVDN_REQUIRE(a->dtype == TVDN_F32 || a->dtype == TVDN_F64, "bad dtype %d", a->dtype);
+    TVDN_REQUIRE(a->ndim == 3 || a->ndim == 4, "ndim must be 3 or 4, got %d", a->ndim);
+    double cube = a->dtype == TVDN_F32 ? 4.0 : 8.0;
+    size_t cube_b = a->dtype == TVDN_F32 ? 4 : 8;
+    for (int i = 0; i < a->ndim; ++i) {
+        TVDN_REQUIRE(a->shape[i] >= 1, "shape[%d] must be >= 1", i);
+        cube *= (double)a->shape[i];
+        cube_b *= (size_t)a->shape[i];
+    }
+    const int n_state = a->n_fista > 0 ? 2 : 1;
+    const bool want_mse = a->mse_out != nullptr && a->reference != nullptr;
+    const bool aliased = a->data && a->recon_out && cube < 9.0e18 && tvdn::arrays_overlap(a->data, a->recon_out, cube_b);
+    const double need = (double)(a->ndim * n_state + 2 + (want_mse ? 1 : 0) + (aliased ? 1 : 0)) * cube;
+    const size_t avail = tvdn::host_available_bytes();
+    if (need_bytes) *need_bytes = need < 9.0e18 ? (int64_t)need : INT64_MAX;
+    if (avail_bytes) *avail_bytes = (int64_t)avail;
+    if (avail == 0 || need > 0.8 * (double)avail) {
+        tvdn::set_error("a streamed run of this cube needs %.0f bytes of page-locked host memory, which exceeds what the host has "
+                        "available (%zu bytes, of which 80 %% are used at most): cut it into slabs over several nodes (cytvdn_amd.plan_run)",
+                        need, avail);
+        return TVDN_ERR_UNSUPPORTED;
+    }
+    return TVDN_OK;
+}
+
+namespace tvdn {
+
 int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
 {
     const auto t_start = std::chrono::steady_clock::now();
@@ -234,17 +277,32 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
     TVDN_REQUIRE(R >= 1 && K >= 1, "stream_rows and stream_k must be >= 1");
     if (a->use_stop) K = 1;  // the stopping rule needs a decision after every iteration: one level per pass
     K = std::min<int64_t>(K, std::max<int64_t>(1, n_total));
-    {   // BEFORE anything of the caller's is touched: can the host hold the state at all?  (page-locked: it cannot swap)
-        const double need = (double)((size_t)nd * n_state + 3) * (double)cube_bytes;
-        const size_t avail = host_available_bytes();
-        if (avail == 0 || need > 0.8 * (double)avail) {
-            set_error("a streamed run of this cube needs %.0f bytes of page-locked host memory, which exceeds what the host has "
-                      "available (%zu bytes, of which 80 %% are used at most): cut it into slabs over several nodes (cytvdn_amd.plan_run)",
-                      need, avail);
+    // BEFORE anything of the caller's is touched: can the host hold the state at all?  (page-locked: it cannot swap)
+    {
+        int64_t need = 0, avail = 0;
+        const int rc0 = tvdn_stream_host_need(a, &need, &avail);
+        if (rc0) return rc0;
+    }
+    TVDN_HIP(hipSetDevice(device));
+    // ... and do the rings fit the device?  Also before anything is page-locked or copied (the wrap planes are counted
+    // whether or not they will be needed: deciding that reads the caller's first row).
+    const int64_t cap = R + 2, ocap = R + K + 3;
+    const int n_in = 2 + nd * n_state + (want_mse ? 1 : 0), n_out = 1 + nd * n_state;
+    auto aligned = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t ring_b = aligned((size_t)cap * row_bytes), oring_b = aligned((size_t)ocap * row_bytes);
+    const size_t box_b = aligned((size_t)R * row_bytes), plane_b = aligned(row_bytes);
+    const size_t n_rings = (size_t)(K + 1) + (size_t)(K + 2) * nd;
+    const size_t dev_bytes_max = n_rings * ring_b + oring_b * (want_mse ? 2 : 1) + 2 * (size_t)(n_in + n_out) * box_b +
+                                 (size_t)(K + 1) * plane_b;
+    {
+        size_t free_b = 0, total_b = 0;
+        TVDN_HIP(hipMemGetInfo(&free_b, &total_b));
+        if (dev_bytes_max > free_b) {
+            set_error("streamed run with %lld-row chunks and k = %lld needs %zu bytes of HBM, device %d has %zu free",
+                      (long long)R, (long long)K, dev_bytes_max, device, free_b);
             return TVDN_ERR_UNSUPPORTED;
         }
     }
-    TVDN_HIP(hipSetDevice(device));
 
     // Jia-Zhao wrap at the top face: exact (TVDN_EDGE_WRAP, row 0 of every level kept aside) when row 0 is not finite
     bool exact_wrap = false;
@@ -259,10 +317,18 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
     // ---- host state: orig and recon are the caller's arrays page-locked in place where possible ----------------------
     HostArr orig_h, recon_h, ref_h;
     std::unique_ptr<HostArr[]> state_h(new HostArr[(size_t)nd * 2]);
-    int rc = orig_h.pin_in_place(const_cast<void *>(a->data), cube_bytes);
+    // `data` may be the very array the result goes to (the resident run allows it too): the passes then write recon rows
+    // over the rows the next pass would upload as `orig`, so the data term gets its own pinned copy first.
+    const bool aliased = arrays_overlap(a->data, a->recon_out, cube_bytes);
+    int rc = aliased ? orig_h.alloc(cube_bytes) : orig_h.pin_in_place(const_cast<void *>(a->data), cube_bytes);
     if (rc) return rc;
     if (orig_h.owned) parallel_copy(orig_h.p, a->data, cube_bytes);
-    parallel_copy(a->recon_out, a->data, cube_bytes);  // recon = datacube.copy() (cyTVDN.py:145)
+    if (a->recon_out != a->data) {  // recon = datacube.copy() (cyTVDN.py:145)
+        if (aliased)
+            std::memmove(a->recon_out, a->data, cube_bytes);
+        else
+            parallel_copy(a->recon_out, a->data, cube_bytes);
+    }
     rc = recon_h.pin_in_place(a->recon_out, cube_bytes);
     if (rc) return rc;
     if (recon_h.owned) parallel_copy(recon_h.p, a->data, cube_bytes);
@@ -286,24 +352,8 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
     TVDN_HIP(hipStreamCreateWithFlags(&st.main, hipStreamNonBlocking));
     TVDN_HIP(hipStreamCreateWithFlags(&st.up, hipStreamNonBlocking));
     TVDN_HIP(hipStreamCreateWithFlags(&st.down, hipStreamNonBlocking));
-    const int64_t cap = R + 2, ocap = R + K + 3;
-    const int n_in = 2 + nd * n_state + (want_mse ? 1 : 0), n_out = 1 + nd * n_state;
-    auto aligned = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t ring_b = aligned((size_t)cap * row_bytes), oring_b = aligned((size_t)ocap * row_bytes);
-    const size_t box_b = aligned((size_t)R * row_bytes), plane_b = aligned(row_bytes);
-    const size_t n_rings = (size_t)(K + 1) + (size_t)(K + 2) * nd;
-    const size_t dev_bytes = n_rings * ring_b + oring_b * (want_mse ? 2 : 1) + 2 * (size_t)(n_in + n_out) * box_b +
-                             (exact_wrap ? (size_t)(K + 1) * plane_b : 0);
+    const size_t dev_bytes = dev_bytes_max - (exact_wrap ? 0 : (size_t)(K + 1) * plane_b);
     DevMem mem, sums_d, mse_d;
-    {
-        size_t free_b = 0, total_b = 0;
-        TVDN_HIP(hipMemGetInfo(&free_b, &total_b));
-        if (dev_bytes > free_b) {
-            set_error("streamed run with %lld-row chunks and k = %lld needs %zu bytes of HBM, device %d has %zu free",
-                      (long long)R, (long long)K, dev_bytes, device, free_b);
-            return TVDN_ERR_UNSUPPORTED;
-        }
-    }
     TVDN_HIP(hipMalloc(&mem.p, dev_bytes));
     TVDN_HIP(hipMemsetAsync(mem.p, 0, dev_bytes, st.main));
     char *cursor = (char *)mem.p;
@@ -382,7 +432,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
         for (int j = 0; j < kk; ++j) {
             const bool acc = !std::isnan(ratios[j]);
             TVDN_REQUIRE(!acc || forms[j], "a FISTA iteration cannot follow an unaccelerated one");
-            modes[j] = acc ? TVDN_ITER_FISTA_D : (forms[j] ? TVDN_ITER_FISTA_D_TO_PLAIN : TVDN_ITER_PLAIN);
+            modes[j] = iter_mode(acc, forms[j] != 0);
             forms[j + 1] = acc;
             tkp[j] = prev;
             if (acc) prev = ratios[j];
@@ -530,15 +580,8 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
 
     // ---- the schedule: FISTA ratios in float64 on the host (cyTVDN.py:153-156), then the unaccelerated tail -------------
     std::vector<double> ratios((size_t)n_total);
-    {
-        double tk = 1.0;
-        for (int i = 0; i < a->n_fista; ++i) {
-            const double tk_new = (1.0 + std::sqrt(1.0 + 4.0 * (tk * tk))) / 2.0;
-            ratios[i] = (tk - 1.0) / tk_new;
-            tk = tk_new;
-        }
-        for (int i = a->n_fista; i < n_total; ++i) ratios[i] = NAN;
-    }
+    fista_ratios(a->n_fista, ratios.data());
+    for (int i = a->n_fista; i < n_total; ++i) ratios[i] = NAN;
     int ran = 0;
     auto stop_after = [&](int slot, bool &stop) -> int {
         double s3[3];

@@ -44,14 +44,9 @@ ARRAY_SKEW = 4096   # bytes by which consecutive state arrays are staggered insi
 
 
 def fista_ratios(n: int) -> np.ndarray:
-    """(tk-1)/tk_new for iterations 0..n-1, float64 on the host (reference cyTVDN.py:153-156)."""
-    out = np.empty(int(n), np.float64)
-    tk = 1.0
-    for i in range(int(n)):
-        tk_new = (1 + np.sqrt(1 + 4 * tk ** 2)) / 2
-        out[i] = (tk - 1.0) / tk_new
-        tk = tk_new
-    return out
+    """(tk-1)/tk_new for iterations 0..n-1, float64 on the host (reference cyTVDN.py:153-156): the library's own
+    recurrence (_lib.fista_ratios), so that this schedule is defined once for every engine."""
+    return _lib.fista_ratios(n)
 
 
 @dataclass(frozen=True)
@@ -222,15 +217,22 @@ class HipBackend:
         else:
             # S[q][k]: k-th rotating array of axis q (3 with FISTA: d_k, d_k-1, next; 2 without: b, next)
             self.S = [[arr() for _ in range(per_axis)] for _ in range(self.nd)]
-            self.i_d, self.i_prev, self.i_out = 0, 1, 2      # roles while the state is in d-form
-            self.i_b, self.i_bout = 0, 1                     # roles while the state is in b-form
-            self.d_form = bool(fista)                        # all-zero d_k, d_k-1 == all-zero b
         r1 = arr()                                           # zeroed: its halo rows are read before any exchange fills them
         self.orig = arr()
         self.recon = [arr(), r1]
-        self.tk_prev = 0.0
+        # Which array plays which role (recon[cur]; d_k / d_k-1 / next while the state is in d-form, b / next in b-form)
+        # lives in a tvdn_many_args that the library binds and rotates (tvdn_roles_bind / tvdn_roles_advance): the
+        # same code tvdn_iterate_many and tvdn_run execute.  All-zero (d_k, d_k-1) == all-zero b.
+        self._roles = _lib.ManyArgs()
+        m = self._roles
+        m.recon[0], m.recon[1] = self.recon[0].data_ptr(), self.recon[1].data_ptr()
+        if state == "compact":
+            for q in range(self.nd):
+                for k, t in enumerate(self.S[q]):
+                    m.S[q][k] = t.data_ptr()
+        m.cur, m.i_d, m.i_prev, m.i_out, m.i_b, m.i_bout = 0, 0, 1, 2, 0, 1
+        m.d_form, m.tk_prev = int(bool(fista)), 0.0
         self.sums = torch.zeros((max(int(max_iters), 1), 3), dtype=torch.float64, device=dev)
-        self.cur = 0
         self._mode = None
         self._args = _lib.IterArgs()
         a = self._args
@@ -248,6 +250,16 @@ class HipBackend:
                 self.ctx = None
         except Exception:
             pass
+
+    # role bookkeeping: views of the library-side struct
+    cur = property(lambda self: int(self._roles.cur), lambda self, v: setattr(self._roles, "cur", int(v)))
+    i_d = property(lambda self: int(self._roles.i_d))
+    i_prev = property(lambda self: int(self._roles.i_prev))
+    i_out = property(lambda self: int(self._roles.i_out))
+    i_b = property(lambda self: int(self._roles.i_b))
+    i_bout = property(lambda self: int(self._roles.i_bout))
+    d_form = property(lambda self: bool(self._roles.d_form))
+    tk_prev = property(lambda self: float(self._roles.tk_prev))
 
     # -- the five methods SlabRunner needs ------------------------------------------------------
     def set_params(self, clip, lam_mu):
@@ -293,40 +305,23 @@ class HipBackend:
     def _bind(self, tk_ratio):
         """Point the argument block at the arrays of the iteration about to run."""
         a = self._args
-        i, o = self.cur, self.cur ^ 1
         use_fista = tk_ratio is not None
         if use_fista and not self.fista:
             raise ValueError("backend was allocated without FISTA state")
-        a.tk = float(tk_ratio) if use_fista else 0.0
-        a.tk_prev = float(self.tk_prev)
-        a.recon_in, a.recon_out = self.recon[i].data_ptr(), self.recon[o].data_ptr()
-        for q in range(self.nd):
-            a.b_in[q] = a.b_out[q] = a.d_in[q] = a.d_out[q] = a.dprev_in[q] = None
-        if self.state == "reference":
-            mode = _lib.ITER_FISTA if use_fista else _lib.ITER_PLAIN
+        if self.state == "compact":
+            _lib.check(_lib.lib().tvdn_roles_bind(C.byref(self._roles), int(use_fista), float(tk_ratio or 0.0), C.byref(a)))
+        else:
+            i, o = self.cur, self.cur ^ 1
+            a.tk = float(tk_ratio) if use_fista else 0.0
+            a.tk_prev = 0.0
+            a.recon_in, a.recon_out = self.recon[i].data_ptr(), self.recon[o].data_ptr()
             for q in range(self.nd):
+                a.b_in[q] = a.b_out[q] = a.d_in[q] = a.d_out[q] = a.dprev_in[q] = None
                 a.b_in[q], a.b_out[q] = self.b[q][i].data_ptr(), self.b[q][o].data_ptr()
                 if use_fista:
                     a.d_in[q], a.d_out[q] = self.d[q][i].data_ptr(), self.d[q][o].data_ptr()
-        elif use_fista:
-            if not self.d_form:
-                raise ValueError("a FISTA iteration cannot follow an unaccelerated one (nor does it upstream)")
-            mode = _lib.ITER_FISTA_D
-            for q in range(self.nd):
-                S = self.S[q]
-                a.d_in[q], a.dprev_in[q], a.d_out[q] = S[self.i_d].data_ptr(), S[self.i_prev].data_ptr(), S[self.i_out].data_ptr()
-        elif self.d_form:
-            mode = _lib.ITER_FISTA_D_TO_PLAIN
-            for q in range(self.nd):
-                S = self.S[q]
-                a.d_in[q], a.dprev_in[q], a.b_out[q] = S[self.i_d].data_ptr(), S[self.i_prev].data_ptr(), S[self.i_out].data_ptr()
-        else:
-            mode = _lib.ITER_PLAIN
-            for q in range(self.nd):
-                S = self.S[q]
-                a.b_in[q], a.b_out[q] = S[self.i_b].data_ptr(), S[self.i_bout].data_ptr()
-        a.mode = mode
-        self._mode = (mode, tk_ratio)
+            a.mode = _lib.ITER_FISTA if use_fista else _lib.ITER_PLAIN
+        self._mode = (int(a.mode), tk_ratio)
 
     def step(self, tk_ratio, slot: int, rows=None, accumulate: bool = False):
         """One iteration over the own rows, or over the sub-range `rows` = (lo, hi) of them.  The state
@@ -354,35 +349,19 @@ class HipBackend:
         n_f = len(ratios)
         if n_f and not self.fista:
             raise ValueError("backend was allocated without FISTA state")
-        self._bind(None if not n_f else float(ratios[0]))      # fills the fixed part of the argument block
-        m = _lib.ManyArgs()
-        C.memmove(C.byref(m.base), C.byref(self._args), C.sizeof(_lib.IterArgs))
-        m.recon[0], m.recon[1] = self.recon[0].data_ptr(), self.recon[1].data_ptr()
-        for q in range(self.nd):
-            for k, t in enumerate(self.S[q]):
-                m.S[q][k] = t.data_ptr()
-        m.cur, m.i_d, m.i_prev, m.i_out = self.cur, self.i_d, self.i_prev, self.i_out
-        m.i_b, m.i_bout, m.d_form, m.tk_prev = self.i_b, self.i_bout, int(self.d_form), float(self.tk_prev)
+        m = self._roles
+        C.memmove(C.byref(m.base), C.byref(self._args), C.sizeof(_lib.IterArgs))   # the fixed part of the argument block
         r = (C.c_double * max(n_f, 1))(*[float(v) for v in ratios])
         _lib.check(_lib.lib().tvdn_iterate_many(self.ctx, C.byref(m), n_f, r, int(n_plain),
                                                 C.c_void_p(self.sums[slot0].data_ptr()), _lib.current_stream(self.device)))
-        self.cur, self.i_d, self.i_prev, self.i_out = m.cur, m.i_d, m.i_prev, m.i_out
-        self.i_b, self.i_bout, self.d_form, self.tk_prev = m.i_b, m.i_bout, bool(m.d_form), float(m.tk_prev)
 
     def flip(self):
         """Make the freshly written arrays current (after a full sweep or a set of partial sweeps)."""
         mode, tk_ratio = self._mode
-        self.cur ^= 1
         if self.state == "compact":
-            if mode == _lib.ITER_FISTA_D:
-                self.i_d, self.i_prev, self.i_out = self.i_out, self.i_d, self.i_prev
-            elif mode == _lib.ITER_FISTA_D_TO_PLAIN:
-                self.i_b, self.i_bout = self.i_out, self.i_prev      # b now lives where d_k+1 would have gone
-                self.d_form = False
-            elif mode == _lib.ITER_PLAIN:
-                self.i_b, self.i_bout = self.i_bout, self.i_b
-        if tk_ratio is not None:
-            self.tk_prev = float(tk_ratio)
+            _lib.check(_lib.lib().tvdn_roles_advance(C.byref(self._roles), int(tk_ratio is not None), float(tk_ratio or 0.0)))
+        else:
+            self.cur ^= 1
 
     # -- staging support (cytvdn_amd/outofcore.py): a backend reused for blocks of varying height ----------
     def set_block(self, rows: int, hi_mode: int):
@@ -399,11 +378,9 @@ class HipBackend:
         """Declare what the state arrays hold after an upload: (d_k, d_k-1) pairs or b."""
         if self.state != "compact":
             raise ValueError("staging uses the compact state")
-        self.d_form = bool(d_form)
-        self.i_d, self.i_prev, self.i_out = 0, 1, 2
-        self.i_b, self.i_bout = 0, 1
-        self.cur = 0
-        self.tk_prev = float(tk_prev)
+        m = self._roles
+        m.cur, m.i_d, m.i_prev, m.i_out, m.i_b, m.i_bout = 0, 0, 1, 2, 0, 1
+        m.d_form, m.tk_prev = int(bool(d_form)), float(tk_prev)
 
     def state_tensors(self):
         """Per axis, the arrays that define the accumulator state right now (upload/download order)."""

@@ -283,14 +283,8 @@ class WavefrontRunner:
         modes, tkp = [], []
         prev_ratio = self.tk_prev
         for j, tk in enumerate(ratios):
-            if tk is not None:
-                if not forms[j]:
-                    raise ValueError("a FISTA iteration cannot follow an unaccelerated one")
-                modes.append(_lib.ITER_FISTA_D)
-                forms.append(True)
-            else:
-                modes.append(_lib.ITER_FISTA_D_TO_PLAIN if forms[j] else _lib.ITER_PLAIN)
-                forms.append(False)
+            modes.append(_lib.iter_mode(tk is not None, forms[j]))   # the library's rule (ValueError: FISTA after plain)
+            forms.append(tk is not None)
             tkp.append(prev_ratio)
             if tk is not None:
                 prev_ratio = tk

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TVDN_ABI_VERSION 3
+#define TVDN_ABI_VERSION 4
 
 typedef enum tvdn_dtype { TVDN_F32 = 0, TVDN_F64 = 1 } tvdn_dtype;
 
@@ -217,8 +217,12 @@ int tvdn_iterate_many(tvdn_ctx *ctx, tvdn_many_args *state, int32_t n_fista, con
  *             edge rows of every slab first, then moves one recon row per neighbour device-to-device (peer
  *             copies over xGMI, on a copy stream per slab) while the interior rows are swept -- the
  *             single-process form of the slab decomposition that replaces cyTVDN/mpi.py:314-434 (the
- *             multi-process form over RCCL is cytvdn_amd.distributed.denoise_slabs).  The slab state must fit
- *             in each device's HBM: cubes beyond that are the Python engines' business (cytvdn_amd.plan_run).
+ *             multi-process form over RCCL is cytvdn_amd.distributed.denoise_slabs).  Each slab's state must fit
+ *             its device's HBM (90 % of what is free, tvdn_plan); a cube beyond the HBM of ONE device is streamed
+ *             through it instead when stream_rows / stream_k ask for it (below).
+ *   data / recon_out may be the same array or overlap (denoise in place): the resident run uploads `data` before it
+ *             writes anything; the streamed run then keeps the data term in a pinned copy of its own (one more cube
+ *             of host memory, counted by tvdn_stream_host_need).
  *   sums_out  host, (n_fista+n_plain) x 3 doubles: sum|b_new|, sum|recon_new-recon_old|, sum|recon_old|
  *             per iteration over the WHOLE cube (the reference's b_norm[i] and delta_recon[i] = [1]/[2]);
  *             rows of iterations that did not run stay zero
@@ -265,6 +269,30 @@ typedef struct tvdn_run_args {
 } tvdn_run_args;
 
 int tvdn_run(const tvdn_run_args *args);
+
+/* Host side of a STREAMED tvdn_run as arithmetic only -- no HIP call, no device needed, none of the caller's arrays
+ * dereferenced: *need_bytes = the page-locked host memory the run would hold (data term, recon = recon_out, the
+ * reference when an MSE trace is asked for, one or two accumulator-state arrays per axis, one more cube when data
+ * overlaps recon_out); *avail_bytes = what the host may give: MemAvailable, capped by the physical memory, by the
+ * control group's limit and by the environment variable TVDN_HOST_LIMIT ("64G", "512M", bytes).  Returns TVDN_OK when
+ * need <= 80 % of avail, else TVDN_ERR_UNSUPPORTED with both numbers in tvdn_last_error().  tvdn_run makes this very
+ * call before it touches anything (the reference's counterpart is check_memory, cyTVDN/cyTVDN.py:438-467, which only
+ * prints). */
+int tvdn_stream_host_need(const tvdn_run_args *args, int64_t *need_bytes, int64_t *avail_bytes);
+
+/* The host side of the schedule, for callers that drive tvdn_iterate_fused themselves (cytvdn_amd/engine.py does): the
+ * very functions tvdn_iterate_many and tvdn_run use, so that the parity-critical logic exists once.  Pure host code.
+ *   tvdn_fista_ratios   out[i] = (tk-1)/tk_new of iteration i, float64 recurrence of cyTVDN/cyTVDN.py:153-156
+ *   tvdn_iter_mode      the TVDN_ITER_* form of an iteration on the compact state: FISTA iterations keep the d-form,
+ *                       the first unaccelerated one after them converts it to b, later ones ping-pong b (>= 0;
+ *                       TVDN_ERR_INVALID for a FISTA iteration on a b-form state)
+ *   tvdn_roles_bind     points it->recon_in/out, tk, tk_prev, b/d/dprev pointers and mode at the arrays of the
+ *                       iteration about to run (state->cur / i_* / d_form say which array plays which role)
+ *   tvdn_roles_advance  the role rotation after that iteration (state updated in place) */
+int tvdn_fista_ratios(int32_t n, double *out);
+int tvdn_iter_mode(int32_t use_fista, int32_t d_form);
+int tvdn_roles_bind(const tvdn_many_args *state, int32_t use_fista, double ratio, tvdn_iter_args *it);
+int tvdn_roles_advance(tvdn_many_args *state, int32_t use_fista, double ratio);
 
 /* The HBM arithmetic of the reference's check_memory (cyTVDN/cyTVDN.py:438-467) for this engine: how many
  * arrays the compact state has, how many bytes the tallest slab of an `n_slabs`-way split of axis 0 needs

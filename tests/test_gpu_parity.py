@@ -429,35 +429,3 @@ def test_native_loop_equals_python_loop(tv, monkeypatch, shape, dtype, its, fist
     b = fn(x, mu, its, FISTA=fista, quiet=True)
     for u, v in zip(a, b):
         assert bits_equal(u, v)
-
-
-def test_tvdn_plan_and_the_misfit_message(tv):
-    """tvdn_plan's arithmetic, and tvdn_run refusing a cube whose slabs cannot fit with that arithmetic in the message."""
-    import ctypes as C
-    from cytvdn_amd import _lib
-    L = _lib.lib()
-    out = _lib.PlanOut()
-    sh = _lib.shape_arr((256, 256, 128, 128))
-    assert L.tvdn_plan(0, 4, sh, 1, 1, 0, C.byref(out)) == 0
-    assert out.arrays == 15 and out.bytes_per_slab >= 15 * 4 * 2 ** 30 and out.fits == 1 and out.min_slabs == 1
-    big = _lib.shape_arr((4096, 512, 256, 256))                       # 8 TiB of state: no MI355X holds it
-    assert L.tvdn_plan(0, 4, big, 1, 1, 0, C.byref(out)) == 0 and out.fits == 0 and out.min_slabs > 8
-    assert L.tvdn_plan(0, 4, sh, 0, 2, 0, C.byref(out)) == 0 and out.arrays == 11
-    assert out.bytes_per_slab >= 11 * 130 * 256 * 128 * 128 * 4
-    assert L.tvdn_plan(0, 4, sh, 1, 0, 0, C.byref(out)) == -1
-    a = _lib.RunArgs(dtype=0, ndim=4, bc_mode=2, device=0, n_fista=2, n_plain=0)
-    for i, s in enumerate((4096, 512, 256, 256)):
-        a.shape[i] = s
-    x = np.zeros(4, np.float32)                                        # never read: the call is refused before any copy
-    sums = np.zeros((2, 3))
-    a.data, a.recon_out, a.sums_out = x.ctypes.data, x.ctypes.data, sums.ctypes.data
-    assert L.tvdn_run(C.byref(a)) == -2
-    msg = L.tvdn_last_error().decode()
-    assert "exceeds" in msg and "plan_run" in msg
-    # asked to stream when needed (-1 / -1), the same cube is refused as well -- its 5.6 TiB of state exceed the host's
-    # memory -- and again before any of the caller's arrays is touched (x has four elements)
-    a.stream_rows = a.stream_k = -1
-    assert L.tvdn_run(C.byref(a)) == -2
-    msg = L.tvdn_last_error().decode()
-    # (when earlier tests have left little HBM free the refusal may already come from the ring arithmetic)
-    assert ("host memory" in msg and "exceeds" in msg) or "fit the device" in msg

@@ -1,0 +1,161 @@
+"""Host-only pieces of the C ABI, exercised WITHOUT a GPU:
+ * tvdn_stream_host_need -- the arithmetic that decides whether a streamed tvdn_run may page-lock its state (the check
+   whose absence cost round 2 its GPU boxes): need per mode / dtype / MSE / aliasing, the TVDN_HOST_LIMIT cap, the
+   80 % rule, and that a refused call dereferences nothing;
+ * tvdn_fista_ratios against the reference's float64 recurrence (cyTVDN/cyTVDN.py:153-156), bit for bit;
+ * tvdn_iter_mode / tvdn_roles_bind / tvdn_roles_advance -- the one definition of the role rotation -- against a model
+   written out independently here (which array each sweep reads and writes over a hybrid schedule: no array is
+   read and written by the same sweep, and every d_k written is the d_k read next)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from cytvdn_amd import _lib
+
+GiB = 1 << 30
+
+
+def _args(shape, dtype=0, n_fista=2, n_plain=0, data=1 << 40, recon=1 << 44, mse=False):
+    a = _lib.RunArgs(dtype=dtype, ndim=len(shape), bc_mode=2, device=0, n_fista=n_fista, n_plain=n_plain)
+    for i, s in enumerate(shape):
+        a.shape[i] = s
+    a.data, a.recon_out = data, recon           # never dereferenced by tvdn_stream_host_need
+    if mse:
+        a.reference, a.mse_out = 0x70000000, 0x70000000
+    return a
+
+
+def _need(a):
+    need, avail = C.c_int64(), C.c_int64()
+    rc = _lib.lib().tvdn_stream_host_need(C.byref(a), C.byref(need), C.byref(avail))
+    return rc, need.value, avail.value
+
+
+@pytest.mark.parametrize("shape,dtype,n_fista,n_plain,mse,cubes", [
+    ((8, 4, 4, 8), 0, 3, 0, False, 2 + 4 * 2), ((8, 4, 4, 8), 0, 0, 3, False, 2 + 4), ((8, 4, 8), 1, 2, 1, False, 2 + 3 * 2),
+    ((8, 4, 8), 1, 0, 1, True, 3 + 3), ((8, 4, 4, 8), 0, 2, 2, True, 3 + 8),
+])
+def test_need_counts_the_arrays_a_streamed_run_pins(monkeypatch, shape, dtype, n_fista, n_plain, mse, cubes):
+    monkeypatch.setenv("TVDN_HOST_LIMIT", "1G")
+    rc, need, avail = _need(_args(shape, dtype, n_fista, n_plain, mse=mse))
+    assert rc == 0 and need == cubes * int(np.prod(shape)) * (4 if dtype == 0 else 8) and 0 < avail <= GiB
+
+
+def test_aliased_data_and_result_cost_one_more_cube(monkeypatch):
+    monkeypatch.setenv("TVDN_HOST_LIMIT", "1G")
+    cube = 8 * 4 * 4 * 8 * 4
+    assert _need(_args((8, 4, 4, 8), data=0x5000, recon=0x5000))[1] == 11 * cube
+    assert _need(_args((8, 4, 4, 8), data=0x5000, recon=0x5000 + cube - 4))[1] == 11 * cube      # partial overlap
+    assert _need(_args((8, 4, 4, 8), data=0x5000, recon=0x5000 + cube))[1] == 10 * cube          # adjacent: distinct
+
+
+def test_the_cap_and_the_80_percent_rule(monkeypatch):
+    shape = (256, 256, 128, 128)                       # 4 GiB cube, 40 GiB of pinned state with FISTA
+    for cap, ok in (("64G", True), ("51G", True), ("49G", False), ("1G", False), ("512M", False)):
+        monkeypatch.setenv("TVDN_HOST_LIMIT", cap)
+        rc, need, avail = _need(_args(shape))
+        if avail < int(float(cap[:-1]) * (GiB if cap[-1] == "G" else 1 << 20)):
+            continue                                   # this machine has less than the cap: nothing to learn from it
+        assert need == 10 * 4 * GiB
+        assert (rc == 0) == ok, cap
+        if not ok:
+            assert rc == -2
+            msg = _lib.lib().tvdn_last_error().decode()
+            assert "host memory" in msg and "exceeds" in msg and str(need) in msg
+
+
+def test_round_2s_box_killer_is_refused_with_null_arrays(monkeypatch):
+    """The call that took two GPU boxes down: an 8 TiB shape behind a 16-byte array.  The arithmetic must refuse it on
+    any host, with or without a cap, and must not dereference data / recon_out to do so (NULL here)."""
+    big = (4096, 512, 256, 256)
+    for cap in (None, "64G", "1G"):
+        if cap is None:
+            monkeypatch.delenv("TVDN_HOST_LIMIT", raising=False)
+        else:
+            monkeypatch.setenv("TVDN_HOST_LIMIT", cap)
+        rc, need, avail = _need(_args(big, data=0, recon=0))
+        assert rc == -2 and need == 10 * 4 * int(np.prod(big)) and avail > 0 and need > avail
+
+
+def test_argument_errors_and_huge_shapes():
+    L = _lib.lib()
+    assert L.tvdn_stream_host_need(None, None, None) == -1
+    assert L.tvdn_stream_host_need(C.byref(_args((4, 4))), None, None) == -1
+    a = _args((4, 0, 4))
+    assert L.tvdn_stream_host_need(C.byref(a), None, None) == -1
+    a = _args((1 << 40, 1 << 20, 1 << 20, 4))         # 2^84 bytes: beyond int64, must not wrap into "fits"
+    rc, need, avail = _need(a)
+    assert rc == -2 and need == (1 << 63) - 1
+
+
+def test_fista_ratios_are_the_reference_recurrence():
+    # cyTVDN/cyTVDN.py:153-156:  tk_new = (1 + np.sqrt(1 + 4 * tk ** 2)) / 2 ; ratio = (tk - 1) / tk_new, in float64
+    tk, want = 1.0, []
+    for _ in range(500):
+        tk_new = (1 + np.sqrt(1 + 4 * tk ** 2)) / 2
+        want.append((tk - 1) / tk_new)
+        tk = tk_new
+    got = _lib.fista_ratios(500)
+    assert got.dtype == np.float64 and got.tobytes() == np.array(want, np.float64).tobytes()
+    assert got[0] == 0.0 and 0.98 < got[-1] < 1.0
+    assert _lib.fista_ratios(0).shape == (0,)
+    from cytvdn_amd.engine import fista_ratios
+    assert fista_ratios(7).tobytes() == got[:7].tobytes()
+
+
+def test_iter_mode():
+    assert _lib.iter_mode(True, True) == _lib.ITER_FISTA_D
+    assert _lib.iter_mode(False, True) == _lib.ITER_FISTA_D_TO_PLAIN
+    assert _lib.iter_mode(False, False) == _lib.ITER_PLAIN
+    with pytest.raises(ValueError, match="cannot follow"):
+        _lib.iter_mode(True, False)
+
+
+@pytest.mark.parametrize("nd,n_fista,n_plain", [(4, 5, 0), (3, 0, 4), (4, 3, 3), (3, 1, 1), (4, 0, 1)])
+def test_role_rotation_against_an_independent_model(nd, n_fista, n_plain):
+    L = _lib.lib()
+    m = _lib.ManyArgs()
+    # "addresses": recon 100/101; S[q][k] = 1000 + 10 q + k
+    m.recon[0], m.recon[1] = 100, 101
+    for q in range(4):
+        for k in range(3):
+            m.S[q][k] = 1000 + 10 * q + k
+    m.cur, m.i_d, m.i_prev, m.i_out, m.i_b, m.i_bout, m.d_form, m.tk_prev = 0, 0, 1, 2, 0, 1, int(n_fista > 0), 0.0
+    it = _lib.IterArgs(ndim=nd)
+    ratios = _lib.fista_ratios(n_fista)
+    # the model: per axis, a dict of what each array HOLDS ("d", k) / ("b", k); recon likewise
+    holds = {1000 + 10 * q + k: (("d", 0 if k == 0 else -1) if n_fista else ("b", 0)) for q in range(nd) for k in range(3)}
+    holds_r = {100: 0, 101: None}
+    last_ratio = 0.0
+    for i in range(n_fista + n_plain):
+        fista = i < n_fista
+        ratio = float(ratios[i]) if fista else 0.0
+        assert L.tvdn_roles_bind(C.byref(m), int(fista), ratio, C.byref(it)) == 0
+        assert holds_r[it.recon_in] == i and it.recon_out != it.recon_in
+        assert it.tk == ratio and it.tk_prev == last_ratio
+        for q in range(4):
+            if q >= nd:
+                assert not any((it.b_in[q], it.b_out[q], it.d_in[q], it.d_out[q], it.dprev_in[q]))
+                continue
+            if fista:
+                assert it.mode == _lib.ITER_FISTA_D and not it.b_in[q] and not it.b_out[q]
+                assert holds[it.d_in[q]] == ("d", i) and holds[it.dprev_in[q]] == ("d", i - 1)
+                assert it.d_out[q] not in (it.d_in[q], it.dprev_in[q])
+                holds[it.d_out[q]] = ("d", i + 1)
+            elif it.mode == _lib.ITER_FISTA_D_TO_PLAIN:
+                assert i == n_fista and n_fista > 0 and not it.b_in[q] and not it.d_out[q]
+                assert holds[it.d_in[q]] == ("d", i) and holds[it.dprev_in[q]] == ("d", i - 1)
+                assert it.b_out[q] not in (it.d_in[q], it.dprev_in[q])
+                holds[it.b_out[q]] = ("b", i + 1)
+            else:
+                assert it.mode == _lib.ITER_PLAIN and not it.d_in[q] and not it.d_out[q] and not it.dprev_in[q]
+                assert holds[it.b_in[q]] == ("b", i) and it.b_out[q] != it.b_in[q]
+                holds[it.b_out[q]] = ("b", i + 1)
+        holds_r[it.recon_out] = i + 1
+        assert L.tvdn_roles_advance(C.byref(m), int(fista), ratio) == 0
+        if fista:
+            last_ratio = ratio
+    assert m.cur == (n_fista + n_plain) % 2 and bool(m.d_form) == (n_plain == 0 and n_fista > 0)
+    if n_plain:
+        assert L.tvdn_roles_bind(C.byref(m), 1, 0.5, C.byref(it)) == -1      # FISTA after unaccelerated: refused
