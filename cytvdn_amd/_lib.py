@@ -49,6 +49,7 @@ class IterArgs(C.Structure):
         ("sweep_lo", C.c_int64), ("sweep_hi", C.c_int64), ("accumulate", C.c_int32), ("reserved", C.c_int32),
         ("wrap_recon", C.c_void_p),
         ("ring_rows", C.c_int64), ("orig_ring_rows", C.c_int64),
+        ("ring_phase", C.c_int64), ("orig_ring_phase", C.c_int64),
     ]
 
 
@@ -128,7 +129,7 @@ def lib():
     L.tvdn_synth_fill.argtypes = [C.c_int, C.c_int, i64p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header and library out of step
-    if L.tvdn_abi_version() != 3:
+    if L.tvdn_abi_version() != 4:
         raise TvdnError("libtvdn_hip.so ABI version mismatch")
     _lib = L
     return L
