@@ -50,9 +50,17 @@ def _run(x, mu, n_f, n_p, stop=None, ref=None, stream=None, device=0):
     ((5, 3, 4, 8), np.float32, 12, 0, 16, 5),         # chunk taller than the cube
     ((19, 3, 4, 8), np.float32, 6, 3, 1, 7),          # one-row chunks
     ((40, 4, 8, 16), np.float32, 11, 0, 8, 128),      # k beyond the iteration count: one pass
+    ((40, 4, 8, 16), np.float32, 11, 0, 4, 3),        # four passes, chained when asked to
+    ((40, 4, 8, 16), np.float32, 7, 6, 3, 4),         # the d -> b transition inside a chained run
+    ((37, 6, 16), np.float64, 0, 9, 2, 2),            # odd row count: the last chunk of a pass is short
+    ((33, 3, 4, 8), np.float32, 10, 0, 1, 5),         # one-row chunks, chained
 ])
-def test_streamed_run_equals_resident_run(shape, dtype, n_f, n_p, rows, k):
+@pytest.mark.parametrize("chain", ["1", "0"], ids=["chained", "drained"])
+def test_streamed_run_equals_resident_run(monkeypatch, shape, dtype, n_f, n_p, rows, k, chain):
+    """`chain`: several passes back to back without draining the pipeline (where the cube is tall enough for it:
+    rows >= k + 4 x chunk height and more iterations than k), or every pass on its own."""
     from cytvdn_amd import synth
+    monkeypatch.setenv("TVDN_STREAM_CHAIN", chain)
     dt = np.dtype(dtype)
     nd = len(shape)
     x = synth.cube(shape, seed=61, dtype=dt) + dt.type(0.25)
@@ -103,6 +111,10 @@ def test_streamed_run_mse_trace_and_nonfinite_first_row():
     want = _run(x, mu, 5, 0)
     got = _run(x, mu, 5, 0, stream=(4, 3))
     assert np.isnan(want[0]).any()
+    assert bits_equal(got[0], want[0])
+    # ... and in a chained run, where two passes' copies of row 0 are alive at once (14 rows >= 2 + 4 x 2)
+    want = _run(x, mu, 7, 0)
+    got = _run(x, mu, 7, 0, stream=(2, 2))
     assert bits_equal(got[0], want[0])
 
 
