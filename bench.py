@@ -27,8 +27,12 @@ At N = 1 the line also carries
   cpu_baseline  the reference-structured CPU restatement (oracle/libtvdn_oracle_timed.so, kind "port": the
                 reference's five passes per iteration, its visiting order, dtype-width sums and serial
                 boundary hyperslab) on the host cores of the same box, on config 2 itself when the host has
-                the memory for it; when oracle/_ref (the reference's own compiled kernels) is present they are
-                timed on the same arrays and reported beside it.
+                the memory for it.  Nothing built from the reference's sources runs (or travels) here: how the port
+                compares with the reference's own compiled kernels is measured in the build container by
+                tools/port_vs_reference.py (profiles/r03_port_vs_reference.json).
+  sustained     config 2 again for >= 300 steps (several seconds of sweeps) with the same fields: what a user's
+                200-iteration denoise4D sees once the device has settled, next to the short headline run.
+Every roofline object carries the per-step sweep-kernel time as mean, minimum, median and maximum (HIP events per launch).
 """
 import argparse
 import ctypes as C
@@ -148,13 +152,6 @@ def cpu_baseline(target_s, x_host=None):
                sample=f"denoise4D FISTA f32 {'x'.join(map(str, shape))} synthetic 4D-STEM ({what}), {n} iterations, "
                       f"{dt:.1f} s, OMP_NUM_THREADS={cores}; oracle/libtvdn_oracle_timed.so = the reference's five "
                       f"passes, visiting order, dtype-width sums and serial boundary hyperslab")
-    if oracle.have_reference_kernels():
-        try:  # the reference's own compiled kernels, when they travelled: same arrays, same loop
-            rv, rn, rdt = leg(oracle.load_reference_kernels(), min(target_s, 8.0))
-            out["reference_kernels"] = dict(value=rv, iterations=rn, seconds=round(rdt, 1),
-                                            port_over_reference=round(v / rv, 3))
-        except Exception as e:
-            out["reference_kernels"] = dict(error=repr(e))
     return out
 
 
@@ -270,11 +267,16 @@ def measure(shape, dtype_name, fista, state, steps, warmup, device, rank=0, worl
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    tot_ms, nl = C.c_double(), C.c_int64()
-    _lib.check(_lib.lib().tvdn_ctx_timing_read(be.ctx, C.byref(tot_ms), C.byref(nl)))
+    nl = C.c_int64()
+    cap = 4 * steps + 16
+    each = (C.c_double * cap)()
+    _lib.check(_lib.lib().tvdn_ctx_timing_read_each(be.ctx, each, cap, C.byref(nl)))
     _lib.check(_lib.lib().tvdn_ctx_timing_enable(be.ctx, 0))
     # sweep-kernel time per iteration (a slab iteration is three launches: two edge rows + interior)
-    kern_ms = tot_ms.value / max(steps, 1)
+    per_launch = np.array(each[:min(cap, nl.value)], np.float64)
+    lps = max(1, int(nl.value // max(steps, 1)))
+    per_step = per_launch[:lps * steps].reshape(steps, lps).sum(axis=1) if per_launch.size >= lps * steps else per_launch
+    kern_ms = float(per_launch.sum()) / max(steps, 1)
     if world > 1:
         t = torch.tensor([elapsed, kern_ms], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)      # control-plane group (gloo, host memory)
@@ -301,7 +303,11 @@ def measure(shape, dtype_name, fista, state, steps, warmup, device, rank=0, worl
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel": "fused_iter_kernel", "kernel_ms": round(kern_ms, 4),
+                     "kernel_ms_min": round(float(per_step.min()), 4), "kernel_ms_median": round(float(np.median(per_step)), 4),
+                     "kernel_ms_max": round(float(per_step.max()), 4),
                      "launches_per_step": int(nl.value // max(steps, 1)),
+                     "traffic_source": "profiles/traffic.json: PMC passes (2 x FETCH_SIZE + WRITE_SIZE) of the same "
+                                       "workload, collected in separate rocprofv3 --pmc runs (not in this run)",
                      "basis": f"SURVEY 8d algorithmic bytes: {passes_algorithmic(nd, fista)} array passes x {item} B = "
                               f"{bpv} B per voxel-iteration (the reference's state, each array read once and written once)",
                      "algorithmic_bytes_per_launch": own_vox * bpv,
@@ -435,6 +441,15 @@ def main():
             except Exception as e:   # e.g. a smaller GPU: say so instead of failing the headline
                 also.append({"config": {"workload": workload_name(shp, dn, fi, 1, slab)}, "error": repr(e)})
 
+    sustained = None
+    if headline and not a.no_also:
+        try:
+            n_sus = max(300, a.steps)
+            sustained = measure(shape, dtype_name, fista, a.state, n_sus, a.warmup, local_rank, traffic_table=traffic_table)
+            sustained["steps"], sustained["warmup"] = n_sus, a.warmup
+        except Exception as e:
+            sustained = {"error": repr(e)}
+
     cpu = None
     if headline and rank == 0 and not a.no_cpu_baseline:
         x_host = None
@@ -459,6 +474,8 @@ def main():
             out["config"]["overlap"] = bool(overlap)
             out["transport_fallback"] = bool(fallback)
             out["preflight"] = preflight
+        if sustained is not None:
+            out["sustained"] = sustained
         if also is not None:
             out["also"] = also
         print(json.dumps(out), flush=True)

@@ -26,7 +26,7 @@ ITER_PLAIN, ITER_FISTA, ITER_FISTA_D, ITER_FISTA_D_TO_PLAIN = 0, 1, 2, 3
 
 EXPORTS = (
     "tvdn_abi_version", "tvdn_last_error", "tvdn_device_count", "tvdn_ctx_create", "tvdn_ctx_destroy",
-    "tvdn_ctx_timing_enable", "tvdn_ctx_timing_read",
+    "tvdn_ctx_timing_enable", "tvdn_ctx_timing_read", "tvdn_ctx_timing_read_each",
     "tvdn_accumulator_update", "tvdn_datacube_update", "tvdn_sum_square_error", "tvdn_iterate_fused",
     "tvdn_synth_fill", "tvdn_run", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many", "tvdn_plan", "tvdn_copy_many",
     "tvdn_stream_host_need", "tvdn_fista_ratios", "tvdn_iter_mode", "tvdn_roles_bind", "tvdn_roles_advance",
@@ -80,6 +80,7 @@ class RunArgs(C.Structure):
         ("sums_out", C.c_void_p), ("mse_out", C.c_void_p), ("iters_run", C.c_void_p),
         ("devices", C.c_int32 * 16),
         ("stream_rows", C.c_int32), ("stream_k", C.c_int32),
+        ("phase_iters", C.c_void_p),
     ]
 
 
@@ -112,6 +113,7 @@ def lib():
     L.tvdn_ctx_destroy.argtypes = [C.c_void_p]
     L.tvdn_ctx_timing_enable.argtypes = [C.c_void_p, C.c_int]
     L.tvdn_ctx_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.tvdn_ctx_timing_read_each.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int64)]
     i64p = C.POINTER(C.c_int64)
     L.tvdn_accumulator_update.argtypes = [C.c_void_p, C.c_int, C.c_int, i64p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_double, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]

@@ -255,6 +255,24 @@ int tvdn_ctx_timing_read(tvdn_ctx *ctx, double *total_ms, int64_t *launches)
     return TVDN_OK;
 }
 
+int tvdn_ctx_timing_read_each(tvdn_ctx *ctx, double *ms_out, int64_t cap, int64_t *launches)
+{
+    TVDN_REQUIRE(ctx && launches && (ms_out || cap == 0) && cap >= 0, "bad argument");
+    int64_t n = 0;
+    for (auto &ev : ctx->events) {
+        TVDN_HIP(hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        TVDN_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+        if (n < cap) ms_out[n] = ms;
+        ++n;
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    ctx->events.clear();
+    *launches = n;
+    return TVDN_OK;
+}
+
 int tvdn_ctx_destroy(tvdn_ctx *ctx)
 {
     if (!ctx) return TVDN_OK;

@@ -205,7 +205,7 @@ static int run_impl(const tvdn_run_args *a)
         if (rc) return rc;
     }
 
-    int ran = 0;
+    int ran = 0, ran_phase[2] = {0, 0};
     auto cur_of = [&]() { return (int)sl[0].roles.cur; };  // every slab rotates in lockstep
 
     // one launch on slab s over rows [lo, hi) of its own rows (0, 0 = all)
@@ -302,6 +302,7 @@ static int run_impl(const tvdn_run_args *a)
         const double ratio = ratios[i];
         int rc = one(i, true, ratio);
         if (rc) return rc;
+        ++ran_phase[0];
         bool st;
         rc = stopped(i, st);
         if (rc) return rc;
@@ -311,6 +312,7 @@ static int run_impl(const tvdn_run_args *a)
         const int slot = j + a->n_fista;
         int rc = one(slot, false, 0.0);
         if (rc) return rc;
+        ++ran_phase[1];
         bool st;
         rc = stopped(slot, st);
         if (rc) return rc;
@@ -339,6 +341,10 @@ static int run_impl(const tvdn_run_args *a)
         }
     }
     if (a->iters_run) *a->iters_run = ran;
+    if (a->phase_iters) {
+        a->phase_iters[0] = ran_phase[0];
+        a->phase_iters[1] = ran_phase[1];
+    }
     return TVDN_OK;
 }
 

@@ -753,7 +753,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
     std::vector<double> ratios((size_t)n_total);
     fista_ratios(a->n_fista, ratios.data());
     for (int i = a->n_fista; i < n_total; ++i) ratios[i] = NAN;
-    int ran = 0;
+    int ran = 0, ran_phase[2] = {a->n_fista, a->n_plain};
     auto stop_after = [&](int slot, bool &stop) -> int {
         double s3[3];
         TVDN_HIP(hipMemcpy(s3, (double *)sums_d.p + 3 * (size_t)slot, sizeof s3, hipMemcpyDeviceToHost));
@@ -782,9 +782,11 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
         for (int phase = 0; phase < 2; ++phase) {
             const int first = phase == 0 ? 0 : a->n_fista, last = phase == 0 ? a->n_fista : n_total;
             done = first;
+            ran_phase[phase] = 0;
             for (int i = first; i < last; ++i) {
                 if ((rc = pass(ratios.data() + i, 1))) return rc;
                 ++ran;
+                ++ran_phase[phase];
                 bool stop;
                 if ((rc = stop_after(i, stop))) return rc;
                 if (stop) break;
@@ -810,6 +812,10 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
         }
     }
     if (a->iters_run) *a->iters_run = ran;
+    if (a->phase_iters) {
+        a->phase_iters[0] = ran_phase[0];
+        a->phase_iters[1] = ran_phase[1];
+    }
     return TVDN_OK;
 }
 

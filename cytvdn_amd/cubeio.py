@@ -152,6 +152,11 @@ def denoise_file(input_path, output_path, mu, iterations=10, FISTA=True, stoppin
     from . import driver
     dt = np.dtype(dtype)
     assert dt in (np.float32, np.float64), "datacube must be floating point datatype."
+    # The output is created (truncated) while the input is still being read through its memory map: writing onto the
+    # input -- same path, a symlink or a hard link to it -- would destroy the cube before a single row has been read.
+    if os.path.exists(output_path) and os.path.exists(input_path) and os.path.samefile(input_path, output_path):
+        raise ValueError(f"output {output_path!r} is the input file itself: denoise_file writes to a distinct file "
+                         "(as the reference's MPI driver does, mpi.py:436-498)")
     src = open_cube(input_path, dt, dataset=dataset, shape=shape, file_dtype=file_dtype)
     try:
         nd = src.ndim

@@ -234,14 +234,20 @@ def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, sto
     sums = np.zeros((max(n, 1), 3))
     mse = np.zeros(n + 1)
     ran = C.c_int32(0)
+    phases = (C.c_int32 * 2)(0, 0)
     a.data, a.recon_out, a.sums_out = x.ctypes.data, recon.ctypes.data, sums.ctypes.data
+    a.phase_iters = C.addressof(phases)
     if reference_data is not None:
         ref = np.ascontiguousarray(reference_data)
         a.reference, a.mse_out = ref.ctypes.data, mse.ctypes.data
     a.iters_run = C.addressof(ran)
     _lib.check(_lib.lib().tvdn_run(C.byref(a)))
     sums = sums[:n]
-    done = sums[:, 2] != 0                      # slots of iterations that never ran keep the reference's zero tail
+    # which slots ran, from the library's own per-phase counts (not guessed from the values: an all-zero cube has zero
+    # sums in slots that DID run, and upstream reports 0/0 = NaN there); the rest keep the reference's zero tail
+    done = np.zeros(n, dtype=bool)
+    done[:phases[0]] = True
+    done[n_fista:n_fista + phases[1]] = True
     b_norm = np.where(done, sums[:, 0], 0.0).astype(dtype)
     with np.errstate(divide="ignore", invalid="ignore"):
         delta_recon = np.where(done, sums[:, 1].astype(dtype) / sums[:, 2].astype(dtype), dtype.type(0)).astype(dtype)

@@ -168,6 +168,11 @@ class StagedRunner:
             return x if hasattr(x, "read_rows") else np.ascontiguousarray(x)
 
         # host state: orig, recon old/new, per axis up to two state arrays old/new
+        if pin:     # page-locked memory cannot swap: refuse here, whoever the caller is, what this host cannot hold
+            from .planner import check_host_fits
+            n_host = 3 + 2 * self.nd * (2 if self.fista else 1) + (reference is not None)
+            check_host_fits(dict(mode="trapezoid", k=self.k,
+                                 host_bytes_per_rank=n_host * int(np.prod(self.shape)) * self.dtype.itemsize))
         self.orig_h = host(as_source(datacube))
         self.recon_h = [host(as_source(datacube)), host()]
         n_state = 2 if self.fista else 1

@@ -136,8 +136,13 @@ class WavefrontRunner:
         # state (download), so old and new can be the SAME pinned arrays: 1 + 1 + nd x n_state of them (10 for 4-D
         # FISTA) instead of 19 -- 2.5 TiB instead of 4.9 TiB for BASELINE config 5, which is what fits a 3 TB host.
         # `host_inplace=False` keeps separate old/new arrays (cross-check).
-        self.orig_h = host(as_source(datacube))
         n_state = 2 if self.fista else 1
+        if pin:     # page-locked memory cannot swap: refuse here, whoever the caller is, what this host cannot hold
+            from .planner import check_host_fits
+            n_host = (2 + self.nd * n_state) * (1 if host_inplace else 2) - (0 if host_inplace else 1) + (reference is not None)
+            check_host_fits(dict(mode="wavefront", k=self.k,
+                                 host_bytes_per_rank=n_host * int(np.prod(self.shape)) * self.dtype.itemsize))
+        self.orig_h = host(as_source(datacube))
         r0 = host(as_source(datacube))
         s0 = [[host() for _ in range(n_state)] for _ in range(self.nd)]
         if host_inplace:

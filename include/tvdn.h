@@ -65,6 +65,9 @@ int tvdn_ctx_destroy(tvdn_ctx *ctx);
  * *total_ms / *launches, and forgets them. */
 int tvdn_ctx_timing_enable(tvdn_ctx *ctx, int on);
 int tvdn_ctx_timing_read(tvdn_ctx *ctx, double *total_ms, int64_t *launches);
+/* The same, launch by launch in issue order: the first min(cap, *launches) durations go to ms_out (bench.py forms the
+ * per-step minimum / median / maximum from them). */
+int tvdn_ctx_timing_read_each(tvdn_ctx *ctx, double *ms_out, int64_t cap, int64_t *launches);
 
 /* ------------------------------------------------------------------------------------------
  * Kernel-level entry points: one reference pass each, in place, any shape.
@@ -271,6 +274,10 @@ typedef struct tvdn_run_args {
      * the host copy of the state. */
     int32_t stream_rows;
     int32_t stream_k;
+    /* ABI 4.  host, optional, 2 entries: iterations executed in the FISTA phase and in the unaccelerated phase (with
+     * use_stop either may end early; the unaccelerated phase writes its sums from slot n_fista on regardless,
+     * cyTVDN.py:201).  What tells a caller which sums_out rows are real without guessing from their values. */
+    int32_t *phase_iters;
 } tvdn_run_args;
 
 int tvdn_run(const tvdn_run_args *args);

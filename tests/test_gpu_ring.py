@@ -173,3 +173,79 @@ def test_ring_instantiation_on_resident_arrays(tv, monkeypatch, shape, dtype, it
     b = fn(x, mu, its, FISTA=True, quiet=True)
     for u, v in zip(a, b):
         assert np.asarray(u).tobytes() == np.asarray(v).tobytes()
+
+
+@pytest.mark.parametrize("shape,dtype,R,first_row_finite", [
+    ((13, 3, 4, 8), np.float32, 3, True), ((13, 3, 4, 8), np.float32, 4, False), ((11, 5, 6), np.float64, 2, False),
+])
+def test_ring_sweeps_against_the_oracle(oracle, shape, dtype, R, first_row_finite):
+    """Three FISTA iterations driven through rings of R + 2 rows, launch by launch from this test, against the CPU
+    ORACLE directly (not against another HIP run) -- including a non-finite first row, where the top face needs
+    TVDN_EDGE_WRAP with the current recon of row 0 handed in as `wrap_recon` (anisotropic.pyx:65-73)."""
+    import torch
+    from cytvdn_amd import _lib, synth
+    L, ctx = _lib.lib(), _lib.ctx(0)
+    dt = np.dtype(dtype)
+    nd, N0 = len(shape), shape[0]
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    x = synth.cube(shape, seed=17, dtype=dt) + dt.type(0.25)
+    if not first_row_finite:
+        x[(0, 1) + (2,) * (nd - 2)] = np.inf
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    lam = mu / dt.type(32.0 if nd == 4 else 16.0)
+    n_it = 3
+    ref = oracle.denoise(x, mu, n_it, True)
+    if not first_row_finite:
+        assert np.isnan(ref["recon"][-1]).any()
+    ratios = _lib.fista_ratios(n_it)
+    cap, ocap = R + 2, R + 1
+    plane = shape[1:]
+    # whole-cube arrays are only the "host copies" rows are staged from / to; the sweeps see rings alone
+    recon = [torch.from_numpy(x).cuda(), torch.zeros(shape, dtype=tdt, device="cuda")]
+    orig = torch.from_numpy(x).cuda()
+    S = [[torch.zeros(shape, dtype=tdt, device="cuda") for _ in range(3)] for _ in range(nd)]   # d_k, d_k-1, next
+
+    def ring(n):
+        return torch.full((n,) + plane, float("nan"), dtype=tdt, device="cuda")
+
+    r_in, r_out, o_rg = ring(cap), ring(cap), ring(ocap)
+    d_in, d_prev, d_out = ([ring(cap) for _ in range(nd)] for _ in range(3))
+    tk_prev = 0.0
+    i_d, i_prev, i_out = 0, 1, 2
+    cur = 0
+    for it in range(n_it):
+        row0 = recon[cur][0].clone()
+        for c0 in range(0, N0, R):
+            c1 = min(c0 + R, N0)
+            for g in range(max(0, c0 - 1), min(N0, c1 + 1)):
+                r_in[g % cap].copy_(recon[cur][g])
+                for q in range(nd):
+                    d_in[q][g % cap].copy_(S[q][i_d][g])
+                    d_prev[q][g % cap].copy_(S[q][i_prev][g])
+            for g in range(c0, c1):
+                o_rg[g % ocap].copy_(orig[g])
+            a = _lib.IterArgs(dtype=_lib.dtype_code(dt), ndim=nd, row_lo=0, row_hi=N0, lo_mode=_lib.EDGE_BC,
+                              hi_mode=_lib.EDGE_ZERO if first_row_finite else _lib.EDGE_WRAP, bc_mode=2,
+                              mode=_lib.ITER_FISTA_D, tk=float(ratios[it]), tk_prev=tk_prev, accumulate=1)
+            for i, s_ in enumerate(shape):
+                a.shape[i] = s_
+            for q in range(nd):
+                a.clip[q] = float((1.0 / lam)[q])
+                a.lambda_mu[q] = float((lam / mu).astype(dt)[q])
+                a.d_in[q], a.dprev_in[q], a.d_out[q] = d_in[q].data_ptr(), d_prev[q].data_ptr(), d_out[q].data_ptr()
+            a.orig, a.recon_in, a.recon_out = o_rg.data_ptr(), r_in.data_ptr(), r_out.data_ptr()
+            a.sweep_lo, a.sweep_hi, a.ring_rows, a.orig_ring_rows = c0, c1, cap, ocap
+            if not first_row_finite:
+                a.wrap_recon = row0.data_ptr()
+            sums = torch.zeros(3, dtype=torch.float64, device="cuda")
+            _lib.check(L.tvdn_iterate_fused(ctx, C.byref(a), sums.data_ptr(), _lib.current_stream(0)))
+            for g in range(c0, c1):
+                recon[cur ^ 1][g].copy_(r_out[g % cap])
+                for q in range(nd):
+                    S[q][i_out][g].copy_(d_out[q][g % cap])
+        cur ^= 1
+        i_d, i_prev, i_out = i_out, i_d, i_prev
+        tk_prev = float(ratios[it])
+    torch.cuda.synchronize()
+    from golden_util import bits_equal
+    assert bits_equal(recon[cur].cpu().numpy(), ref["recon"])

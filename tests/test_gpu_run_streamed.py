@@ -1,7 +1,9 @@
 """tvdn_run's out-of-core branch (csrc/tvdn_stream.hip): a cube streamed through the GPU from pinned host memory with the
 wavefront schedule gives the bits of the resident run -- recon and the b_norm / delta_recon traces -- for every schedule
 (FISTA, hybrid, unaccelerated, stopping rule), dtype, rank, chunk height and depth, with non-finite first rows, and the
-MSE trace within summation-order tolerance."""
+MSE trace within summation-order tolerance.  Every case is ALSO compared with the CPU oracle directly (recon bit for bit,
+traces against its f64 yardsticks), not only with the resident HIP run: the ring instantiation of the sweep and the
+streamed loop are the least-travelled code in the tree (reference loop: cyTVDN/cyTVDN.py:148-242)."""
 import ctypes as C
 
 import numpy as np
@@ -10,6 +12,19 @@ import pytest
 from golden_util import bits_equal
 
 pytestmark = pytest.mark.gpu
+
+
+def _oracle(oracle, x, mu, n_f, n_p, **kw):
+    """The CPU oracle on the same schedule (lam = mu/32 for 4-D, mu/16 for 3-D, as `_run` sets it)."""
+    if n_f and n_p:
+        return oracle.denoise(x, mu, [n_f, n_p], True, **kw)
+    return oracle.denoise(x, mu, n_f or n_p, bool(n_f), **kw)
+
+
+def _check_traces(sums, ref, n):
+    np.testing.assert_allclose(sums[:n, 0], ref["b_norm64"][:n], rtol=1e-9)
+    np.testing.assert_allclose(sums[:n, 1], ref["delta64"][:n], rtol=1e-9)
+    np.testing.assert_allclose(sums[:n, 2], ref["rnorm64"][:n], rtol=1e-9)
 
 
 def _run(x, mu, n_f, n_p, stop=None, ref=None, stream=None, device=0):
@@ -56,7 +71,7 @@ def _run(x, mu, n_f, n_p, stop=None, ref=None, stream=None, device=0):
     ((33, 3, 4, 8), np.float32, 10, 0, 1, 5),         # one-row chunks, chained
 ])
 @pytest.mark.parametrize("chain", ["1", "0"], ids=["chained", "drained"])
-def test_streamed_run_equals_resident_run(monkeypatch, shape, dtype, n_f, n_p, rows, k, chain):
+def test_streamed_run_equals_resident_run(oracle, monkeypatch, shape, dtype, n_f, n_p, rows, k, chain):
     """`chain`: several passes back to back without draining the pipeline (where the cube is tall enough for it:
     rows >= k + 4 x chunk height and more iterations than k), or every pass on its own."""
     from cytvdn_amd import synth
@@ -72,13 +87,16 @@ def test_streamed_run_equals_resident_run(monkeypatch, shape, dtype, n_f, n_p, r
     assert bits_equal(got[0], want[0])
     assert got[3] == want[3] == n_f + n_p
     np.testing.assert_allclose(got[1], want[1], rtol=1e-12)   # f64 sums: per-launch partials added in another order
+    ref = _oracle(oracle, x, mu, n_f, n_p)                    # ... and the oracle itself, not only the resident HIP run
+    assert bits_equal(got[0], ref["recon"])
+    _check_traces(got[1], ref, n_f + n_p)
 
 
 @pytest.mark.parametrize("shape,dtype,n_f,n_p,stop,rows,k", [
     ((12, 5, 8, 12), np.float32, 0, 40, 0.02, 4, 6),
     ((11, 3, 7, 9), np.float64, 30, 6, 0.03, 3, 4),
 ])
-def test_streamed_run_with_stopping_rule(shape, dtype, n_f, n_p, stop, rows, k):
+def test_streamed_run_with_stopping_rule(oracle, shape, dtype, n_f, n_p, stop, rows, k):
     """With a stopping rule every pass is one iteration deep; both phases and the zero tails as the resident run."""
     from cytvdn_amd import synth
     dt = np.dtype(dtype)
@@ -92,9 +110,15 @@ def test_streamed_run_with_stopping_rule(shape, dtype, n_f, n_p, stop, rows, k):
     assert bits_equal(got[0], want[0])
     assert np.array_equal(got[1][:, 2] != 0, want[1][:, 2] != 0)
     np.testing.assert_allclose(got[1], want[1], rtol=1e-12)
+    ref = _oracle(oracle, x, mu, n_f, n_p, stopping_relative_change=stop)
+    assert ref["iters_done"] == got[3]                   # stops where the oracle stops
+    assert bits_equal(got[0], ref["recon"])
+    ran = got[1][:, 2] != 0
+    np.testing.assert_allclose(got[1][ran, 0], ref["b_norm64"][ran], rtol=1e-9)
+    np.testing.assert_allclose(got[1][ran, 1], ref["delta64"][ran], rtol=1e-9)
 
 
-def test_streamed_run_mse_trace_and_nonfinite_first_row():
+def test_streamed_run_mse_trace_and_nonfinite_first_row(oracle, monkeypatch):
     from cytvdn_amd import synth
     dt = np.dtype(np.float32)
     shape = (14, 3, 6, 8)
@@ -105,6 +129,9 @@ def test_streamed_run_mse_trace_and_nonfinite_first_row():
     got = _run(x, mu, 6, 2, ref=ref, stream=(3, 4))
     assert bits_equal(got[0], want[0])
     np.testing.assert_allclose(got[2], want[2], rtol=1e-6)
+    oref = _oracle(oracle, x, mu, 6, 2, reference_data=ref)
+    assert bits_equal(got[0], oref["recon"])
+    np.testing.assert_allclose(got[2], oref["MSE64"], rtol=1e-9)
     # an Inf in the cube's first row turns the wrapped axis-0 accumulator into NaN upstream (anisotropic.pyx:65-73):
     # the streamed run keeps row 0 of every level aside and must reproduce the resident run's NaN pattern
     x[0, 1, 2, 3] = np.inf
@@ -112,10 +139,18 @@ def test_streamed_run_mse_trace_and_nonfinite_first_row():
     got = _run(x, mu, 5, 0, stream=(4, 3))
     assert np.isnan(want[0]).any()
     assert bits_equal(got[0], want[0])
+    oref = _oracle(oracle, x, mu, 5, 0)
+    assert np.isnan(oref["recon"][-1]).any() and bits_equal(got[0], oref["recon"])   # NaNs where the oracle has them
     # ... and in a chained run, where two passes' copies of row 0 are alive at once (14 rows >= 2 + 4 x 2)
     want = _run(x, mu, 7, 0)
-    got = _run(x, mu, 7, 0, stream=(2, 2))
-    assert bits_equal(got[0], want[0])
+    for chain in ("0", "1"):
+        monkeypatch.setenv("TVDN_STREAM_CHAIN", chain)
+        got = _run(x, mu, 7, 0, stream=(2, 2))
+        assert bits_equal(got[0], want[0]), chain
+        assert bits_equal(got[0], _oracle(oracle, x, mu, 7, 0)["recon"]), chain
+    # a hybrid schedule whose d -> b transition falls INSIDE a pass, on rings, with the non-finite first row
+    got = _run(x, mu, 3, 3, stream=(3, 4))
+    assert bits_equal(got[0], _oracle(oracle, x, mu, 3, 3)["recon"])
 
 
 def test_streamed_run_argument_checks():
@@ -131,3 +166,30 @@ def test_streamed_run_argument_checks():
     want = _run(x, mu, 3, 0)
     got = _run(x, mu, 3, 0, stream=(-1, -1))
     assert bits_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+def test_streamed_run_in_place(oracle):
+    """data and recon_out the SAME array (the resident run allows it): a streamed run of several passes must
+    not feed its own output back as the data term."""
+    from cytvdn_amd import _lib, synth
+    dt = np.dtype(np.float32)
+    shape = (21, 3, 4, 8)
+    x = synth.cube(shape, seed=13, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6], dt)
+    ref = _oracle(oracle, x, mu, 7, 0)
+    for stream in (None, (3, 2)):                        # resident, then streamed in four passes
+        buf = x.copy()
+        lam = mu / dt.type(32.0)
+        a = _lib.RunArgs(dtype=0, ndim=4, bc_mode=2, device=0, n_fista=7, n_plain=0)
+        if stream:
+            a.stream_rows, a.stream_k = stream
+        for i, s_ in enumerate(shape):
+            a.shape[i] = s_
+            a.clip[i] = float((1.0 / lam)[i])
+            a.lambda_mu[i] = float((lam / mu).astype(dt)[i])
+        sums = np.zeros((7, 3))
+        a.data = a.recon_out = buf.ctypes.data
+        a.sums_out = sums.ctypes.data
+        _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+        assert bits_equal(buf, ref["recon"]), stream
+        _check_traces(sums, ref, 7)

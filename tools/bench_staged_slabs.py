@@ -17,6 +17,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _default_host_limit():
+    """Unless the caller says otherwise, a measurement may page-lock at most half of what the host has available
+    (TVDN_HOST_LIMIT is honoured by every streamed engine, C++ and Python): a mistyped shape gets an error, not the box."""
+    if "TVDN_HOST_LIMIT" in os.environ:
+        return
+    try:
+        with open("/proc/meminfo") as f:
+            kb = next(int(line.split()[1]) for line in f if line.startswith("MemAvailable:"))
+        os.environ["TVDN_HOST_LIMIT"] = str(kb * 1024 // 2)
+    except (OSError, StopIteration, ValueError):
+        os.environ["TVDN_HOST_LIMIT"] = "32G"
+
+
+_default_host_limit()
+
+
 def worker(rank, world, port, a, q):
     import numpy as np
     import torch
