@@ -131,7 +131,8 @@ def test_streamed_run_mse_trace_and_nonfinite_first_row(oracle, monkeypatch):
     np.testing.assert_allclose(got[2], want[2], rtol=1e-6)
     oref = _oracle(oracle, x, mu, 6, 2, reference_data=ref)
     assert bits_equal(got[0], oref["recon"])
-    np.testing.assert_allclose(got[2], oref["MSE64"], rtol=1e-9)
+    # the device squares the f32 difference in f32 before the f64 sum, the yardstick squares in f64: one f32 rounding per term
+    np.testing.assert_allclose(got[2], oref["MSE64"], rtol=2e-7)
     # an Inf in the cube's first row turns the wrapped axis-0 accumulator into NaN upstream (anisotropic.pyx:65-73):
     # the streamed run keeps row 0 of every level aside and must reproduce the resident run's NaN pattern
     x[0, 1, 2, 3] = np.inf

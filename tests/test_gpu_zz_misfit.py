@@ -64,10 +64,11 @@ def test_misfit_is_refused_before_anything_is_touched(lib):
     assert L.tvdn_run(C.byref(a)) == -2
     msg = L.tvdn_last_error().decode()
     assert "exceeds" in msg and "plan_run" in msg
-    # (2) the host side as arithmetic: 10 cubes of 512 GiB (data, recon, 2 x 4 state arrays) against a 1 GiB cap -> refusal, no device, no array touched
+    # (2) the host side as arithmetic: 11 cubes of 512 GiB (data, recon, 2 x 4 state arrays, and one more because two
+    # arrays 4 MiB apart that claim 512 GiB each overlap) against a 1 GiB cap -> refusal, no device, no array touched
     need, avail = C.c_int64(), C.c_int64()
     assert L.tvdn_stream_host_need(C.byref(a), C.byref(need), C.byref(avail)) == -2
-    assert need.value == 10 * 4 * int(np.prod(BIG)) and 0 < avail.value <= 1 << 30
+    assert need.value == 11 * 4 * int(np.prod(BIG)) and 0 < avail.value <= 1 << 30
     # (3) only now the streamed forms of the call itself: decide-yourself (-1 / -1) and explicit rows / k
     for rows, k in ((-1, -1), (2, 4)):
         a.stream_rows, a.stream_k = rows, k
