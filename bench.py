@@ -65,6 +65,7 @@ def parse():
                     help="single GPU: run ONE interior slab of an N-slab job (halo edges, edge rows first, halo rows "
                          "refreshed by device copies) instead of the whole cube; --shape is then the GLOBAL shape")
     ap.add_argument("--no-also", action="store_true", help="skip the extra single-GPU configurations")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 300-step repeat of the headline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of each timed CPU leg")
     ap.add_argument("--no-preflight", action="store_true", help="N > 1: skip the bit-exactness check of the exchange")
@@ -442,7 +443,7 @@ def main():
                 also.append({"config": {"workload": workload_name(shp, dn, fi, 1, slab)}, "error": repr(e)})
 
     sustained = None
-    if headline and not a.no_also:
+    if headline and not a.no_sustained:
         try:
             n_sus = max(300, a.steps)
             sustained = measure(shape, dtype_name, fista, a.state, n_sus, a.warmup, local_rank, traffic_table=traffic_table)

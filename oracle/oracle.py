@@ -39,13 +39,13 @@ _threads = 1
 
 
 def build(force: bool = False) -> None:
-    """Compile the C restatement (and the reference kernels when /root/reference exists)."""
+    """Compile the C restatement.  (The reference's own kernels, oracle/_ref, are built on demand by `make -C oracle ref`
+    -- oracle/make_golden.py and tools/port_vs_reference.py do -- in the build container only.)"""
     if force or not os.path.exists(_LIB_PATH) or (
         os.path.getmtime(_LIB_PATH)
         < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("tvdn_oracle.c", "tvdn_oracle_impl.h"))
     ) or not os.path.exists(os.path.join(_HERE, "libtvdn_oracle_timed.so")):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle"], stdout=sys.stderr)
-    subprocess.check_call(["make", "-s", "-C", _HERE, "ref"], stdout=sys.stderr)   # bench.py's stdout carries one JSON line only
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle"], stdout=sys.stderr)   # bench.py's stdout carries one JSON line only
 
 
 def lib():
@@ -335,6 +335,8 @@ def have_reference_kernels() -> bool:
 
 def load_reference_kernels():
     """Namespace with the reference's own compiled kernel functions (oracle/_ref)."""
+    if not have_reference_kernels() and os.path.isdir("/root/reference/cyTVDN"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"], stdout=sys.stderr)   # build container: on demand
     if not have_reference_kernels():
         raise ImportError("oracle/_ref is empty: run `make -C oracle ref` where /root/reference exists")
     if _REF_DIR not in sys.path:
