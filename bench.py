@@ -32,6 +32,11 @@ At N = 1 the line also carries
                 tools/port_vs_reference.py (profiles/r03_port_vs_reference.json).
   sustained     config 2 again for >= 300 steps (several seconds of sweeps) with the same fields: what a user's
                 200-iteration denoise4D sees once the device has settled, next to the short headline run.
+  placement     the sweep's speed depends on which physical pages the state's allocation got (same clocks, same virtual
+                address, 11.2 / 12.1 / 12.6 ms for config 2: profiles/r03_placement_audition_*.jsonl), so the engine tries
+                --audition N placements (default 3, as many as fit the HBM) and keeps the fastest -- as denoise3D/4D do
+                for runs of >= 100 iterations; config.placement_audition_ms lists the candidates' probe times (kept one
+                first), so the spread of the box is in the line.  Untimed set-up, like the allocation itself.
 Every roofline object carries the per-step sweep-kernel time as mean, minimum, median and maximum (HIP events per launch).
 """
 import argparse
@@ -64,6 +69,9 @@ def parse():
     ap.add_argument("--slab-of", type=int, default=0, metavar="N",
                     help="single GPU: run ONE interior slab of an N-slab job (halo edges, edge rows first, halo rows "
                          "refreshed by device copies) instead of the whole cube; --shape is then the GLOBAL shape")
+    ap.add_argument("--audition", type=int, default=3, metavar="N",
+                    help="placements of the state tried before the run, the fastest kept (engine.HipBackend.best_of: the "
+                         "sweep's speed depends on which physical pages the allocation got); 1 = take the first")
     ap.add_argument("--no-also", action="store_true", help="skip the extra single-GPU configurations")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 300-step repeat of the headline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -218,7 +226,7 @@ class EmulatedNeighbours:
 
 
 def measure(shape, dtype_name, fista, state, steps, warmup, device, rank=0, world=1, group=None,
-            slab_of=0, overlap=True, traffic_table=None):
+            slab_of=0, overlap=True, traffic_table=None, audition=1):
     """Runs warmup + steps iterations of one workload on this rank's slab; returns the result dict (same on all ranks).
     `group` is the data-plane group (RCCL; None = the default group); barriers and the timing reduction use the
     default group, which `init_groups` makes a gloo one (host memory)."""
@@ -233,7 +241,7 @@ def measure(shape, dtype_name, fista, state, steps, warmup, device, rank=0, worl
         lay = SlabLayout(shape, slab_of // 2, slab_of, 2)
     else:
         lay = SlabLayout(shape, rank, world, 2)
-    be = HipBackend(lay, dtype, fista, device=device, max_iters=steps + warmup, state=state)
+    be = HipBackend.best_of(audition, lay, dtype, fista, device=device, max_iters=steps + warmup, state=state)
     mu = np.array([1.0, 1.0, 0.5, 0.5] if nd == 4 else [1.0, 1.0, 0.5], dtype)
     lam = mu / dtype(32.0 if nd == 4 else 16.0)
     be.set_params(1.0 / lam, (lam / mu).astype(dtype))
@@ -300,6 +308,7 @@ def measure(shape, dtype_name, fista, state, steps, warmup, device, rank=0, worl
         "ms_per_step": round(elapsed / steps * 1e3, 4), "dtype": dtype_name,
         "config": {"workload": name, "global_shape": list(shape), "local_block": list(lay.local_shape), "bc_mode": 2,
                    "state_arrays": be.n_arrays(), "state": state,
+                   "placement_audition_ms": getattr(be, "audition", []),
                    "parallelism": f"slab{world}" if world > 1 else ("one slab of %d" % slab_of if slab_of else "single")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -426,7 +435,7 @@ def main():
         traffic_table = None
 
     main_res = measure(shape, dtype_name, fista, a.state, a.steps, a.warmup, local_rank, rank, world, group,
-                       a.slab_of, overlap, traffic_table)
+                       a.slab_of, overlap, traffic_table, a.audition)
 
     also = None
     headline = world == 1 and not a.slab_of and not a.shape and dtype_name == "f32" and fista
@@ -436,7 +445,8 @@ def main():
                                            ((128, 128, 512), "f32", True, 200, 20, 0),         # configs[0] shape on the GPU
                                            ((512, 512, 256, 256), "f32", True, 10, 2, 8)):     # one slab of configs[3]
             try:
-                r = measure(shp, dn, fi, a.state, st_, wu, local_rank, slab_of=slab, traffic_table=traffic_table)
+                r = measure(shp, dn, fi, a.state, st_, wu, local_rank, slab_of=slab, traffic_table=traffic_table,
+                            audition=a.audition)
                 r["steps"], r["warmup"] = st_, wu
                 also.append(r)
             except Exception as e:   # e.g. a smaller GPU: say so instead of failing the headline
@@ -446,7 +456,8 @@ def main():
     if headline and not a.no_sustained:
         try:
             n_sus = max(300, a.steps)
-            sustained = measure(shape, dtype_name, fista, a.state, n_sus, a.warmup, local_rank, traffic_table=traffic_table)
+            sustained = measure(shape, dtype_name, fista, a.state, n_sus, a.warmup, local_rank, traffic_table=traffic_table,
+                                audition=a.audition)
             sustained["steps"], sustained["warmup"] = n_sus, a.warmup
         except Exception as e:
             sustained = {"error": repr(e)}

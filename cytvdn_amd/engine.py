@@ -363,6 +363,71 @@ class HipBackend:
         else:
             self.cur ^= 1
 
+    # -- placement audition ------------------------------------------------------------------------------------------
+    def probe_ms(self, sweeps: int = 2) -> float:
+        """Fastest of `sweeps` timed sweeps on THIS allocation with an all-zero state (the sweep is branch-free: its time
+        does not depend on the values), after one untimed sweep.  Leaves the state all-zero with its roles reset, i.e.
+        as freshly constructed; call it before set_input."""
+        for q in range(self.nd):
+            self._args.clip[q], self._args.lambda_mu[q] = 1.0, 1.0 / 32.0
+        self.orig.zero_()
+        self.recon[0].zero_()
+        L = _lib.lib()
+        n = 1 + int(sweeps)
+        _lib.check(L.tvdn_ctx_timing_enable(self.ctx, 1))
+        try:
+            for i in range(n):
+                self.step(0.5 if self.fista else None, 0)
+            each = (C.c_double * (n + 4))()
+            nl = C.c_int64()
+            _lib.check(L.tvdn_ctx_timing_read_each(self.ctx, each, n + 4, C.byref(nl)))
+        finally:
+            _lib.check(L.tvdn_ctx_timing_enable(self.ctx, 0))
+        self.sums.zero_()
+        if self.state == "compact":
+            self.set_form(self.fista, 0.0)
+        else:
+            self.cur = 0
+        return float(min(each[1:nl.value])) if nl.value > 1 else float(each[0])
+
+    @classmethod
+    def best_of(cls, candidates: int, layout, dtype, fista, device: int = 0, hbm_fraction: float = 0.8, **kw):
+        """The sweep's speed depends on WHERE in HBM its state landed: with identical clocks, the same 60 GiB state of
+        BASELINE config 2 sweeps in 11.2, 12.1 or 12.6 ms depending on the physical pages one hipMalloc happened to get
+        (three states held at once in one process, timed in turn, each reproducible: profiles/r03_placement_audition_*.jsonl;
+        plain per-array streaming is equally fast on all of them, so it is the relation BETWEEN the 15 streams -- DRAM
+        bank/row conflicts -- not the regions themselves).  The virtual address says nothing (the same address is fast
+        in one allocation and slow in the next) and physical addresses are not visible to a user process, so the engine
+        auditions: up to `candidates` states are allocated side by side (as many as fit in `hbm_fraction` of the free
+        HBM), each is timed for two sweeps, the fastest is kept and the others are freed.  Costs ~3 sweeps per candidate
+        before the run; `denoise3D/4D` do it when the run is long enough to pay for it (driver._audition_candidates).
+        The result carries `.audition` = the candidates' probe times in ms (kept one first)."""
+        item = np.dtype(dtype).itemsize
+        per = int(np.prod(layout.local_shape)) * item
+        nd = len(layout.shape)
+        n_arr = 3 + nd * ((3 if fista else 2) if kw.get("state", DEFAULT_STATE) == "compact" else (4 if fista else 2))
+        need = n_arr * (per + ARRAY_SKEW + 256)
+        held, times = [], []
+        for _ in range(max(1, int(candidates))):
+            if held:
+                free, _total = torch.cuda.mem_get_info(device)
+                if need > hbm_fraction * free:
+                    break
+            be = cls(layout, dtype, fista, device=device, **kw)
+            held.append(be)
+            if candidates > 1:
+                times.append(be.probe_ms())
+        if len(held) == 1:
+            held[0].audition = [round(t, 4) for t in times]
+            return held[0]
+        torch.cuda.current_stream(device).synchronize()
+        best = min(range(len(held)), key=lambda i: times[i])
+        keep = held[best]
+        keep.audition = [round(times[best], 4)] + [round(t, 4) for i, t in enumerate(times) if i != best]
+        del held, be
+        torch.cuda.empty_cache()       # hand the losers' HBM back to the driver (torch caches freed blocks otherwise)
+        return keep
+
     # -- staging support (cytvdn_amd/outofcore.py): a backend reused for blocks of varying height ----------
     def set_block(self, rows: int, hi_mode: int):
         """Use only the first `rows` rows of every array (a contiguous prefix) as the local block."""

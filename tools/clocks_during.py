@@ -14,20 +14,20 @@ import time
 
 
 def sysfs_sources():
+    """Every amdgpu card the box shows (the container sees all 8 of the host; which one is ours shows in gpu_busy_percent)."""
     src = {}
     for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
         if not os.path.exists(os.path.join(card, "pp_dpm_sclk")):
             continue
-        for name in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk", "pp_dpm_socclk", "gpu_busy_percent", "mem_busy_percent",
-                     "current_link_speed"):
+        c = os.path.basename(os.path.dirname(card))
+        for name in ("gpu_busy_percent", "mem_busy_percent"):
             p = os.path.join(card, name)
             if os.path.exists(p):
-                src[name] = p
+                src[f"{c}.{name}"] = p
         for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):
             for f in sorted(os.listdir(hw)):
                 if f.startswith(("freq", "power", "temp")) and f.endswith(("_input", "_average")):
-                    src["hwmon_" + f] = os.path.join(hw, f)
-        break       # one-GPU box
+                    src[f"{c}.{f}"] = os.path.join(hw, f)
     return src
 
 
@@ -58,7 +58,7 @@ def main():
     out_path = sys.argv[1]
     cmd = sys.argv[sys.argv.index("--") + 1:]
     src = sysfs_sources()
-    use_smi = not any(k.startswith("hwmon_") or k == "pp_dpm_sclk" for k in src) or os.environ.get("CLOCKS_SMI") == "1"
+    use_smi = not src or os.environ.get("CLOCKS_SMI") == "1"
     with open(out_path, "w") as f:
         f.write("# sources: %s\n" % (json.dumps(src) if not use_smi else "rocm-smi --showclocks --showpower --showtemp --showuse"))
         f.write("# command: %s\n" % " ".join(cmd))

@@ -27,7 +27,7 @@ with open(os.path.join(O, "kernel_trace_full.csv"), newline="") as fh:
     for r in csv.DictReader(fh):
         n = r["Kernel_Name"]
         if "tvdn::" in n:
-            acc[(n.replace("void ", "").split("(")[0], r["Grid_Size"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+            acc[(n.replace("void ", "").split("(")[0], r.get("Grid_Size") or r["Grid_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 with open(os.path.join(O, "r03_a_kernel_trace_by_grid.csv"), "w", newline="") as fh:
     w = csv.writer(fh)
     w.writerow(["kernel", "grid", "calls", "mean_ms", "min_ms", "median_ms", "max_ms"])
