@@ -69,6 +69,7 @@ struct FusedParams {
     int chunk;        // rows per workgroup march
     long long tiles;  // workgroups per cross-section
     long long units;  // A * B * (C / VEC)
+    int block;        // threads per workgroup of this launch: kFusedBlock, or kSmallBlock for small grids
     int xcd;          // 1: remap workgroup ids so each XCD sweeps a contiguous run of tiles
     // patch order of the tiles of a cross-section (0 = plain order): patches of patch_a A-rows x patch_t tiles
     long long patch_a, patch_t, tiles_per_arow;
@@ -81,7 +82,8 @@ struct FusedParams {
 #ifndef TVDN_FUSED_BLOCK
 #define TVDN_FUSED_BLOCK 256
 #endif
-constexpr int kFusedBlock = TVDN_FUSED_BLOCK;  // threads per workgroup (measurement knob: 512 tried)
+constexpr int kFusedBlock = TVDN_FUSED_BLOCK;  // threads per workgroup (128 / 512 / 1024 lose on every large shape: profiles/r03_ab_inproc_blocks_*.jsonl)
+constexpr int kSmallBlock = 128;               // ... but small cross-sections gain 9 % from twice as many workgroups half the size
 
 // One accumulator update at one voxel.  v1/v2 are the values loaded from in1/in2.
 // Returns b_new (what the divergence and b_norm use); o1/o2 are what out1/out2 receive.
@@ -109,7 +111,25 @@ __device__ __forceinline__ T acc_new(T r_x, T r_prev, T v1, T v2, T tk, T tk_pre
 
 // Axis whose neighbours are whole packs (A and B): update own state at x, recompute b_new at the
 // +1 neighbour, add lm * (b_new(x) - b_new(x+e)) to `sum` (left-to-right as utils.c:5641).
-template <typename T, int VEC, int MODE>
+// Which loads of the A / B / C accumulator state are streaming (non-temporal) ones -- a compile-time mask, so that
+// variants can be built and compared (tools/build_variants.sh, tools/ab_inproc.py):
+//   bit 0: B own   bit 1: C own   bit 2: A own   bit 3: B next   bit 4: A next
+// Measured with variants alternating on one allocation (tools/ab_inproc.py; profiles/r03_ab_inproc_ntmask_*.jsonl):
+// streaming the A-axis state a thread reads at its own position is worth 0.2-1.1 % (config 2 / f64); every other bit
+// costs 2-27 % (the B and C neighbours are served by the lines the own loads have just brought in).
+#ifndef TVDN_NTMASK
+#define TVDN_NTMASK 4
+#endif
+constexpr int kNtMask = TVDN_NTMASK;
+
+template <typename T, int VEC, bool NT>
+__device__ __forceinline__ Pack<T, VEC> ldx(const T *p)
+{
+    if (NT) return ldv_nt<T, VEC>(p);
+    return ldv<T, VEC>(p);
+}
+
+template <typename T, int VEC, int MODE, bool nt_own, bool nt_next>
 __device__ __forceinline__ void axis_pack(const Pack<T, VEC> &r_cur, const T *__restrict__ r_in,
                                           const AxisState<T> &s, long long x, long long off_prev,
                                           long long off_next, bool self_next, T tk, T tkp, T cl, T lm,
@@ -119,12 +139,12 @@ __device__ __forceinline__ void axis_pack(const Pack<T, VEC> &r_cur, const T *__
     using M = ModeTraits<MODE>;
     const P rp = ldv<T, VEC>(r_in + x + off_prev);
     const P rn = ldv<T, VEC>(r_in + x + off_next);
-    const P v1_own = ldv<T, VEC>(s.in1 + x);
-    const P v1_nx = ldv<T, VEC>(s.in1 + x + off_next);
+    const P v1_own = ldx<T, VEC, nt_own>(s.in1 + x);
+    const P v1_nx = ldx<T, VEC, nt_next>(s.in1 + x + off_next);
     P v2_own, v2_nx;
     if (M::kIn2) {
-        v2_own = ldv<T, VEC>(s.in2 + x);
-        v2_nx = ldv<T, VEC>(s.in2 + x + off_next);
+        v2_own = ldx<T, VEC, nt_own>(s.in2 + x);
+        v2_nx = ldx<T, VEC, nt_next>(s.in2 + x + off_next);
     }
     P o1, o2;
 #pragma unroll
@@ -143,7 +163,7 @@ __device__ __forceinline__ void axis_pack(const Pack<T, VEC> &r_cur, const T *__
 
 // Contiguous axis C: neighbours inside the pack come from registers; only the element before the
 // pack and the one after it are fetched.
-template <typename T, int VEC, int MODE>
+template <typename T, int VEC, int MODE, bool nt_own>
 __device__ __forceinline__ void axis_contig(const Pack<T, VEC> &r_cur, const T *__restrict__ r_in,
                                             const AxisState<T> &s, long long x, long long off_prev,
                                             long long off_next, bool self_next, T tk, T tkp, T cl, T lm,
@@ -155,9 +175,9 @@ __device__ __forceinline__ void axis_contig(const Pack<T, VEC> &r_cur, const T *
     const T r_after = r_in[x + off_next];
     const T v1_after = s.in1[x + off_next];
     const T v2_after = M::kIn2 ? s.in2[x + off_next] : (T)0;
-    const P v1_own = ldv<T, VEC>(s.in1 + x);
+    const P v1_own = ldx<T, VEC, nt_own>(s.in1 + x);
     P v2_own;
-    if (M::kIn2) v2_own = ldv<T, VEC>(s.in2 + x);
+    if (M::kIn2) v2_own = ldx<T, VEC, nt_own>(s.in2 + x);
     P o1, o2, bn_own;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -186,8 +206,8 @@ __device__ __forceinline__ long long row_slot(long long m, unsigned ring, unsign
     return RING ? (long long)(((unsigned)m + phase) % ring) : m;
 }
 
-template <typename T, int VEC, int NAX, int MODE, bool RING>
-__global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> p)
+template <typename T, int VEC, int NAX, int MODE, bool RING, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
 {
     using P = Pack<T, VEC>;
     using MT = ModeTraits<MODE>;
@@ -208,7 +228,7 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
         tile = (pa * p.patch_a + r / p.patch_t) * p.tiles_per_arow + pt * p.patch_t + r % p.patch_t;
     }
 
-    const long long u = tile * kFusedBlock + threadIdx.x;
+    const long long u = tile * BLOCK + threadIdx.x;
     double acc[3] = {0.0, 0.0, 0.0};  // b_norm, sum|delta|, sum|old|
 
     const long long m0 = p.sweep_lo + chunk_id * p.chunk;
@@ -315,12 +335,12 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
 #pragma unroll
             for (int j = 0; j < VEC; ++j) sum.v[j] = lmM * (bM_cur.v[j] - bM_next.v[j]);
             if (HAS_A)
-                axis_pack<T, VEC, MODE>(r_cur, p.r_in, p.ax[iA], x, offA_prev, offA_next, selfA, tk, tkp, p.clip[iA],
-                                        p.lm[iA], sum, acc[0]);
-            axis_pack<T, VEC, MODE>(r_cur, p.r_in, p.ax[iB], x, offB_prev, offB_next, selfB, tk, tkp, clB, lmB, sum,
-                                    acc[0]);
-            axis_contig<T, VEC, MODE>(r_cur, p.r_in, p.ax[iC], x, offC_prev, offC_next, selfC, tk, tkp, clC, lmC, sum,
-                                      acc[0]);
+                axis_pack<T, VEC, MODE, (kNtMask & 4) != 0, (kNtMask & 16) != 0>(r_cur, p.r_in, p.ax[iA], x, offA_prev, offA_next,
+                                                                                 selfA, tk, tkp, p.clip[iA], p.lm[iA], sum, acc[0]);
+            axis_pack<T, VEC, MODE, (kNtMask & 1) != 0, (kNtMask & 8) != 0>(r_cur, p.r_in, p.ax[iB], x, offB_prev, offB_next, selfB,
+                                                                            tk, tkp, clB, lmB, sum, acc[0]);
+            axis_contig<T, VEC, MODE, (kNtMask & 2) != 0>(r_cur, p.r_in, p.ax[iC], x, offC_prev, offC_next, selfC, tk, tkp, clC,
+                                                          lmC, sum, acc[0]);
 
             // (3) reconstruction update at row m (utils.pyx:90-104)
             const P og = ldv_nt<T, VEC>(p.orig + (RING ? row_slot<RING>(m, p.ring_orig, p.phase_orig) * SM + xs : x));
@@ -338,16 +358,18 @@ __global__ void __launch_bounds__(kFusedBlock) fused_iter_kernel(FusedParams<T> 
             bM_cur = bM_next;
         }
     }
-    block_store_partials<3, kFusedBlock>(acc, p.partials);
+    block_store_partials<3, BLOCK>(acc, p.partials);
 }
 
 template <typename T, int VEC, int NAX, int MODE>
 static int launch_fused_t(const FusedParams<T> &p, int grid, hipStream_t s)
 {
     if (p.ring)
-        hipLaunchKernelGGL((fused_iter_kernel<T, VEC, NAX, MODE, true>), dim3(grid), dim3(kFusedBlock), 0, s, p);
+        hipLaunchKernelGGL((fused_iter_kernel<T, VEC, NAX, MODE, true, kFusedBlock>), dim3(grid), dim3(kFusedBlock), 0, s, p);
+    else if (p.block == kSmallBlock)
+        hipLaunchKernelGGL((fused_iter_kernel<T, VEC, NAX, MODE, false, kSmallBlock>), dim3(grid), dim3(kSmallBlock), 0, s, p);
     else
-        hipLaunchKernelGGL((fused_iter_kernel<T, VEC, NAX, MODE, false>), dim3(grid), dim3(kFusedBlock), 0, s, p);
+        hipLaunchKernelGGL((fused_iter_kernel<T, VEC, NAX, MODE, false, kFusedBlock>), dim3(grid), dim3(kFusedBlock), 0, s, p);
     TVDN_HIP(hipGetLastError());
     return TVDN_OK;
 }
@@ -417,43 +439,58 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
 
     const int vec = (al && (p.C % VMAX == 0)) ? VMAX : 1;
     p.units = p.A * p.B * (p.C / vec);
-    p.tiles = (p.units + kFusedBlock - 1) / kFusedBlock;
-    // tuning knobs (measurement only): TVDN_CHUNK = rows per march, TVDN_XCD = 0 disables the XCD remap
-    const char *e_chunk = getenv("TVDN_CHUNK"), *e_xcd = getenv("TVDN_XCD");
-    p.xcd = e_xcd ? atoi(e_xcd) : 1;
+    const long long rows = p.sweep_hi - p.sweep_lo;
+    // tuning knobs (measurement only): TVDN_CHUNK = rows per march, TVDN_XCD = 0 / 1 forces the XCD remap off / on,
+    // TVDN_PATCH = "A-rows,tiles" ("0": plain order), TVDN_BLOCK = threads per workgroup (128 / 256)
+    const char *e_chunk = getenv("TVDN_CHUNK"), *e_xcd = getenv("TVDN_XCD"), *e_block = getenv("TVDN_BLOCK");
+    long long chunk = 8, grid = 0;
+    p.block = kFusedBlock;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        p.tiles = (p.units + p.block - 1) / p.block;
+        // rows per march: long enough to amortise the look-ahead row (3 extra pack loads per chunk), short enough that the
+        // workgroups in flight stay close together; 8 beats 2, 4, 6, 12, 16 and 32 on the large shapes when the variants
+        // alternate on one allocation (profiles/r03_ab_inproc_blocks_chunks_xcd.jsonl)
+        chunk = e_chunk ? atoll(e_chunk) : 8;
+        if (chunk < 1) chunk = 1;
+        while (chunk > 4 && p.tiles * ((rows + chunk - 1) / chunk) < 256 * 8) chunk /= 2;
+        // the reduction scratch grows with the grid (ensure_partials), so big planes keep their short marches;
+        // only beyond kMaxPartialBlocks workgroups do the marches get longer
+        while (p.tiles * ((rows + chunk - 1) / chunk) > kMaxPartialBlocks && chunk < rows) chunk *= 2;
+        grid = p.tiles * ((rows + chunk - 1) / chunk);
+        // Small cross-sections (the 128x128x512 shape of BASELINE configs[0]: 2048 workgroups of 256 threads, two per SIMD
+        // slot set): workgroups of 128 threads, twice as many, sweep 9 % faster (0.0795 against 0.0872 ms, same file);
+        // from 512^3 on the sizes are even, and on every 4-D cube 256 wins.
+        const bool small = e_block ? atoi(e_block) == kSmallBlock : grid < 4096;
+        if (attempt == 0 && small && !p.ring && vec == VMAX && kFusedBlock != kSmallBlock && p.units % kSmallBlock == 0)
+            p.block = kSmallBlock;
+        else
+            break;
+    }
+    p.chunk = (int)chunk;
     {
-        // Patch order (see the kernel): needs whole tiles per A-row and extents divisible by the patch.  A patch holds
-        // the 128 tiles an XCD has in flight.  Interleaved A/B on one MI355X (profiles/r02_ab_patch_order.txt):
-        //   A-rows of 16 tiles (config 2, 64 KiB):      plain order 11.36 ms, every patch shape slower (11.50-12.01)
-        //   A-rows of 32 tiles (config 3, f64, 128 KiB): plain 17.52, 8x16 16.82, 32x4 16.91, 16x8 17.04 ms
-        //   A-rows of 64 tiles (config-4 slab, 256 KiB): plain 24.37, 8x16 23.39, 16x16 23.22, 16x8 23.15, 32x8 23.04 ms
+        // Order of the tiles of a cross-section.  A-rows of fewer than 32 tiles (config 2: 16): plain order, and workgroup
+        // ids remapped so that every XCD (private L2) sweeps a contiguous run.  Longer A-rows: patches of 32 A-rows x 8
+        // tiles walked by all eight XCDs together (no remap) -- consecutive workgroups go to consecutive XCDs, so the A
+        // neighbour, 8 tiles on, lands on the SAME XCD one slot later, and the chip as a whole streams one 1 MiB region
+        // per array instead of eight.  Variants alternating on one allocation (profiles/r03_ab_inproc_xcd0_patch.jsonl,
+        // r03_ab_inproc_blocks_chunks_xcd_2.jsonl): config-4 slab 24.27 -> 23.17 ms (-4.6 %), config 3 (f64, 32 tiles per
+        // A-row) 16.93 -> 16.54 ms (-2.3 %); round 2's 8x16 / 16x8 patches under the remap: 23.3-23.4 / 16.7 ms.
+        // Config 2 is indifferent to all of it (11.45-11.52 ms), so it keeps the simpler order.
         const long long row_units = p.B * (p.C / vec);
-        const long long tr = (row_units % kFusedBlock == 0) ? row_units / kFusedBlock : 0;
-        long long ga = tr >= 64 ? 16 : 8, gt = tr >= 64 ? 8 : 16;
-        const char *e_patch = getenv("TVDN_PATCH");  // "A-rows,tiles"; "0" switches it off (measurement knob)
+        const long long tr = (row_units % p.block == 0) ? row_units / p.block : 0;
+        long long ga = (p.A % 32 == 0) ? 32 : ((p.A % 16 == 0) ? 16 : 8), gt = 8;
+        const char *e_patch = getenv("TVDN_PATCH");
         if (e_patch) {
             ga = atoll(e_patch);
             const char *c = strchr(e_patch, ',');
-            gt = c ? atoll(c + 1) : 16;
+            gt = c ? atoll(c + 1) : 8;
         }
         p.patch_a = p.patch_t = p.tiles_per_arow = 0;
-        if (nax == 4 && ga > 1 && gt >= 1 && tr > 0 && tr % gt == 0 && (e_patch ? tr > gt : tr >= 32) && p.A % ga == 0) {
+        if (nax == 4 && ga > 1 && gt >= 1 && tr > 0 && tr % gt == 0 && (e_patch ? tr >= gt : tr >= 32) && p.A % ga == 0) {
             p.patch_a = ga; p.patch_t = gt; p.tiles_per_arow = tr;
         }
+        p.xcd = e_xcd ? atoi(e_xcd) : (p.patch_a > 1 ? 0 : 1);
     }
-    const long long rows = p.sweep_hi - p.sweep_lo;
-    // rows per march: long enough to amortise the look-ahead row (3 extra pack loads per chunk); short
-    // marches measured best on MI355X (2..8 rows: 14.7-14.9 ms, 32 rows: 15.3 ms on 256x256x128x128 f32):
-    // many short-lived workgroups keep the set of open DRAM pages compact
-    long long chunk = e_chunk ? atoll(e_chunk) : 8;
-    if (chunk < 1) chunk = 1;
-    while (chunk > 4 && p.tiles * ((rows + chunk - 1) / chunk) < 256 * 8) chunk /= 2;
-    // the reduction scratch grows with the grid (ensure_partials), so big planes keep their short marches;
-    // only beyond kMaxPartialBlocks workgroups do the marches get longer
-    while (p.tiles * ((rows + chunk - 1) / chunk) > kMaxPartialBlocks && chunk < rows) chunk *= 2;
-    p.chunk = (int)chunk;
-    const long long nchunks = (rows + chunk - 1) / chunk;
-    const long long grid = p.tiles * nchunks;
     TVDN_REQUIRE(grid >= 1 && grid <= kMaxPartialBlocks, "fused grid %lld out of range (max %d)", grid, kMaxPartialBlocks);
     {
         const int rce = ensure_partials(ctx, grid);

@@ -217,3 +217,69 @@ extern "C" int tvdn_copy_many(int32_t n, void *const *dst, const void *const *sr
     }
     return TVDN_OK;
 }
+
+
+// ---- measurement aid: a pure N-read / M-write 16-byte stream over caller-chosen arrays -------------------------------------
+// What HBM gives a kernel that does nothing but stream `n_read` arrays in and `n_write` arrays out, one 16-byte element per
+// thread, streaming (non-temporal) accesses -- the practical ceiling of the fused sweep for the SAME arrays in the SAME
+// physical placement (tools/ceiling_vs_sweep.py times both side by side).  Not used by any product path.
+namespace tvdn {
+struct MixPtrs {
+    const float4 *in[12];
+    float4 *out[12];
+};
+
+template <int NR, int NW>
+__global__ void __launch_bounds__(256) stream_mix_kernel(MixPtrs p, long long n16)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const long long i = xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (i >= n16) return;
+    f4 v[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p.in[k]) + i);
+    f4 s = v[0];
+#pragma unroll
+    for (int k = 1; k < NR; ++k) s += v[k];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        f4 o = s;
+        o.x += (float)k;
+        __builtin_nontemporal_store(o, reinterpret_cast<f4 *>(p.out[k]) + i);
+    }
+}
+}  // namespace tvdn
+
+extern "C" int tvdn_stream_mix(int32_t n_read, const void *const *in, int32_t n_write, void *const *out, int64_t bytes_each,
+                               void *stream)
+{
+    TVDN_REQUIRE(in && out && bytes_each > 0 && bytes_each % 16 == 0, "bad argument");
+    tvdn::MixPtrs p;
+    std::memset(&p, 0, sizeof p);
+    TVDN_REQUIRE(n_read >= 1 && n_read <= 12 && n_write >= 1 && n_write <= 12, "1..12 arrays each way");
+    for (int k = 0; k < n_read; ++k) {
+        TVDN_REQUIRE(in[k] && tvdn::aligned16(in[k]), "in[%d] NULL or unaligned", k);
+        p.in[k] = (const float4 *)in[k];
+    }
+    for (int k = 0; k < n_write; ++k) {
+        TVDN_REQUIRE(out[k] && tvdn::aligned16(out[k]), "out[%d] NULL or unaligned", k);
+        p.out[k] = (float4 *)out[k];
+    }
+    const long long n16 = bytes_each / 16;
+    const long long grid = (n16 + 255) / 256;
+    TVDN_REQUIRE(grid < (1LL << 31), "array too long for one launch");
+#define TVDN_MIX(NR, NW)                                                                                                           \
+    if (n_read == NR && n_write == NW) {                                                                                           \
+        hipLaunchKernelGGL((tvdn::stream_mix_kernel<NR, NW>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, n16); \
+        TVDN_HIP(hipGetLastError());                                                                                               \
+        return TVDN_OK;                                                                                                            \
+    }
+    TVDN_MIX(10, 5)  // 4-D FISTA, compact state: orig, recon, 4 x (d_k, d_k-1) in; recon, 4 x d_k+1 out
+    TVDN_MIX(6, 5)   // 4-D unaccelerated
+    TVDN_MIX(8, 4)   // 3-D FISTA, compact state
+    TVDN_MIX(5, 4)   // 3-D unaccelerated
+    TVDN_MIX(1, 1)   // plain copy
+#undef TVDN_MIX
+    tvdn::set_error("stream mix %d in / %d out is not instantiated (10/5, 6/5, 8/4, 5/4, 1/1)", n_read, n_write);
+    return TVDN_ERR_UNSUPPORTED;
+}

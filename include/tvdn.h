@@ -343,6 +343,13 @@ int tvdn_copy_to_host(void *dst_host, const void *src_device, size_t bytes, int 
 int tvdn_copy_many(int32_t n, void *const *dst, const void *const *src, int64_t bytes_each, int32_t max_blocks,
                    void *stream);
 
+/* Measurement aid: a pure stream of n_read arrays in and n_write arrays out (16-byte elements, one per thread,
+ * streaming accesses, XCD-aware workgroup order) over caller-chosen device arrays of bytes_each bytes -- what HBM
+ * gives the read/write mix of a sweep on the very arrays (the very physical pages) the sweep uses; tools/ceiling_vs_sweep.py
+ * puts the two side by side.  Instantiated for the mixes of the fused sweep: 10/5, 6/5, 8/4, 5/4, and 1/1. */
+int tvdn_stream_mix(int32_t n_read, const void *const *in, int32_t n_write, void *const *out, int64_t bytes_each,
+                    void *stream);
+
 /* Synthetic input (cytvdn_amd/synth.py restated on the device, bit-identical): fills rows
  * [row0, row0+rows) of the GLOBAL cube `shape` into `out` (rows*prod(shape[1:]) elements). */
 int tvdn_synth_fill(int dtype, int ndim, const int64_t *shape, uint64_t seed, int64_t row0,

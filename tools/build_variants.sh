@@ -8,6 +8,15 @@ FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fP
 build() { # tag, extra flags
   /opt/rocm/bin/hipcc $FLAGS $2 $SRC -o tools/ubench/libtvdn_hip_$1.so
 }
+if [ "$1" = "blocks" ]; then   # workgroup sizes of the fused sweep, for tools/ab_inproc.py
+  for b in 128 512 1024; do build blk$b "-DTVDN_FUSED_BLOCK=$b" & done
+  build ntm4 "-DTVDN_NTMASK=4" &
+  wait; ls -la tools/ubench/*blk*.so; exit 0
+fi
+if [ "$1" = "ntmask" ]; then   # round 3: which accumulator-state loads stream past the L2 (csrc/tvdn_fused.hip, kNtMask)
+  for m in 1 2 3 7 11 27 31 4 16; do build ntm$m "-DTVDN_NTMASK=$m" & done
+  wait; ls -la tools/ubench/*ntm*.so; exit 0
+fi
 build ntl0 "-DTVDN_NT_LOADS=0" &
 build nts0 "-DTVDN_NT_STORES=0" &
 build nt00 "-DTVDN_NT_LOADS=0 -DTVDN_NT_STORES=0" &
