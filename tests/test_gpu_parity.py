@@ -171,6 +171,31 @@ def test_fused_patch_order_of_tiles(tv, oracle, monkeypatch, patch):
                                    rtol=1e-6 if dt == np.float32 else 1e-12)
 
 
+@pytest.mark.parametrize("block,xcd,patch", [("256", "1", None), ("256", "0", None), ("128", "1", None), ("128", "0", None),
+                                             ("256", "0", "32,8"), ("128", "0", "16,8"), ("256", "1", "0")])
+def test_fused_launch_shapes_do_not_move_the_bits(tv, oracle, monkeypatch, block, xcd, patch):
+    """Workgroup size (256 / 128 threads), XCD remap on / off and the patch walk are launch decisions the library takes by
+    shape (csrc/tvdn_fused.hip); forced here in every combination on shapes with long A-rows (patches of 32 x 8 tiles
+    apply), short A-rows and a 3-D cube: who computes which voxel changes, the voxel's arithmetic does not."""
+    from cytvdn_amd import synth
+    monkeypatch.setenv("TVDN_BLOCK", block)
+    monkeypatch.setenv("TVDN_XCD", xcd)
+    if patch is not None:
+        monkeypatch.setenv("TVDN_PATCH", patch)
+    for shape, dtype in (((3, 32, 128, 256), np.float32), ((2, 64, 64, 128), np.float64), ((5, 4, 16, 64), np.float32),
+                         ((9, 24, 512), np.float32)):
+        dt = np.dtype(dtype)
+        nd = len(shape)
+        x = synth.cube(shape, seed=67, dtype=dt) + dt.type(0.25)
+        mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+        fn = tv.denoise4D if nd == 4 else tv.denoise3D
+        recon, bn, dl = fn(x, mu, [2, 2], FISTA=True, quiet=True)
+        ref = oracle.denoise(x, mu, [2, 2], True)
+        assert bits_equal(recon, ref["recon"]), (shape, block, xcd, patch)
+        np.testing.assert_allclose(bn.astype(np.float64), ref["b_norm64"].astype(dt).astype(np.float64),
+                                   rtol=1e-6 if dt == np.float32 else 1e-12)
+
+
 def test_device_tensors_in_place(tv, oracle):
     """Kernel-level calls on torch CUDA tensors update HBM in place."""
     import torch
