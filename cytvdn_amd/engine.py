@@ -203,13 +203,29 @@ class HipBackend:
         stride_el = (-(-(n_el * item) // 256) * 256 + skew) // item
         per_axis = (3 if fista else 2) if state == "compact" else (4 if fista else 2)
         n_arr = 3 + self.nd * per_axis
-        self._slab = torch.empty(n_arr * stride_el, dtype=tdt, device=dev)
-        self._slab[:(n_arr - 2) * stride_el].zero_()
         it = iter(range(n_arr))
+        if os.environ.get("TVDN_ALLOC", "one") == "separate":
+            # measurement knob: one allocation PER ARRAY (each then gets its own run of physical pages, power-of-two sized
+            # arrays their own naturally aligned blocks), staggered inside its allocation by the same ARRAY_SKEW
+            self._slab = None
+            self._parts = []
+            pad_el = (n_arr * skew) // item + 64
 
-        def arr():
-            i = next(it)
-            return self._slab[i * stride_el:i * stride_el + n_el].view(ls)
+            def arr():
+                i = next(it)
+                t = torch.empty(n_el + pad_el, dtype=tdt, device=dev)
+                if i < n_arr - 2:
+                    t.zero_()
+                self._parts.append(t)
+                off = (i * skew) // item
+                return t[off:off + n_el].view(ls)
+        else:
+            self._slab = torch.empty(n_arr * stride_el, dtype=tdt, device=dev)
+            self._slab[:(n_arr - 2) * stride_el].zero_()
+
+            def arr():
+                i = next(it)
+                return self._slab[i * stride_el:i * stride_el + n_el].view(ls)
 
         if state == "reference":
             self.b = [[arr(), arr()] for _ in range(self.nd)]

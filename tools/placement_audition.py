@@ -44,7 +44,7 @@ def timed(be, tag, steps=12):
     ms, n = C.c_double(), C.c_int64()
     _lib.check(_lib.lib().tvdn_ctx_timing_read(be.ctx, C.byref(ms), C.byref(n)))
     _lib.check(_lib.lib().tvdn_ctx_timing_enable(be.ctx, 0))
-    base = be._slab.data_ptr()
+    base = be._slab.data_ptr() if be._slab is not None else be.orig.data_ptr()
     print(json.dumps({"tag": tag, "kernel_ms": round(ms.value / n.value, 4), "base": hex(base), "t": round(time.time() - T0, 1)}), flush=True)
 
 
@@ -95,3 +95,14 @@ if len(sys.argv) > 2 and sys.argv[2] == "arrays":
     for j, be in enumerate(held):
         timed(be, f"diag2.state{j}")
         per_array(be, f"diag2.state{j}", scratch)
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "separate":
+    # one hipMalloc per array instead of one for the whole state: is the sweep's time then the same for every state?
+    for mode in ("separate", "one", "separate"):
+        os.environ["TVDN_ALLOC"] = mode
+        held = [make() for _ in range(n_hold)]
+        for j, be in enumerate(held):
+            timed(be, f"alloc-{mode}.state{j}")
+        del held, be
+        torch.cuda.empty_cache()
