@@ -50,7 +50,6 @@ class IterArgs(C.Structure):
         ("sweep_lo", C.c_int64), ("sweep_hi", C.c_int64), ("accumulate", C.c_int32), ("reserved", C.c_int32),
         ("wrap_recon", C.c_void_p),
         ("ring_rows", C.c_int64), ("orig_ring_rows", C.c_int64),
-        ("ring_phase", C.c_int64), ("orig_ring_phase", C.c_int64),
     ]
 
 

@@ -75,7 +75,6 @@ struct FusedParams {
     long long patch_a, patch_t, tiles_per_arow;
     // row rings (RING instantiations only): row m of recon / accumulators lives at slot m % ring, of orig at m % ring_orig
     unsigned ring, ring_orig;
-    unsigned phase, phase_orig;  // added to the row number before the modulo (chained passes)
     double *partials;
 };
 
@@ -201,9 +200,9 @@ __device__ __forceinline__ void axis_contig(const Pack<T, VEC> &r_cur, const T *
 // RING: the arrays are rings of row-planes (tvdn.h, ring_rows): the only change is where a row starts.  Row numbers
 // are wave-uniform, so the modulo is scalar work per row step; a separate instantiation keeps the resident path as is.
 template <bool RING>
-__device__ __forceinline__ long long row_slot(long long m, unsigned ring, unsigned phase)
+__device__ __forceinline__ long long row_slot(long long m, unsigned ring)
 {
-    return RING ? (long long)(((unsigned)m + phase) % ring) : m;
+    return RING ? (long long)((unsigned)m % ring) : m;
 }
 
 template <typename T, int VEC, int NAX, int MODE, bool RING, int BLOCK>
@@ -261,7 +260,7 @@ __global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
         const AxisState<T> sM = p.ax[iM];
 
         // ---- prologue: M-axis accumulator of row m0 -----------------------------------------------
-        P r_cur = ldv<T, VEC>(p.r_in + row_slot<RING>(m0, p.ring, p.phase) * SM + xs);
+        P r_cur = ldv<T, VEC>(p.r_in + row_slot<RING>(m0, p.ring) * SM + xs);
         P bM_cur;
         {
             long long mp;  // the row that precedes m0
@@ -269,8 +268,8 @@ __global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
                 mp = m0 - 1;
             else
                 mp = bc2 ? m0 : p.row_hi - 1;  // TVDN_EDGE_BC: Jia-Zhao -> itself, periodic -> last row
-            const long long x0 = row_slot<RING>(m0, p.ring, p.phase) * SM + xs;
-            const P r_prev = ldv<T, VEC>(p.r_in + row_slot<RING>(mp, p.ring, p.phase) * SM + xs);
+            const long long x0 = row_slot<RING>(m0, p.ring) * SM + xs;
+            const P r_prev = ldv<T, VEC>(p.r_in + row_slot<RING>(mp, p.ring) * SM + xs);
             const P v1 = ldv_nt<T, VEC>(sM.in1 + x0);
             P v2, o1, o2;
             if (MT::kIn2) v2 = ldv_nt<T, VEC>(sM.in2 + x0);
@@ -286,7 +285,7 @@ __global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
 
         // ---- march -------------------------------------------------------------------------------
         for (long long m = m0; m < m1; ++m) {
-            const long long x = row_slot<RING>(m, p.ring, p.phase) * SM + xs;
+            const long long x = row_slot<RING>(m, p.ring) * SM + xs;
             const bool last = (m + 1 == m1);
             const bool at_end = (m + 1 == p.row_hi);
 
@@ -301,7 +300,7 @@ __global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
                 // is not (anisotropic.pyx:65-73).  p.wrap holds row 0's current recon; its state is that zero (the
                 // state loads below then land on the own row and are discarded).
                 const bool wrapz = at_end && p.hi_mode == TVDN_EDGE_WRAP;
-                const long long xn = row_slot<RING>(wrap ? p.row_lo : (wrapz ? m : m + 1), p.ring, p.phase) * SM + xs;
+                const long long xn = row_slot<RING>(wrap ? p.row_lo : (wrapz ? m : m + 1), p.ring) * SM + xs;
                 const T *rbase = wrapz ? p.wrap - (RING ? xn - xs : m * SM) : p.r_in;  // wave-uniform: p.wrap + xs == rbase + xn
                 r_next = ldv<T, VEC>(rbase + xn);
                 P v1 = ldv_nt<T, VEC>(sM.in1 + xn);
@@ -343,7 +342,7 @@ __global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
                                                           lmC, sum, acc[0]);
 
             // (3) reconstruction update at row m (utils.pyx:90-104)
-            const P og = ldv_nt<T, VEC>(p.orig + (RING ? row_slot<RING>(m, p.ring_orig, p.phase_orig) * SM + xs : x));
+            const P og = ldv_nt<T, VEC>(p.orig + (RING ? row_slot<RING>(m, p.ring_orig) * SM + xs : x));
             P r_new;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
@@ -431,8 +430,6 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
         p.wrap = a->wrap_recon ? (const T *)a->wrap_recon : p.r_in + a->row_hi * (p.A * p.B * p.C);
     p.ring = (unsigned)a->ring_rows;
     p.ring_orig = (unsigned)(a->ring_rows ? (a->orig_ring_rows ? a->orig_ring_rows : a->shape[0]) : 0);
-    p.phase = p.ring ? (unsigned)(a->ring_phase % (int64_t)p.ring) : 0;
-    p.phase_orig = (p.ring && a->orig_ring_rows) ? (unsigned)(a->orig_ring_phase % (int64_t)p.ring_orig) : 0;
     if (!p.ring && getenv("TVDN_FORCE_RING") && a->shape[0] < (1LL << 31))  // measurement knob: the ring instantiation on
         p.ring = p.ring_orig = (unsigned)a->shape[0];                        // resident arrays (same rows, same bits)
     p.partials = ctx->partials;
@@ -550,8 +547,6 @@ extern "C" int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *a, double
     TVDN_REQUIRE(!(a->lo_mode == TVDN_EDGE_BC && a->bc_mode == TVDN_BC_PERIODIC && a->hi_mode != TVDN_EDGE_BC),
                  "periodic BC with lo_mode BC needs the whole ring in this block (hi_mode BC)");
     TVDN_REQUIRE(a->ring_rows >= 0 && a->orig_ring_rows >= 0, "negative ring size");
-    TVDN_REQUIRE(a->ring_phase >= 0 && a->orig_ring_phase >= 0, "negative ring phase");
-    TVDN_REQUIRE(a->ring_rows > 0 || (a->ring_phase == 0 && a->orig_ring_phase == 0), "ring phase without ring_rows");
     TVDN_REQUIRE(a->ring_rows > 0 || a->orig_ring_rows == 0, "orig_ring_rows without ring_rows");
     if (a->ring_rows > 0) {
         const long long s0 = (a->sweep_lo == 0 && a->sweep_hi == 0) ? a->row_lo : a->sweep_lo;

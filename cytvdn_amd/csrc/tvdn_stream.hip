@@ -293,7 +293,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
     const size_t box_b = aligned((size_t)R * row_bytes), plane_b = aligned(row_bytes);
     const size_t n_rings = (size_t)(K + 1) + (size_t)(K + 2) * nd;
     const size_t dev_bytes_max = n_rings * ring_b + oring_b * (want_mse ? 2 : 1) + 2 * (size_t)(n_in + n_out) * box_b +
-                                 2 * (size_t)(K + 1) * plane_b;  // (two copies of row 0 per level: chained passes)
+                                 (size_t)(K + 1) * plane_b;
     {
         size_t free_b = 0, total_b = 0;
         TVDN_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -352,7 +352,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
     TVDN_HIP(hipStreamCreateWithFlags(&st.main, hipStreamNonBlocking));
     TVDN_HIP(hipStreamCreateWithFlags(&st.up, hipStreamNonBlocking));
     TVDN_HIP(hipStreamCreateWithFlags(&st.down, hipStreamNonBlocking));
-    const size_t dev_bytes = dev_bytes_max - (exact_wrap ? 0 : 2 * (size_t)(K + 1) * plane_b);
+    const size_t dev_bytes = dev_bytes_max - (exact_wrap ? 0 : (size_t)(K + 1) * plane_b);
     DevMem mem, sums_d, mse_d;
     TVDN_HIP(hipMalloc(&mem.p, dev_bytes));
     TVDN_HIP(hipMemsetAsync(mem.p, 0, dev_bytes, st.main));
@@ -369,11 +369,9 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
         for (int i = 0; i < n_in; ++i) inbox[h][i] = take(box_b);
         for (int i = 0; i < n_out; ++i) outbox[h][i] = take(box_b);
     }
-    std::vector<char *> row0, row0_odd;  // row 0 of every level, kept for the top face; a second set for odd chained passes
-    if (exact_wrap) {
+    std::vector<char *> row0;  // row 0 of every level, kept for the top face
+    if (exact_wrap)
         for (int64_t j = 0; j <= K; ++j) row0.push_back(take(plane_b));
-        for (int64_t j = 0; j <= K; ++j) row0_odd.push_back(take(plane_b));
-    }
     auto A = [&](int64_t level, int q) -> Ring & { return Aw[(size_t)(level + 1) * nd + q]; };
 
     TVDN_HIP(hipMalloc(&sums_d.p, sizeof(double) * 3 * (size_t)std::max(1, n_total)));
@@ -580,193 +578,6 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
         return TVDN_OK;
     };
 
-    // ---- chained passes: the pipeline is not drained between passes ------------------------------------------------------
-    // Pass p + 1 starts uploading in the chunk after pass p's last upload, while pass p's upper levels are still climbing
-    // to the top face.  Rows are addressed by a running index G = p * Tc * R + g (Tc = chunks per pass), which the rings
-    // see as one endless cube (tvdn_iter_args.ring_phase); two passes meet in a level's ring only in the chunk where one
-    // ends and the next begins, the older one first.  A row must be home before it is uploaded again: N0 >= K + 4 R.
-    // The schedule is modelled in tests/test_wavefront_schedule_cpu.py::simulate_chained.
-    struct PassPlan {
-        int first = 0, kk = 0, n_in_state = 1, n_out_state = 1;
-        int64_t tail = 0;
-        std::vector<int> modes;
-        std::vector<double> tkp;
-    };
-    auto run_chained = [&](const double *ratios) -> int {
-        int rc2_unused = TVDN_OK;
-        const int64_t Tc = (N0 + R - 1) / R;
-        std::vector<PassPlan> plan;
-        {
-            bool form = d_form;
-            double prev = tk_prev;
-            for (int i = 0; i < n_total; i += (int)K) {
-                PassPlan pp;
-                pp.first = i;
-                pp.kk = (int)std::min<int64_t>(K, n_total - i);
-                pp.n_in_state = form ? 2 : 1;
-                for (int j = 0; j < pp.kk; ++j) {
-                    const bool acc = !std::isnan(ratios[i + j]);
-                    TVDN_REQUIRE(!acc || form, "a FISTA iteration cannot follow an unaccelerated one");
-                    pp.modes.push_back(iter_mode(acc, form));
-                    pp.tkp.push_back(prev);
-                    form = acc;
-                    if (acc) prev = ratios[i + j];
-                }
-                pp.n_out_state = form ? 2 : 1;
-                pp.tail = (N0 + pp.kk + R - 1) / R;
-                plan.push_back(pp);
-            }
-            d_form = form;
-            tk_prev = prev;
-        }
-        const int P = (int)plan.size();
-        const int64_t T = (int64_t)(P - 1) * Tc + plan[P - 1].tail;
-        // one event per (pass parity, chunk of the pass): "the rows this chunk sends home have arrived".  An upload of the
-        // next pass waits for exactly the download that brought ITS rows home -- several chunks back -- and so never
-        // for the download that is running beside it (waiting on the most recent one instead, as a first version did,
-        // serialises the two PCIe directions: 57 against 70 Gvoxel-iters/s drained, profiles/r03_outofcore_chained.jsonl)
-        int64_t max_tail = 0;
-        for (const PassPlan &pp : plan) max_tail = std::max(max_tail, pp.tail);
-        std::vector<hipEvent_t> home[2];
-        for (int par = 0; par < 2; ++par) {
-            home[par].resize((size_t)max_tail, nullptr);
-            for (hipEvent_t &e : home[par])
-                if ((rc2_unused = evs.make(&e))) return rc2_unused;
-        }
-        std::vector<int> home_pass[2] = {std::vector<int>((size_t)max_tail, -1), std::vector<int>((size_t)max_tail, -1)};
-        int64_t n_down = 0;
-
-        auto upload = [&](int64_t t) -> int {  // the rows global chunk t brings in
-            const int p = (int)(t / Tc);
-            if (p >= P) return TVDN_OK;
-            const int64_t c = t - (int64_t)p * Tc;
-            const int64_t u0 = c * R, u1 = std::min((c + 1) * R, N0);
-            if (u0 >= u1) return TVDN_OK;
-            const int h = (int)(t % 2);
-            if (in_free_set[h]) TVDN_HIP(hipStreamWaitEvent(st.up, in_free[h], 0));
-            if (p > 0) {  // the previous pass has sent these rows home: its chunk that downloads row u1 - 1
-                const int64_t cd = (u1 - 1 + plan[p - 1].kk) / R;
-                TVDN_REQUIRE(cd < plan[p - 1].tail && home_pass[(p - 1) % 2][(size_t)cd] == p - 1, "chained passes: rows uploaded before they are home");
-                TVDN_HIP(hipStreamWaitEvent(st.up, home[(p - 1) % 2][(size_t)cd], 0));
-            }
-            const size_t off = (size_t)u0 * row_bytes, len = (size_t)(u1 - u0) * row_bytes;
-            int i = 0;
-            TVDN_HIP(hipMemcpyAsync(inbox[h][i++], orig_h.p + off, len, hipMemcpyHostToDevice, st.up));
-            TVDN_HIP(hipMemcpyAsync(inbox[h][i++], recon_h.p + off, len, hipMemcpyHostToDevice, st.up));
-            for (int q = 0; q < nd; ++q)
-                for (int s = 0; s < plan[p].n_in_state; ++s)
-                    TVDN_HIP(hipMemcpyAsync(inbox[h][i++], state_h[(size_t)q * 2 + s].p + off, len, hipMemcpyHostToDevice, st.up));
-            TVDN_HIP(hipEventRecord(in_ready[h], st.up));
-            return TVDN_OK;
-        };
-
-        int rc2 = upload(0);
-        if (rc2) return rc2;
-        for (int64_t t = 0; t < T; ++t) {
-            if ((rc2 = upload(t + 1))) return rc2;
-            for (int p = 0; p < P; ++p) {  // older passes first
-                const int64_t c = t - (int64_t)p * Tc;
-                if (c < 0 || c >= plan[p].tail) continue;
-                const PassPlan &pp = plan[p];
-                const int64_t base = (int64_t)p * Tc * R;  // running row index of this pass's row 0
-                std::vector<char *> &r0 = (p % 2) ? row0_odd : row0;
-                const int64_t u0 = c * R, u1 = std::min((c + 1) * R, N0);
-                if (u0 < u1) {
-                    const int h = (int)(t % 2);
-                    TVDN_HIP(hipStreamWaitEvent(st.main, in_ready[h], 0));
-                    cdst.clear();
-                    csrc.clear();
-                    auto scatter = [&](const Ring &rg, const char *box) {
-                        for (int64_t g = u0; g < u1; ++g) {
-                            cdst.push_back(rg.row(base + g));
-                            csrc.push_back((void *)(box + (size_t)(g - u0) * row_bytes));
-                        }
-                    };
-                    int i = 0;
-                    scatter(Ow, inbox[h][i++]);
-                    scatter(Rw[0], inbox[h][i++]);
-                    for (int q = 0; q < nd; ++q) {
-                        scatter(A(0, q), inbox[h][i++]);
-                        if (pp.n_in_state == 2) scatter(A(-1, q), inbox[h][i++]);
-                    }
-                    if ((rc2 = copy_rows(cdst, csrc, row_bytes, st.main))) return rc2;
-                    if (exact_wrap && u0 == 0)
-                        TVDN_HIP(hipMemcpyAsync(r0[0], Rw[0].row(base), row_bytes, hipMemcpyDeviceToDevice, st.main));
-                    TVDN_HIP(hipEventRecord(in_free[h], st.main));
-                    in_free_set[h] = true;
-                }
-                it.ring_phase = base % cap;
-                it.orig_ring_phase = base % ocap;
-                for (int j = 0; j < pp.kk; ++j) {
-                    const int64_t lo = std::max<int64_t>(0, c * R - (j + 1)), hi = std::min<int64_t>(N0, (c + 1) * R - (j + 1));
-                    if (lo >= hi) continue;
-                    it.sweep_lo = lo;
-                    it.sweep_hi = hi;
-                    it.mode = pp.modes[j];
-                    it.tk = pp.modes[j] == TVDN_ITER_FISTA_D ? ratios[pp.first + j] : 0.0;
-                    it.tk_prev = pp.tkp[j];
-                    it.recon_in = Rw[j].base;
-                    it.recon_out = Rw[j + 1].base;
-                    it.wrap_recon = exact_wrap ? r0[j] : nullptr;
-                    for (int q = 0; q < nd; ++q) {
-                        char *cur = A(j, q).base, *prv = A(j - 1, q).base, *nxt = A(j + 1, q).base;
-                        it.b_in[q] = it.d_in[q] = it.dprev_in[q] = nullptr;
-                        it.b_out[q] = it.d_out[q] = nullptr;
-                        if (pp.modes[j] == TVDN_ITER_FISTA_D) {
-                            it.d_in[q] = cur; it.dprev_in[q] = prv; it.d_out[q] = nxt;
-                        } else if (pp.modes[j] == TVDN_ITER_FISTA_D_TO_PLAIN) {
-                            it.d_in[q] = cur; it.dprev_in[q] = prv; it.b_out[q] = nxt;
-                        } else {
-                            it.b_in[q] = cur; it.b_out[q] = nxt;
-                        }
-                    }
-                    rc2 = tvdn_iterate_fused(ctx.c, &it, (double *)sums_d.p + 3 * (size_t)(pp.first + j), st.main);
-                    if (rc2) return rc2;
-                    if (exact_wrap && lo == 0)
-                        TVDN_HIP(hipMemcpyAsync(r0[j + 1], Rw[j + 1].row(base), row_bytes, hipMemcpyDeviceToDevice, st.main));
-                }
-                const int64_t lo = std::max<int64_t>(0, c * R - pp.kk), hi = std::min<int64_t>(N0, (c + 1) * R - pp.kk);
-                if (lo < hi) {
-                    const int h = (int)(n_down++ % 2);
-                    if (out_free_set[h]) TVDN_HIP(hipStreamWaitEvent(st.main, out_free[h], 0));
-                    cdst.clear();
-                    csrc.clear();
-                    auto gather = [&](char *box, const Ring &rg) {
-                        for (int64_t g = lo; g < hi; ++g) {
-                            cdst.push_back(box + (size_t)(g - lo) * row_bytes);
-                            csrc.push_back(rg.row(base + g));
-                        }
-                    };
-                    int i = 0;
-                    gather(outbox[h][i++], Rw[pp.kk]);
-                    for (int q = 0; q < nd; ++q) {
-                        gather(outbox[h][i++], A(pp.kk, q));
-                        if (pp.n_out_state == 2) gather(outbox[h][i++], A(pp.kk - 1, q));
-                    }
-                    if ((rc2 = copy_rows(cdst, csrc, row_bytes, st.main))) return rc2;
-                    TVDN_HIP(hipEventRecord(out_ready[h], st.main));
-                    TVDN_HIP(hipStreamWaitEvent(st.down, out_ready[h], 0));
-                    const size_t off = (size_t)lo * row_bytes, len = (size_t)(hi - lo) * row_bytes;
-                    i = 0;
-                    TVDN_HIP(hipMemcpyAsync(recon_h.p + off, outbox[h][i++], len, hipMemcpyDeviceToHost, st.down));
-                    for (int q = 0; q < nd; ++q)
-                        for (int s = 0; s < pp.n_out_state; ++s)
-                            TVDN_HIP(hipMemcpyAsync(state_h[(size_t)q * 2 + s].p + off, outbox[h][i++], len, hipMemcpyDeviceToHost, st.down));
-                    TVDN_HIP(hipEventRecord(out_free[h], st.down));
-                    out_free_set[h] = true;
-                    TVDN_HIP(hipEventRecord(home[p % 2][(size_t)c], st.down));
-                    home_pass[p % 2][(size_t)c] = p;
-                }
-            }
-        }
-        it.ring_phase = it.orig_ring_phase = 0;
-        TVDN_HIP(hipStreamSynchronize(st.down));
-        TVDN_HIP(hipStreamSynchronize(st.main));
-        TVDN_HIP(hipStreamSynchronize(st.up));
-        done = n_total;
-        return TVDN_OK;
-    };
-
     // ---- the schedule: FISTA ratios in float64 on the host (cyTVDN.py:153-156), then the unaccelerated tail -------------
     std::vector<double> ratios((size_t)n_total);
     fista_ratios(a->n_fista, ratios.data());
@@ -781,13 +592,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
     };
     TVDN_HIP(hipStreamSynchronize(st.main));
     const auto t_passes = std::chrono::steady_clock::now();
-    const char *e_chain = getenv("TVDN_STREAM_CHAIN");
-    // TVDN_STREAM_CHAIN=1 asks for chained passes where the cube allows them (opt-in until measured and verified on the GPU)
-    const bool chain = !a->use_stop && !want_mse && n_total > K && N0 >= K + 4 * R && e_chain && atoi(e_chain) != 0;
-    if (chain) {
-        if ((rc = run_chained(ratios.data()))) return rc;
-        ran = n_total;
-    } else if (!a->use_stop) {
+    if (!a->use_stop) {
         for (int i = 0; i < n_total;) {  // a pass may hold the last FISTA iterations and the first unaccelerated ones
             const int kk = (int)std::min<int64_t>(K, n_total - i);
             if ((rc = pass(ratios.data() + i, kk))) return rc;

@@ -181,11 +181,6 @@ typedef struct tvdn_iter_args {
      * block loop it replaces upstream: cyTVDN/cyTVDN.py:148-242 on a cube that does not fit). */
     int64_t ring_rows;
     int64_t orig_ring_rows;
-    /* ABI 4: row m lives at slot (m + ring_phase) % ring_rows (orig: (m + orig_ring_phase) % orig_ring_rows); both >= 0.
-     * Lets a caller run several passes over the same rings without draining them in between (chained passes of the
-     * streamed engine: the rings see one endless cube of rows pass * rows_per_pass + m). */
-    int64_t ring_phase;
-    int64_t orig_ring_phase;
 } tvdn_iter_args;
 
 int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *args, double *sums_out, void *stream);

@@ -34,8 +34,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_iter_args_struct_matches_header_layout():
-    # 2 int32 + 4 int64 + 2 int64 + 4 int32 + 2 double + 8 doubles + 3 ptr + 20 ptr + 2 int64 + 2 int32 + 1 ptr (ABI v2) + 2 int64 (ABI v3: row rings) + 2 int64 (ABI v4: ring phases)
-    assert ctypes.sizeof(_lib.IterArgs) == 8 + 32 + 16 + 16 + 16 + 64 + 24 + 160 + 16 + 8 + 8 + 16 + 16
+    # 2 int32 + 4 int64 + 2 int64 + 4 int32 + 2 double + 8 doubles + 3 ptr + 20 ptr + 2 int64 + 2 int32 + 1 ptr (ABI v2) + 2 int64 (ABI v3: row rings)
+    assert ctypes.sizeof(_lib.IterArgs) == 8 + 32 + 16 + 16 + 16 + 64 + 24 + 160 + 16 + 8 + 8 + 16
     assert _lib.IterArgs.shape.offset == 8 and _lib.IterArgs.tk.offset == 72 and _lib.IterArgs.orig.offset == 152
     assert _lib.IterArgs.dprev_in.offset == 304 and _lib.IterArgs.sweep_lo.offset == 336
 
@@ -163,7 +163,7 @@ def test_struct_layouts_match_the_c_header(tmp_path):
                    '#define P(s, f) printf(#s "." #f " %zu\\n", offsetof(s, f))\n'
                    'int main(void) {\n'
                    '  printf("tvdn_iter_args %zu\\n", sizeof(tvdn_iter_args)); P(tvdn_iter_args, wrap_recon); P(tvdn_iter_args, ring_rows);\n'
-                   '  P(tvdn_iter_args, orig_ring_rows); P(tvdn_iter_args, ring_phase); P(tvdn_iter_args, orig_ring_phase); P(tvdn_iter_args, accumulate);\n'
+                   '  P(tvdn_iter_args, orig_ring_rows); P(tvdn_iter_args, accumulate);\n'
                    '  printf("tvdn_many_args %zu\\n", sizeof(tvdn_many_args)); P(tvdn_many_args, recon); P(tvdn_many_args, S); P(tvdn_many_args, tk_prev);\n'
                    '  printf("tvdn_run_args %zu\\n", sizeof(tvdn_run_args)); P(tvdn_run_args, stop); P(tvdn_run_args, data); P(tvdn_run_args, devices);\n'
                    '  P(tvdn_run_args, stream_rows); P(tvdn_run_args, stream_k); P(tvdn_run_args, phase_iters); P(tvdn_run_args, n_devices);\n'

@@ -65,17 +65,13 @@ def _run(x, mu, n_f, n_p, stop=None, ref=None, stream=None, device=0):
     ((5, 3, 4, 8), np.float32, 12, 0, 16, 5),         # chunk taller than the cube
     ((19, 3, 4, 8), np.float32, 6, 3, 1, 7),          # one-row chunks
     ((40, 4, 8, 16), np.float32, 11, 0, 8, 128),      # k beyond the iteration count: one pass
-    ((40, 4, 8, 16), np.float32, 11, 0, 4, 3),        # four passes, chained when asked to
-    ((40, 4, 8, 16), np.float32, 7, 6, 3, 4),         # the d -> b transition inside a chained run
+    ((40, 4, 8, 16), np.float32, 11, 0, 4, 3),        # four passes
+    ((40, 4, 8, 16), np.float32, 7, 6, 3, 4),         # the d -> b transition inside the second pass
     ((37, 6, 16), np.float64, 0, 9, 2, 2),            # odd row count: the last chunk of a pass is short
-    ((33, 3, 4, 8), np.float32, 10, 0, 1, 5),         # one-row chunks, chained
+    ((33, 3, 4, 8), np.float32, 10, 0, 1, 5),         # one-row chunks, two passes
 ])
-@pytest.mark.parametrize("chain", ["1", "0"], ids=["chained", "drained"])
-def test_streamed_run_equals_resident_run(oracle, monkeypatch, shape, dtype, n_f, n_p, rows, k, chain):
-    """`chain`: several passes back to back without draining the pipeline (where the cube is tall enough for it:
-    rows >= k + 4 x chunk height and more iterations than k), or every pass on its own."""
+def test_streamed_run_equals_resident_run(oracle, shape, dtype, n_f, n_p, rows, k):
     from cytvdn_amd import synth
-    monkeypatch.setenv("TVDN_STREAM_CHAIN", chain)
     dt = np.dtype(dtype)
     nd = len(shape)
     x = synth.cube(shape, seed=61, dtype=dt) + dt.type(0.25)
@@ -118,7 +114,7 @@ def test_streamed_run_with_stopping_rule(oracle, shape, dtype, n_f, n_p, stop, r
     np.testing.assert_allclose(got[1][ran, 1], ref["delta64"][ran], rtol=1e-9)
 
 
-def test_streamed_run_mse_trace_and_nonfinite_first_row(oracle, monkeypatch):
+def test_streamed_run_mse_trace_and_nonfinite_first_row(oracle):
     from cytvdn_amd import synth
     dt = np.dtype(np.float32)
     shape = (14, 3, 6, 8)
@@ -142,13 +138,11 @@ def test_streamed_run_mse_trace_and_nonfinite_first_row(oracle, monkeypatch):
     assert bits_equal(got[0], want[0])
     oref = _oracle(oracle, x, mu, 5, 0)
     assert np.isnan(oref["recon"][-1]).any() and bits_equal(got[0], oref["recon"])   # NaNs where the oracle has them
-    # ... and in a chained run, where two passes' copies of row 0 are alive at once (14 rows >= 2 + 4 x 2)
+    # ... and over four passes of two levels
     want = _run(x, mu, 7, 0)
-    for chain in ("0", "1"):
-        monkeypatch.setenv("TVDN_STREAM_CHAIN", chain)
-        got = _run(x, mu, 7, 0, stream=(2, 2))
-        assert bits_equal(got[0], want[0]), chain
-        assert bits_equal(got[0], _oracle(oracle, x, mu, 7, 0)["recon"]), chain
+    got = _run(x, mu, 7, 0, stream=(2, 2))
+    assert bits_equal(got[0], want[0])
+    assert bits_equal(got[0], _oracle(oracle, x, mu, 7, 0)["recon"])
     # a hybrid schedule whose d -> b transition falls INSIDE a pass, on rings, with the non-finite first row
     got = _run(x, mu, 3, 3, stream=(3, 4))
     assert bits_equal(got[0], _oracle(oracle, x, mu, 3, 3)["recon"])

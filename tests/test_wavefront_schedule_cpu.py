@@ -70,73 +70,3 @@ def test_a_ring_one_row_shorter_would_lose_rows():
     exec(text, g)
     with pytest.raises(AssertionError):
         g["shorter"](17, 4, 5)
-
-
-def simulate_chained(N0, R, K, P):
-    """P passes back to back WITHOUT draining the pipeline in between (the plan for the next round): pass
-    p + 1 starts uploading in the chunk after pass p's last upload, while pass p's upper levels are still working their way
-    to the top face.  Rows are addressed by a running index G = p * Tc * R + g (Tc = chunks per pass), so that the rings
-    see one endless cube; the model checks the same things as `simulate`, plus that a row is uploaded for pass p + 1 only
-    after pass p has sent it home (with a chunk to spare for the prefetch)."""
-    cap, ocap = R + 2, R + K + 3
-    Tc = -(-N0 // R)
-    tail = -(-(N0 + K) // R)                        # chunks a pass is active for
-    recon = [dict() for _ in range(K + 1)]
-    state = [dict() for _ in range(K + 2)]
-    orig = {}
-    produced, home_at, up_at = set(), {}, {}
-    for t in range((P - 1) * Tc + tail):
-        for p in range(P):                          # older passes first: their rows sit at lower running indices
-            c = t - p * Tc
-            if c < 0 or c >= tail:
-                continue
-            base = p * Tc * R
-            u0, u1 = c * R, min((c + 1) * R, N0)
-            for g in range(u0, u1):
-                if p > 0:
-                    assert home_at[(p - 1, g)] < t - 1, ("upload before the previous pass sent the row home", N0, R, K, p, g)
-                up_at[(p, g)] = t
-                G = base + g
-                orig[G % ocap] = ("orig", p, g)
-                recon[0][G % cap] = (p, 0, g)
-                state[1][G % cap] = (p, 0, g)
-                state[0][G % cap] = (p, -1, g)
-            for j in range(K):
-                lo, hi = max(0, c * R - (j + 1)), min(N0, (c + 1) * R - (j + 1))
-                if lo >= hi:
-                    continue
-                for g in range(max(0, lo - 1), min(N0, hi + 1)):
-                    assert recon[j].get((base + g) % cap) == (p, j, g), ("recon", N0, R, K, P, t, p, j, g)
-                for g in range(lo, min(N0, hi + 1)):
-                    assert state[j + 1].get((base + g) % cap) == (p, j, g), ("state", N0, R, K, P, t, p, j, g)
-                    assert state[j].get((base + g) % cap) == (p, j - 1, g), ("state-prev", N0, R, K, P, t, p, j, g)
-                for g in range(lo, hi):
-                    assert orig.get((base + g) % ocap) == ("orig", p, g), ("orig", N0, R, K, P, t, p, j, g)
-                for g in range(lo, hi):
-                    assert (p, j + 1, g) not in produced
-                    produced.add((p, j + 1, g))
-                    recon[j + 1][(base + g) % cap] = (p, j + 1, g)
-                    state[j + 2][(base + g) % cap] = (p, j + 1, g)
-            lo, hi = max(0, c * R - K), min(N0, (c + 1) * R - K)
-            for g in range(lo, hi):
-                assert recon[K].get((base + g) % cap) == (p, K, g)
-                assert state[K].get((base + g) % cap) == (p, K - 1, g)
-                home_at[(p, g)] = t
-    assert produced == {(p, j, g) for p in range(P) for j in range(1, K + 1) for g in range(N0)}
-    assert len(home_at) == P * N0
-    return (P - 1) * Tc + tail
-
-
-@pytest.mark.parametrize("N0,R,K", [(40, 4, 5), (40, 1, 7), (64, 16, 30), (33, 2, 9), (256, 16, 128), (24, 8, 3), (17, 3, 4)])
-def test_chained_passes_keep_every_ring_consistent(N0, R, K):
-    """Feasible whenever the cube has at least K + 2R more rows than... precisely: when the model's own upload-after-home
-    assertion holds; these shapes satisfy N0 >= K + 2 R."""
-    assert N0 >= K + 2 * R
-    chunks = simulate_chained(N0, R, K, 3)
-    unchained = 3 * simulate(N0, R, K)
-    assert chunks < unchained                       # the fill/drain of two pass boundaries is gone
-
-
-def test_chaining_needs_a_cube_taller_than_the_depth():
-    with pytest.raises(AssertionError, match="upload before"):
-        simulate_chained(12, 4, 9, 2)
