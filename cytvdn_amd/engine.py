@@ -13,8 +13,9 @@ update with a constant (TVDN_EDGE_ZERO) instead of a message from rank 0.  If ro
 into the LAST row.  `SlabLayout(..., wrap_row=True)` reproduces that: rank 0 then also sends its first row to the last
 rank every iteration, which forms the wrapped accumulator from it as upstream does (TVDN_EDGE_WRAP).  `denoise_slabs`,
 `denoise3D/4D` (wavefront / staged engines, single process) and `tvdn_run` switch it on by themselves when the first
-row of the input is not finite; `bench.py` and finite data never pay for the extra message.  Left out: staged slabs
-across ranks (`denoise_slabs(staged=...)`), which keep the constant.
+row of the input is not finite; `bench.py` and finite data never pay for the extra message.  Staged slabs across ranks
+(`denoise_slabs(staged=...)`, wavefront schedule) relay row 0 of every level of a pass from rank 0 to the last rank
+(outofcore.Row0Relay); with a stopping rule (trapezoid engine across ranks) such a cube is refused.
 
 Pieces
 ------

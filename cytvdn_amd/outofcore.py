@@ -108,6 +108,54 @@ class HaloSwap:
             view.copy_(buf)
 
 
+class Row0Relay:
+    """Staged slabs, Jia-Zhao, a cube whose FIRST row is not finite: the last rank closes the wrap of the reconstruction
+    update with the accumulator upstream forms from the CURRENT recon of global row 0 (anisotropic.pyx:65-73; tvdn.h
+    TVDN_EDGE_WRAP) -- at every iteration level of a temporally blocked pass.  Rank 0 computes row 0 of all levels in
+    the first chunks of its pass; the last rank needs them in the last chunks of its own: one message per pass, posted
+    early on both sides, so it hides under the pass.  gloo moves host memory, RCCL device memory."""
+
+    def __init__(self, dist, group, rank, world, planes):
+        self.dist, self.group, self.rank, self.world, self.planes = dist, group, rank, world, planes
+        self.via_dev = dist.get_backend(group) != "gloo"
+        self.peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+        self._work = self._buf = None
+        self.n = 0
+
+    def _staging(self, n):
+        p = self.planes[0]
+        return torch.empty((n,) + tuple(p.shape), dtype=p.dtype, device=p.device if self.via_dev else "cpu")
+
+    def post_recv(self, n):
+        """Last rank, at the start of a pass of n - 1 levels."""
+        self.n, self._buf = n, self._staging(n)
+        self._work = self.dist.irecv(self._buf, self.peer(0), group=self.group, tag=1000)
+
+    def send(self, n):
+        """Rank 0, once planes[0 .. n) hold row 0 of levels 0 .. n - 1 (the stream that wrote them is joined here)."""
+        torch.cuda.current_stream(self.planes[0].device).synchronize()
+        self._buf = self._staging(n)
+        for j in range(n):
+            self._buf[j].copy_(self.planes[j])
+        torch.cuda.current_stream(self.planes[0].device).synchronize()
+        self._work = self.dist.isend(self._buf, self.peer(self.world - 1), group=self.group, tag=1000)
+
+    def wait_recv(self):
+        """Last rank, before its first sweep at the cube's top face."""
+        if self._work is None:
+            return
+        self._work.wait()
+        for j in range(self.n):
+            self.planes[j].copy_(self._buf[j])
+        self._work = self._buf = None
+
+    def finish(self):
+        """Rank 0, at the end of the pass."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = self._buf = None
+
+
 def exchange_halo_rows(dist, group, rank, world, device, arrays, lo, hi, ext_lo, ext_hi, depth):
     """Blocking form of HaloSwap: both shifts completed on return."""
     HaloSwap(dist, group, rank, world, device).start(arrays, lo, hi, ext_lo, ext_hi, depth, overlap=False)

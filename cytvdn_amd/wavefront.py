@@ -203,9 +203,13 @@ class WavefrontRunner:
         # from the recon of global row 0 AT THEIR OWN LEVEL (TVDN_EDGE_WRAP) instead of taking it as zero, which it is
         # only while row 0 is finite (engine.py, "Non-finite data").  Row 0 of every level is computed at the start of a
         # pass and has long left its window when the top is reached, so one plane per level is kept aside.
-        self.row0 = None
-        if exact_wrap and self.world == 1 and not self.periodic:
+        # Across ranks (staged slabs) rank 0 stashes the planes and sends them to the last rank once per pass (Row0Relay).
+        self.row0 = self._relay = None
+        if exact_wrap and not self.periodic and (self.world == 1 or self.rank in (0, self.world - 1)):
             self.row0 = [torch.empty(tuple(plane), dtype=tdt, device=dev) for _ in range(K + 1)]
+            if self.world > 1:
+                from .outofcore import Row0Relay
+                self._relay = Row0Relay(self.dist, self.group, self.rank, self.world, self.row0)
 
     def _wrap_rows(self, arrays, depth):
         """Periodic BC: the halo rows below the first / above the last own row are the cube's own other end."""
@@ -242,7 +246,7 @@ class WavefrontRunner:
         # stashed row 0); periodic runs extend the cube instead and never sweep a row next to row_hi
         A.hi_mode = _lib.EDGE_BC if self.periodic else _lib.EDGE_ZERO
         A.wrap_recon = None
-        if self.row0 is not None:
+        if self.row0 is not None and self.g1 == N0:        # the rank (or the one process) that owns the cube's top face
             A.hi_mode, A.wrap_recon = _lib.EDGE_WRAP, self.row0[j].data_ptr()
         A.bc_mode = self.bc
         A.mode = mode
@@ -343,9 +347,16 @@ class WavefrontRunner:
             self.bytes_h2d += len(pairs) * n * self.row_bytes
             in_ready[c % 2] = evs
 
+        relay = self._relay
+        stash = self.row0 is not None and g0 == 0           # this rank computes global row 0
+        stashed, sent = 0, False
+        if relay is not None and self.rank == self.world - 1:
+            relay.post_recv(kk + 1)
         upload(0)
         for c in range(n_chunks):
             upload(c + 1)                                   # next chunk crosses PCIe while this one is swept
+            if relay is not None and self.rank == self.world - 1 and E0 + (c + 1) * R - 1 >= N0:
+                relay.wait_recv()                           # this chunk's level 0 reaches the top face (no-op afterwards)
             u0, u1 = E0 + c * R, min(E0 + (c + 1) * R, E1)
             if u0 < u1:
                 n = u1 - u0
@@ -362,7 +373,7 @@ class WavefrontRunner:
                     rings.append(self.Fw)
                     srcs.append(box[-1])
                 _lib.copy_many([(rg.row(g), src[g - u0]) for rg, src in zip(rings, srcs) for g in range(u0, u1)], self.device)
-                if self.row0 is not None and u0 == 0:
+                if stash and u0 == 0:
                     self.row0[0].copy_(self.Rw[0].row(0))
                 if self.Fw is not None and self.iters_done == 0:
                     # MSE[0]: the input against the reference (cyTVDN.py:124-125), own rows
@@ -382,11 +393,15 @@ class WavefrontRunner:
                 for x0, x1, slot in ((a, min(b, g0), discard), (max(a, g0), min(b, g1), slot0 + j), (max(a, g1), b, discard)):
                     if x0 < x1:
                         self._launch(j, x0, x1, ratios[j], tkp[j], modes[j], slot)
-                        if self.row0 is not None and x0 == 0:
+                        if stash and x0 == 0:
                             self.row0[j + 1].copy_(self.Rw[j + 1].row(0))
+                            stashed += 1
                         if self.Fw is not None and slot != discard:
                             for g in range(x0, x1):
                                 self._sse(self.Fw.row(g)[None], self.Rw[j + 1].row(g)[None], slot + 1)
+            if relay is not None and self.rank == 0 and stashed == kk and not sent:
+                relay.send(kk + 1)                          # row 0 of every level of this pass is final: off to the last rank
+                sent = True
             if trace is not None:
                 trace.append(("sweep", c, t0, mark(main)))
             # own rows that have reached the last level go home
@@ -432,6 +447,8 @@ class WavefrontRunner:
         for st in self.downs:
             st.synchronize()
         main.synchronize()
+        if relay is not None:
+            relay.finish()
         if trace:
             # timeline of the pass relative to its first event (ms): start-end of every phase, to see what overlaps what
             ref = trace[0][2]

@@ -77,7 +77,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, shape, dtype_name, its, outdir):
+def _worker(rank, world, port, shape, dtype_name, its, outdir, staged=None, stop=None):
     import torch
     import torch.distributed as dist
     from cytvdn_amd.distributed import denoise_slabs, slab_rows
@@ -89,8 +89,12 @@ def _worker(rank, world, port, shape, dtype_name, its, outdir):
         dt = np.dtype(dtype_name)
         x = _cube(shape, dt)
         g0, g1 = slab_rows(shape, rank, world)
-        own, bn, dl = denoise_slabs(x[g0:g1], shape, _mu(len(shape), dt), its, FISTA=True)
-        np.savez(os.path.join(outdir, f"r{rank}.npz"), own=own)
+        try:
+            own, bn, dl = denoise_slabs(x[g0:g1], shape, _mu(len(shape), dt), its, FISTA=True, staged=staged,
+                                        stopping_relative_change=stop)
+            np.savez(os.path.join(outdir, f"r{rank}.npz"), own=own)
+        except NotImplementedError as e:
+            np.savez(os.path.join(outdir, f"r{rank}.npz"), refused=str(e))
     finally:
         dist.destroy_process_group()
 
@@ -105,6 +109,36 @@ def test_denoise_slabs_switches_the_wrap_row_on_by_itself(oracle):
     dt = np.dtype(dtype)
     ref = oracle.denoise(_cube(shape, dt), _mu(4, dt), its, True)
     assert np.isnan(ref["recon"][-1]).any() and bits_equal(recon, ref["recon"])
+
+
+@pytest.mark.parametrize("world,shape,dtype,its,staged", [
+    (2, (20, 3, 4, 8), "float32", 9, (4, 3)),            # three passes of three levels, several chunks per rank
+    (3, (19, 6, 16), "float64", [5, 4], (3, 4)),         # hybrid, the d -> b transition inside a pass, uneven slabs
+    (2, (24, 2, 5, 7), "float32", 7, (2, 8)),            # more levels than chunk rows: row 0 of level j is final only in chunk j / R
+])
+def test_staged_slabs_carry_the_wrap_row_across_ranks(oracle, world, shape, dtype, its, staged):
+    """Slabs in pinned host memory, wavefront schedule inside each (BASELINE config 5 in structure): rank 0 sends row 0 of
+    every level of a pass to the last rank, which closes the Jia-Zhao wrap with it (TVDN_EDGE_WRAP) -- the NaN upstream
+    carries from a non-finite first row into the LAST row (anisotropic.pyx:65-73, utils.pyx:98-101) must appear."""
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.start_processes(_worker, args=(world, _free_port(), shape, dtype, its, tmp, staged), nprocs=world, join=True,
+                           start_method="spawn")
+        recon = np.concatenate([np.load(os.path.join(tmp, f"r{r}.npz"))["own"] for r in range(world)], axis=0)
+    dt = np.dtype(dtype)
+    ref = oracle.denoise(_cube(shape, dt), _mu(len(shape), dt), its, True)
+    assert np.isnan(ref["recon"][-1]).any() and bits_equal(recon, ref["recon"])
+
+
+def test_staged_slabs_with_a_stopping_rule_refuse_a_nonfinite_first_row():
+    """The trapezoid engine across ranks has no wrap row: it says so instead of returning the constant's numbers."""
+    import torch.multiprocessing as mp
+    shape, world = (12, 3, 4, 8), 2
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.start_processes(_worker, args=(world, _free_port(), shape, "float32", 6, tmp, (3, 2), 1e-9), nprocs=world,
+                           join=True, start_method="spawn")
+        for r in range(world):
+            assert "first row" in str(np.load(os.path.join(tmp, f"r{r}.npz"))["refused"])
 
 
 @pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0, 0]])
