@@ -34,7 +34,7 @@ At N = 1 the line also carries
                 200-iteration denoise4D sees once the device has settled, next to the short headline run.
   placement     the sweep's speed depends on which physical pages the state's allocation got (same clocks, same virtual
                 address, 11.2 / 12.1 / 12.6 ms for config 2: profiles/r03_placement_audition_*.jsonl), so the engine tries
-                --audition N placements (default 3, as many as fit the HBM) and keeps the fastest -- as denoise3D/4D do
+                --audition N placements (default 4, as many as fit the HBM) and keeps the fastest -- as denoise3D/4D do
                 for runs of >= 100 iterations; config.placement_audition_ms lists the candidates' probe times (kept one
                 first), so the spread of the box is in the line.  Untimed set-up, like the allocation itself.
 Every roofline object carries the per-step sweep-kernel time as mean, minimum, median and maximum (HIP events per launch).
@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--slab-of", type=int, default=0, metavar="N",
                     help="single GPU: run ONE interior slab of an N-slab job (halo edges, edge rows first, halo rows "
                          "refreshed by device copies) instead of the whole cube; --shape is then the GLOBAL shape")
-    ap.add_argument("--audition", type=int, default=3, metavar="N",
+    ap.add_argument("--audition", type=int, default=4, metavar="N",
                     help="placements of the state tried before the run, the fastest kept (engine.HipBackend.best_of: the "
                          "sweep's speed depends on which physical pages the allocation got); 1 = take the first")
     ap.add_argument("--no-also", action="store_true", help="skip the extra single-GPU configurations")

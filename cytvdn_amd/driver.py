@@ -63,12 +63,12 @@ def _split_iterations(iterations, FISTA):
 def _audition_candidates(n_total: int) -> int:
     """How many placements of the state `HipBackend.best_of` may try before an in-core run: a candidate costs about
     three sweeps and the spread between placements is ~10 % of a sweep (engine.HipBackend.best_of), so three
-    candidates pay for themselves from ~100 iterations on; shorter runs take the first allocation.
+    candidates pay for themselves from ~100 iterations on (four from 200); shorter runs take the first allocation.
     TVDN_AUDITION=n overrides (1 = never)."""
     e = os.environ.get("TVDN_AUDITION")
     if e is not None:
         return max(1, int(e))
-    return 3 if n_total >= 100 else 1
+    return 4 if n_total >= 200 else (3 if n_total >= 100 else 1)
 
 
 def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, reference_data, BC_mode, quiet,
