@@ -483,10 +483,16 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
             gt = c ? atoll(c + 1) : 8;
         }
         p.patch_a = p.patch_t = p.tiles_per_arow = 0;
-        if (nax == 4 && ga > 1 && gt >= 1 && tr > 0 && tr % gt == 0 && (e_patch ? tr >= gt : tr >= 32) && p.A % ga == 0) {
+        // ... in launches of many marches (config 3: 32).  The launches of a slab iteration are short -- 8-row edge blocks
+        // and a 48-row interior, 1 and 6 marches -- and there the plain order, still without the remap, is the better one
+        // (same file of the A/B as bench.py --slab-of 8 runs it, profiles/r03_ab_inproc_slab_mode.jsonl: 22.99 ms against
+        // 23.39 with the patches and 23.16 with round 2's order).
+        const long long n_march = (rows + chunk - 1) / chunk;
+        const bool long_rows = nax == 4 && tr >= 32;
+        if (nax == 4 && ga > 1 && gt >= 1 && tr > 0 && tr % gt == 0 && (e_patch ? tr >= gt : (long_rows && n_march >= 16)) && p.A % ga == 0) {
             p.patch_a = ga; p.patch_t = gt; p.tiles_per_arow = tr;
         }
-        p.xcd = e_xcd ? atoi(e_xcd) : (p.patch_a > 1 ? 0 : 1);
+        p.xcd = e_xcd ? atoi(e_xcd) : (long_rows ? 0 : 1);
     }
     TVDN_REQUIRE(grid >= 1 && grid <= kMaxPartialBlocks, "fused grid %lld out of range (max %d)", grid, kMaxPartialBlocks);
     {

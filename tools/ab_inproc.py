@@ -22,7 +22,10 @@ from cytvdn_amd.engine import HipBackend, SlabLayout, fista_ratios
 CONFIGS = {"2": ((256, 256, 128, 128), np.float32, True), "3": ((256, 256, 128, 128), np.float64, False),
            "plain32": ((256, 256, 128, 128), np.float32, False), "3d": ((512, 512, 512), np.float32, True),
            "3dplain": ((512, 512, 512), np.float32, False), "c1": ((128, 128, 512), np.float32, True),
-           "slab": ((66, 512, 256, 256), np.float32, True), "f64fista": ((256, 256, 128, 128), np.float64, True)}
+           "slab": ((66, 512, 256, 256), np.float32, True), "f64fista": ((256, 256, 128, 128), np.float64, True),
+           # one interior slab of BASELINE configs[3] exactly as bench.py --slab-of 8 runs it: halo edges, two 8-row edge
+           # launches, halo rows refreshed on a side stream, then the 48-row interior launch
+           "slab8": ((512, 512, 256, 256), np.float32, True)}
 
 
 def main():
@@ -40,10 +43,11 @@ def main():
     lam = mu / dt.type(32.0 if nd == 4 else 16.0)
     R = fista_ratios(4096)
     L = _lib.lib()
-    be = HipBackend.best_of(a.audition, SlabLayout(shape, 0, 1, 2), dt, fista, device=0, max_iters=a.steps + 4)
+    lay = SlabLayout(shape, 4, 8, 2) if a.config == "slab8" else SlabLayout(shape, 0, 1, 2)
+    be = HipBackend.best_of(a.audition, lay, dt, fista, device=0, max_iters=a.steps + 4)
     be.set_params(1.0 / lam, (lam / mu).astype(dt))
-    _lib.check(L.tvdn_synth_fill(be.code, nd, _lib.shape_arr(shape), synth.SEED_4D if nd == 4 else synth.SEED_3D, 0, shape[0],
-                                 be.orig.data_ptr(), _lib.current_stream(0)))
+    _lib.check(L.tvdn_synth_fill(be.code, nd, _lib.shape_arr(shape), synth.SEED_4D if nd == 4 else synth.SEED_3D,
+                                 lay.g0 - lay.halo_lo, lay.local_shape[0], be.orig.data_ptr(), _lib.current_stream(0)))
     be.recon[be.cur].copy_(be.orig)
     variants = []
     for v in a.variants:
@@ -67,7 +71,17 @@ def main():
             libs[path] = (Lx, h)
     libs[None] = (L, be.ctx)
 
+    emu = None
+    if a.config == "slab8":
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        emu = bench.EmulatedNeighbours(be)
+
     def step(Lx, ctx, tk, slot):
+        if emu is not None:                 # three launches per iteration, default library only
+            assert Lx is L, "slab8 runs the default library"
+            emu._step(tk, slot)
+            return
         be._bind(tk)
         be._args.sweep_lo = be._args.sweep_hi = 0
         be._args.accumulate = 0
@@ -98,11 +112,11 @@ def main():
                 step(Lx, ctx, float(R[min(it, 4095)]) if fista else None, 2 + i)
                 it += 1
             torch.cuda.synchronize()
-            each = (C.c_double * (a.steps + 4))()
+            each = (C.c_double * (3 * a.steps + 4))()
             nl = C.c_int64()
-            assert Lx.tvdn_ctx_timing_read_each(ctx, each, a.steps + 4, C.byref(nl)) == 0
+            assert Lx.tvdn_ctx_timing_read_each(ctx, each, 3 * a.steps + 4, C.byref(nl)) == 0
             assert Lx.tvdn_ctx_timing_enable(ctx, 0) == 0
-            res[label].append(float(np.mean(each[:nl.value])))
+            res[label].append(float(np.sum(each[:nl.value])) / a.steps)     # per iteration (slab8: three launches each)
     base = np.mean(res[variants[0][0]])
     for label, env in variants:
         v = res[label]
