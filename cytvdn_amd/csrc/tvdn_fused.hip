@@ -128,31 +128,53 @@ __device__ __forceinline__ Pack<T, VEC> ldx(const T *p)
     return ldv<T, VEC>(p);
 }
 
+// Loads and arithmetic of an axis are separate steps: a row's loads -- M look-ahead, A, B, C and orig, 18 packs + 4 scalars
+// in 4-D FISTA -- are ALL issued before the first value is used (fused_iter_kernel), so that a wave has a whole row of
+// requests in flight instead of one axis at a time (the compiler keeps source order across the ~100 instructions of an
+// axis, and each axis used to end in s_waitcnt vmcnt(0): five dependent round trips to memory per row).
+template <typename T, int VEC>
+struct PackLoads {  // axes A and B
+    Pack<T, VEC> rp, rn, v1_own, v1_nx, v2_own, v2_nx;
+};
+
+template <typename T, int VEC>
+struct ContigLoads {  // axis C
+    T r_before, r_after, v1_after, v2_after;
+    Pack<T, VEC> v1_own, v2_own;
+};
+
 template <typename T, int VEC, int MODE, bool nt_own, bool nt_next>
-__device__ __forceinline__ void axis_pack(const Pack<T, VEC> &r_cur, const T *__restrict__ r_in,
-                                          const AxisState<T> &s, long long x, long long off_prev,
-                                          long long off_next, bool self_next, T tk, T tkp, T cl, T lm,
-                                          Pack<T, VEC> &sum, double &bnorm)
+__device__ __forceinline__ void load_pack(PackLoads<T, VEC> &l, const T *__restrict__ r_in, const AxisState<T> &s, long long x,
+                                          long long off_prev, long long off_next)
+{
+    using M = ModeTraits<MODE>;
+    l.rp = ldv<T, VEC>(r_in + x + off_prev);
+    l.rn = ldv<T, VEC>(r_in + x + off_next);
+    l.v1_own = ldx<T, VEC, nt_own>(s.in1 + x);
+    l.v1_nx = ldx<T, VEC, nt_next>(s.in1 + x + off_next);
+    if (M::kIn2) {
+        l.v2_own = ldx<T, VEC, nt_own>(s.in2 + x);
+        l.v2_nx = ldx<T, VEC, nt_next>(s.in2 + x + off_next);
+    }
+}
+
+// Axis whose neighbours are whole packs (A and B): update own state at x, recompute b_new at the
+// +1 neighbour, add lm * (b_new(x) - b_new(x+e)) to `sum` (left-to-right as utils.c:5641).
+template <typename T, int VEC, int MODE>
+__device__ __forceinline__ void axis_pack(const Pack<T, VEC> &r_cur, const PackLoads<T, VEC> &l, const AxisState<T> &s,
+                                          long long x, bool self_next, T tk, T tkp, T cl, T lm, Pack<T, VEC> &sum,
+                                          double &bnorm)
 {
     using P = Pack<T, VEC>;
     using M = ModeTraits<MODE>;
-    const P rp = ldv<T, VEC>(r_in + x + off_prev);
-    const P rn = ldv<T, VEC>(r_in + x + off_next);
-    const P v1_own = ldx<T, VEC, nt_own>(s.in1 + x);
-    const P v1_nx = ldx<T, VEC, nt_next>(s.in1 + x + off_next);
-    P v2_own, v2_nx;
-    if (M::kIn2) {
-        v2_own = ldx<T, VEC, nt_own>(s.in2 + x);
-        v2_nx = ldx<T, VEC, nt_next>(s.in2 + x + off_next);
-    }
     P o1, o2;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        const T bn_own = acc_new<T, MODE>(r_cur.v[j], rp.v[j], v1_own.v[j], M::kIn2 ? v2_own.v[j] : (T)0, tk, tkp, cl,
+        const T bn_own = acc_new<T, MODE>(r_cur.v[j], l.rp.v[j], l.v1_own.v[j], M::kIn2 ? l.v2_own.v[j] : (T)0, tk, tkp, cl,
                                           o1.v[j], o2.v[j]);
         T u1, u2;
-        const T bn_next = acc_new<T, MODE>(rn.v[j], self_next ? rn.v[j] : r_cur.v[j], v1_nx.v[j],
-                                           M::kIn2 ? v2_nx.v[j] : (T)0, tk, tkp, cl, u1, u2);
+        const T bn_next = acc_new<T, MODE>(l.rn.v[j], self_next ? l.rn.v[j] : r_cur.v[j], l.v1_nx.v[j],
+                                           M::kIn2 ? l.v2_nx.v[j] : (T)0, tk, tkp, cl, u1, u2);
         sum.v[j] = sum.v[j] + lm * (bn_own - bn_next);
         bnorm += fabs((double)bn_own);
     }
@@ -160,33 +182,38 @@ __device__ __forceinline__ void axis_pack(const Pack<T, VEC> &r_cur, const T *__
     if (M::kOut2) stv<T, VEC>(s.out2 + x, o2);
 }
 
+template <typename T, int VEC, int MODE, bool nt_own>
+__device__ __forceinline__ void load_contig(ContigLoads<T, VEC> &l, const T *__restrict__ r_in, const AxisState<T> &s,
+                                            long long x, long long off_prev, long long off_next)
+{
+    using M = ModeTraits<MODE>;
+    l.r_before = r_in[x + off_prev];
+    l.r_after = r_in[x + off_next];
+    l.v1_after = s.in1[x + off_next];
+    l.v2_after = M::kIn2 ? s.in2[x + off_next] : (T)0;
+    l.v1_own = ldx<T, VEC, nt_own>(s.in1 + x);
+    if (M::kIn2) l.v2_own = ldx<T, VEC, nt_own>(s.in2 + x);
+}
+
 // Contiguous axis C: neighbours inside the pack come from registers; only the element before the
 // pack and the one after it are fetched.
-template <typename T, int VEC, int MODE, bool nt_own>
-__device__ __forceinline__ void axis_contig(const Pack<T, VEC> &r_cur, const T *__restrict__ r_in,
-                                            const AxisState<T> &s, long long x, long long off_prev,
-                                            long long off_next, bool self_next, T tk, T tkp, T cl, T lm,
-                                            Pack<T, VEC> &sum, double &bnorm)
+template <typename T, int VEC, int MODE>
+__device__ __forceinline__ void axis_contig(const Pack<T, VEC> &r_cur, const ContigLoads<T, VEC> &l, const AxisState<T> &s,
+                                            long long x, bool self_next, T tk, T tkp, T cl, T lm, Pack<T, VEC> &sum,
+                                            double &bnorm)
 {
     using P = Pack<T, VEC>;
     using M = ModeTraits<MODE>;
-    const T r_before = r_in[x + off_prev];
-    const T r_after = r_in[x + off_next];
-    const T v1_after = s.in1[x + off_next];
-    const T v2_after = M::kIn2 ? s.in2[x + off_next] : (T)0;
-    const P v1_own = ldx<T, VEC, nt_own>(s.in1 + x);
-    P v2_own;
-    if (M::kIn2) v2_own = ldx<T, VEC, nt_own>(s.in2 + x);
     P o1, o2, bn_own;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        const T rp = (j == 0) ? r_before : r_cur.v[j > 0 ? j - 1 : 0];
-        bn_own.v[j] = acc_new<T, MODE>(r_cur.v[j], rp, v1_own.v[j], M::kIn2 ? v2_own.v[j] : (T)0, tk, tkp, cl, o1.v[j],
+        const T rp = (j == 0) ? l.r_before : r_cur.v[j > 0 ? j - 1 : 0];
+        bn_own.v[j] = acc_new<T, MODE>(r_cur.v[j], rp, l.v1_own.v[j], M::kIn2 ? l.v2_own.v[j] : (T)0, tk, tkp, cl, o1.v[j],
                                        o2.v[j]);
         bnorm += fabs((double)bn_own.v[j]);
     }
     T u1, u2;
-    const T bn_after = acc_new<T, MODE>(r_after, self_next ? r_after : r_cur.v[VEC - 1], v1_after, v2_after, tk, tkp,
+    const T bn_after = acc_new<T, MODE>(l.r_after, self_next ? l.r_after : r_cur.v[VEC - 1], l.v1_after, l.v2_after, tk, tkp,
                                         cl, u1, u2);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -289,35 +316,60 @@ __global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
             const bool last = (m + 1 == m1);
             const bool at_end = (m + 1 == p.row_hi);
 
-            // (1) M-axis accumulator of the next row (look-ahead by one row)
-            P r_next = r_cur, bM_next;
+            // (0) every load of this row, issued before anything is used: the M look-ahead row, then A, B, C and orig
+            P r_next = r_cur, bM_next, mv1, mv2;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) bM_next.v[j] = (T)0;  // TVDN_EDGE_ZERO
-            if (!(at_end && p.hi_mode == TVDN_EDGE_ZERO)) {
-                const bool wrap = at_end && p.hi_mode == TVDN_EDGE_BC;
-                // TVDN_EDGE_WRAP (Jia-Zhao, last slab of several): the wrapped neighbour is global row 0, whose axis-0
-                // accumulator upstream forms as clip((r0 - r0) + b0) -- zero while row 0 is finite, NaN from the moment it
-                // is not (anisotropic.pyx:65-73).  p.wrap holds row 0's current recon; its state is that zero (the
-                // state loads below then land on the own row and are discarded).
-                const bool wrapz = at_end && p.hi_mode == TVDN_EDGE_WRAP;
-                const long long xn = row_slot<RING>(wrap ? p.row_lo : (wrapz ? m : m + 1), p.ring) * SM + xs;
+            const bool look = !(at_end && p.hi_mode == TVDN_EDGE_ZERO);
+            const bool wrap = at_end && p.hi_mode == TVDN_EDGE_BC;
+            // TVDN_EDGE_WRAP (Jia-Zhao, last slab of several): the wrapped neighbour is global row 0, whose axis-0
+            // accumulator upstream forms as clip((r0 - r0) + b0) -- zero while row 0 is finite, NaN from the moment it
+            // is not (anisotropic.pyx:65-73).  p.wrap holds row 0's current recon; its state is that zero (the
+            // state loads below then land on the own row and are discarded).
+            const bool wrapz = at_end && p.hi_mode == TVDN_EDGE_WRAP;
+            const long long xn = row_slot<RING>(wrap ? p.row_lo : (wrapz ? m : m + 1), p.ring) * SM + xs;
+            if (look) {
                 const T *rbase = wrapz ? p.wrap - (RING ? xn - xs : m * SM) : p.r_in;  // wave-uniform: p.wrap + xs == rbase + xn
                 r_next = ldv<T, VEC>(rbase + xn);
-                P v1 = ldv_nt<T, VEC>(sM.in1 + xn);
-                P v2, o1, o2;
-                if (MT::kIn2) v2 = ldv_nt<T, VEC>(sM.in2 + xn);
+                mv1 = ldv_nt<T, VEC>(sM.in1 + xn);
+                if (MT::kIn2) mv2 = ldv_nt<T, VEC>(sM.in2 + xn);
+            }
+            // ... where the registers allow it: the 4-D FISTA forms hold 18 packs of loads per row and would need 144-163
+            // VGPRs that way (3 waves per SIMD instead of 4, and +0.9 % time on config 2); they keep requesting axis by axis.
+            // The 4-D unaccelerated and the 3-D FISTA forms gain (variants alternating on one allocation,
+            // profiles/r03_ab_inproc_loadfirst.jsonl, r03_ab_inproc_early_vs_head.jsonl): 3-D 128x128x512 -7...9.5 %,
+            // 4-D unaccelerated f32 -2.9...4.1 %, f64 (config 3) -0.8...1.5 %, 3-D 512^3 -1.6...1.9 %.
+            // (3-D unaccelerated, the lightest form, is the one exception the other way: +1.4 % with early loads.)
+            constexpr bool EARLY = HAS_A != MT::kIn2;   // 4-D unaccelerated and 3-D FISTA forms
+            PackLoads<T, VEC> lA, lB;
+            ContigLoads<T, VEC> lC;
+            P og;
+            auto loadA = [&]() { load_pack<T, VEC, MODE, (kNtMask & 4) != 0, (kNtMask & 16) != 0>(lA, p.r_in, p.ax[iA], x, offA_prev, offA_next); };
+            auto loadB = [&]() { load_pack<T, VEC, MODE, (kNtMask & 1) != 0, (kNtMask & 8) != 0>(lB, p.r_in, p.ax[iB], x, offB_prev, offB_next); };
+            auto loadC = [&]() { load_contig<T, VEC, MODE, (kNtMask & 2) != 0>(lC, p.r_in, p.ax[iC], x, offC_prev, offC_next); };
+            auto loadO = [&]() { og = ldv_nt<T, VEC>(p.orig + (RING ? row_slot<RING>(m, p.ring_orig) * SM + xs : x)); };
+            if (EARLY) {
+                if (HAS_A) loadA();
+                loadB();
+                loadC();
+                loadO();
+            }
+
+            // (1) M-axis accumulator of the next row (look-ahead by one row)
+            if (look) {
+                P o1, o2;
                 if (wrapz) {
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
-                        v1.v[j] = (T)0;
-                        if (MT::kIn2) v2.v[j] = (T)0;
+                        mv1.v[j] = (T)0;
+                        if (MT::kIn2) mv2.v[j] = (T)0;
                     }
                 }
                 const bool self = (wrap && bc2) || wrapz;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j)
-                    bM_next.v[j] = acc_new<T, MODE>(r_next.v[j], self ? r_next.v[j] : r_cur.v[j], v1.v[j],
-                                                    MT::kIn2 ? v2.v[j] : (T)0, tk, tkp, clM, o1.v[j], o2.v[j]);
+                    bM_next.v[j] = acc_new<T, MODE>(r_next.v[j], self ? r_next.v[j] : r_cur.v[j], mv1.v[j],
+                                                    MT::kIn2 ? mv2.v[j] : (T)0, tk, tkp, clM, o1.v[j], o2.v[j]);
                 // rows inside the chunk are owned here, and so is a halo row sitting at row_hi
                 if (!last || (at_end && p.hi_mode == TVDN_EDGE_HALO)) {
                     if (MT::kOut1) stv<T, VEC>(sM.out1 + xn, o1);
@@ -333,16 +385,17 @@ __global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
             P sum;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) sum.v[j] = lmM * (bM_cur.v[j] - bM_next.v[j]);
-            if (HAS_A)
-                axis_pack<T, VEC, MODE, (kNtMask & 4) != 0, (kNtMask & 16) != 0>(r_cur, p.r_in, p.ax[iA], x, offA_prev, offA_next,
-                                                                                 selfA, tk, tkp, p.clip[iA], p.lm[iA], sum, acc[0]);
-            axis_pack<T, VEC, MODE, (kNtMask & 1) != 0, (kNtMask & 8) != 0>(r_cur, p.r_in, p.ax[iB], x, offB_prev, offB_next, selfB,
-                                                                            tk, tkp, clB, lmB, sum, acc[0]);
-            axis_contig<T, VEC, MODE, (kNtMask & 2) != 0>(r_cur, p.r_in, p.ax[iC], x, offC_prev, offC_next, selfC, tk, tkp, clC,
-                                                          lmC, sum, acc[0]);
+            if (HAS_A) {
+                if (!EARLY) loadA();
+                axis_pack<T, VEC, MODE>(r_cur, lA, p.ax[iA], x, selfA, tk, tkp, p.clip[iA], p.lm[iA], sum, acc[0]);
+            }
+            if (!EARLY) loadB();
+            axis_pack<T, VEC, MODE>(r_cur, lB, p.ax[iB], x, selfB, tk, tkp, clB, lmB, sum, acc[0]);
+            if (!EARLY) loadC();
+            axis_contig<T, VEC, MODE>(r_cur, lC, p.ax[iC], x, selfC, tk, tkp, clC, lmC, sum, acc[0]);
 
             // (3) reconstruction update at row m (utils.pyx:90-104)
-            const P og = ldv_nt<T, VEC>(p.orig + (RING ? row_slot<RING>(m, p.ring_orig) * SM + xs : x));
+            if (!EARLY) loadO();
             P r_new;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
