@@ -121,11 +121,67 @@ __device__ __forceinline__ T acc_new(T r_x, T r_prev, T v1, T v2, T tk, T tk_pre
 #endif
 constexpr int kNtMask = TVDN_NTMASK;
 
-template <typename T, int VEC, bool NT>
-__device__ __forceinline__ Pack<T, VEC> ldx(const T *p)
+// ---- row-based addressing -----------------------------------------------------------------------------------------
+// Every access of the sweep is (start of a row-plane of one array: wave-uniform) + (position inside the plane: per
+// lane, constant along the march, < 4 GiB).  Expressed as a raw buffer access -- resource = the row's base address in
+// four SGPRs, offset = ONE 32-bit VGPR per neighbour shared by all fifteen arrays -- instead of a 64-bit address per
+// load, the address arithmetic leaves the vector registers: that is what lets a whole row of loads be in flight
+// at 4 waves per SIMD (below).  num_records is the full 32-bit range: the offsets are in range by construction.
+typedef int tvdn_i4 __attribute__((ext_vector_type(4)));
+typedef int tvdn_i2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const void *row_base)
 {
-    if (NT) return ldv_nt<T, VEC>(p);
-    return ldv<T, VEC>(p);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(row_base), 0, -1, 0x00020000);
+}
+
+template <typename T, int VEC, bool NT>
+__device__ __forceinline__ Pack<T, VEC> ldb(const T *row_base, unsigned e)
+{
+    constexpr int BYTES = (int)sizeof(T) * VEC;
+    constexpr int AUX = NT ? 2 : 0;  // bit 1 = nt
+    const __amdgpu_buffer_rsrc_t rs = row_rsrc(row_base);
+    const unsigned off = e * (unsigned)sizeof(T);
+    Pack<T, VEC> x;
+    if (BYTES == 16) {
+        const tvdn_i4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, AUX);
+        __builtin_memcpy(&x, &v, 16);
+    } else if (BYTES == 8) {
+        const tvdn_i2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, AUX);
+        __builtin_memcpy(&x, &v, 8);
+    } else {
+        const int v = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, AUX);
+        __builtin_memcpy(&x, &v, 4);
+    }
+    return x;
+}
+
+template <typename T>
+__device__ __forceinline__ T ldb1(const T *row_base, unsigned e)
+{
+    return ldb<T, 1, false>(row_base, e).v[0];
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ void stb(T *row_base, unsigned e, const Pack<T, VEC> &x)
+{
+    constexpr int BYTES = (int)sizeof(T) * VEC;
+    constexpr int AUX = kNtStores ? 2 : 0;
+    const __amdgpu_buffer_rsrc_t rs = row_rsrc(row_base);
+    const unsigned off = e * (unsigned)sizeof(T);
+    if (BYTES == 16) {
+        tvdn_i4 v;
+        __builtin_memcpy(&v, &x, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, AUX);
+    } else if (BYTES == 8) {
+        tvdn_i2 v;
+        __builtin_memcpy(&v, &x, 8);
+        __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, AUX);
+    } else {
+        int v;
+        __builtin_memcpy(&v, &x, 4);
+        __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, AUX);
+    }
 }
 
 // Loads and arithmetic of an axis are separate steps: a row's loads -- M look-ahead, A, B, C and orig, 18 packs + 4 scalars
@@ -144,17 +200,17 @@ struct ContigLoads {  // axis C
 };
 
 template <typename T, int VEC, int MODE, bool nt_own, bool nt_next>
-__device__ __forceinline__ void load_pack(PackLoads<T, VEC> &l, const T *__restrict__ r_in, const AxisState<T> &s, long long x,
-                                          long long off_prev, long long off_next)
+__device__ __forceinline__ void load_pack(PackLoads<T, VEC> &l, const T *r_row, const AxisState<T> &s, long long row,
+                                          unsigned e0, unsigned e_prev, unsigned e_next)
 {
     using M = ModeTraits<MODE>;
-    l.rp = ldv<T, VEC>(r_in + x + off_prev);
-    l.rn = ldv<T, VEC>(r_in + x + off_next);
-    l.v1_own = ldx<T, VEC, nt_own>(s.in1 + x);
-    l.v1_nx = ldx<T, VEC, nt_next>(s.in1 + x + off_next);
+    l.rp = ldb<T, VEC, false>(r_row, e_prev);
+    l.rn = ldb<T, VEC, false>(r_row, e_next);
+    l.v1_own = ldb<T, VEC, nt_own>(s.in1 + row, e0);
+    l.v1_nx = ldb<T, VEC, nt_next>(s.in1 + row, e_next);
     if (M::kIn2) {
-        l.v2_own = ldx<T, VEC, nt_own>(s.in2 + x);
-        l.v2_nx = ldx<T, VEC, nt_next>(s.in2 + x + off_next);
+        l.v2_own = ldb<T, VEC, nt_own>(s.in2 + row, e0);
+        l.v2_nx = ldb<T, VEC, nt_next>(s.in2 + row, e_next);
     }
 }
 
@@ -162,8 +218,8 @@ __device__ __forceinline__ void load_pack(PackLoads<T, VEC> &l, const T *__restr
 // +1 neighbour, add lm * (b_new(x) - b_new(x+e)) to `sum` (left-to-right as utils.c:5641).
 template <typename T, int VEC, int MODE>
 __device__ __forceinline__ void axis_pack(const Pack<T, VEC> &r_cur, const PackLoads<T, VEC> &l, const AxisState<T> &s,
-                                          long long x, bool self_next, T tk, T tkp, T cl, T lm, Pack<T, VEC> &sum,
-                                          double &bnorm)
+                                          long long row, unsigned e0, bool self_next, T tk, T tkp, T cl, T lm,
+                                          Pack<T, VEC> &sum, double &bnorm)
 {
     using P = Pack<T, VEC>;
     using M = ModeTraits<MODE>;
@@ -178,29 +234,29 @@ __device__ __forceinline__ void axis_pack(const Pack<T, VEC> &r_cur, const PackL
         sum.v[j] = sum.v[j] + lm * (bn_own - bn_next);
         bnorm += fabs((double)bn_own);
     }
-    if (M::kOut1) stv<T, VEC>(s.out1 + x, o1);
-    if (M::kOut2) stv<T, VEC>(s.out2 + x, o2);
+    if (M::kOut1) stb<T, VEC>(s.out1 + row, e0, o1);
+    if (M::kOut2) stb<T, VEC>(s.out2 + row, e0, o2);
 }
 
 template <typename T, int VEC, int MODE, bool nt_own>
-__device__ __forceinline__ void load_contig(ContigLoads<T, VEC> &l, const T *__restrict__ r_in, const AxisState<T> &s,
-                                            long long x, long long off_prev, long long off_next)
+__device__ __forceinline__ void load_contig(ContigLoads<T, VEC> &l, const T *r_row, const AxisState<T> &s, long long row,
+                                            unsigned e0, unsigned e_prev, unsigned e_next)
 {
     using M = ModeTraits<MODE>;
-    l.r_before = r_in[x + off_prev];
-    l.r_after = r_in[x + off_next];
-    l.v1_after = s.in1[x + off_next];
-    l.v2_after = M::kIn2 ? s.in2[x + off_next] : (T)0;
-    l.v1_own = ldx<T, VEC, nt_own>(s.in1 + x);
-    if (M::kIn2) l.v2_own = ldx<T, VEC, nt_own>(s.in2 + x);
+    l.r_before = ldb1<T>(r_row, e_prev);
+    l.r_after = ldb1<T>(r_row, e_next);
+    l.v1_after = ldb1<T>(s.in1 + row, e_next);
+    l.v2_after = M::kIn2 ? ldb1<T>(s.in2 + row, e_next) : (T)0;
+    l.v1_own = ldb<T, VEC, nt_own>(s.in1 + row, e0);
+    if (M::kIn2) l.v2_own = ldb<T, VEC, nt_own>(s.in2 + row, e0);
 }
 
 // Contiguous axis C: neighbours inside the pack come from registers; only the element before the
 // pack and the one after it are fetched.
 template <typename T, int VEC, int MODE>
 __device__ __forceinline__ void axis_contig(const Pack<T, VEC> &r_cur, const ContigLoads<T, VEC> &l, const AxisState<T> &s,
-                                            long long x, bool self_next, T tk, T tkp, T cl, T lm, Pack<T, VEC> &sum,
-                                            double &bnorm)
+                                            long long row, unsigned e0, bool self_next, T tk, T tkp, T cl, T lm,
+                                            Pack<T, VEC> &sum, double &bnorm)
 {
     using P = Pack<T, VEC>;
     using M = ModeTraits<MODE>;
@@ -220,8 +276,8 @@ __device__ __forceinline__ void axis_contig(const Pack<T, VEC> &r_cur, const Con
         const T bn_next = (j + 1 < VEC) ? bn_own.v[j + 1 < VEC ? j + 1 : 0] : bn_after;
         sum.v[j] = sum.v[j] + lm * (bn_own.v[j] - bn_next);
     }
-    if (M::kOut1) stv<T, VEC>(s.out1 + x, o1);
-    if (M::kOut2) stv<T, VEC>(s.out2 + x, o2);
+    if (M::kOut1) stb<T, VEC>(s.out1 + row, e0, o1);
+    if (M::kOut2) stb<T, VEC>(s.out2 + row, e0, o2);
 }
 
 // RING: the arrays are rings of row-planes (tvdn.h, ring_rows): the only change is where a row starts.  Row numbers
@@ -280,6 +336,11 @@ __global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
         const long long offC_next = wrapC ? -(p.C - VEC) : VEC;
         // a wrapped neighbour sits at index 0, where under Jia-Zhao its own "prev" is itself
         const bool selfA = wrapA && bc2, selfB = wrapB && bc2, selfC = wrapC && bc2;
+        // positions inside a row-plane, in elements: 32-bit, constant along the march, shared by every array
+        const unsigned e0 = (unsigned)xs;
+        const unsigned eA_prev = (unsigned)(xs + offA_prev), eA_next = (unsigned)(xs + offA_next);
+        const unsigned eB_prev = (unsigned)(xs + offB_prev), eB_next = (unsigned)(xs + offB_next);
+        const unsigned eC_prev = (unsigned)(xs + offC_prev), eC_next = (unsigned)(xs + offC_next);
 
         const T tk = p.tk, tkp = p.tk_prev;
         const T clM = p.clip[iM], clB = p.clip[iB], clC = p.clip[iC];
@@ -287,7 +348,7 @@ __global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
         const AxisState<T> sM = p.ax[iM];
 
         // ---- prologue: M-axis accumulator of row m0 -----------------------------------------------
-        P r_cur = ldv<T, VEC>(p.r_in + row_slot<RING>(m0, p.ring) * SM + xs);
+        P r_cur = ldb<T, VEC, false>(p.r_in + row_slot<RING>(m0, p.ring) * SM, e0);
         P bM_cur;
         {
             long long mp;  // the row that precedes m0
@@ -295,24 +356,25 @@ __global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
                 mp = m0 - 1;
             else
                 mp = bc2 ? m0 : p.row_hi - 1;  // TVDN_EDGE_BC: Jia-Zhao -> itself, periodic -> last row
-            const long long x0 = row_slot<RING>(m0, p.ring) * SM + xs;
-            const P r_prev = ldv<T, VEC>(p.r_in + row_slot<RING>(mp, p.ring) * SM + xs);
-            const P v1 = ldv_nt<T, VEC>(sM.in1 + x0);
+            const long long row0 = row_slot<RING>(m0, p.ring) * SM;
+            const P r_prev = ldb<T, VEC, false>(p.r_in + row_slot<RING>(mp, p.ring) * SM, e0);
+            const P v1 = ldb<T, VEC, kNtLoads>(sM.in1 + row0, e0);
             P v2, o1, o2;
-            if (MT::kIn2) v2 = ldv_nt<T, VEC>(sM.in2 + x0);
+            if (MT::kIn2) v2 = ldb<T, VEC, kNtLoads>(sM.in2 + row0, e0);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 bM_cur.v[j] = acc_new<T, MODE>(r_cur.v[j], r_prev.v[j], v1.v[j], MT::kIn2 ? v2.v[j] : (T)0, tk, tkp, clM,
                                                o1.v[j], o2.v[j]);
                 acc[0] += fabs((double)bM_cur.v[j]);
             }
-            if (MT::kOut1) stv<T, VEC>(sM.out1 + x0, o1);
-            if (MT::kOut2) stv<T, VEC>(sM.out2 + x0, o2);
+            if (MT::kOut1) stb<T, VEC>(sM.out1 + row0, e0, o1);
+            if (MT::kOut2) stb<T, VEC>(sM.out2 + row0, e0, o2);
         }
 
         // ---- march -------------------------------------------------------------------------------
         for (long long m = m0; m < m1; ++m) {
-            const long long x = row_slot<RING>(m, p.ring) * SM + xs;
+            const long long row = row_slot<RING>(m, p.ring) * SM;   // wave-uniform start of this row in every array
+            const T *r_row = p.r_in + row;
             const bool last = (m + 1 == m1);
             const bool at_end = (m + 1 == p.row_hi);
 
@@ -327,27 +389,25 @@ __global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
             // is not (anisotropic.pyx:65-73).  p.wrap holds row 0's current recon; its state is that zero (the
             // state loads below then land on the own row and are discarded).
             const bool wrapz = at_end && p.hi_mode == TVDN_EDGE_WRAP;
-            const long long xn = row_slot<RING>(wrap ? p.row_lo : (wrapz ? m : m + 1), p.ring) * SM + xs;
+            const long long rown = row_slot<RING>(wrap ? p.row_lo : (wrapz ? m : m + 1), p.ring) * SM;
             if (look) {
-                const T *rbase = wrapz ? p.wrap - (RING ? xn - xs : m * SM) : p.r_in;  // wave-uniform: p.wrap + xs == rbase + xn
-                r_next = ldv<T, VEC>(rbase + xn);
-                mv1 = ldv_nt<T, VEC>(sM.in1 + xn);
-                if (MT::kIn2) mv2 = ldv_nt<T, VEC>(sM.in2 + xn);
+                r_next = ldb<T, VEC, false>(wrapz ? p.wrap : p.r_in + rown, e0);
+                mv1 = ldb<T, VEC, kNtLoads>(sM.in1 + rown, e0);
+                if (MT::kIn2) mv2 = ldb<T, VEC, kNtLoads>(sM.in2 + rown, e0);
             }
-            // ... where the registers allow it: the 4-D FISTA forms hold 18 packs of loads per row and would need 144-163
-            // VGPRs that way (3 waves per SIMD instead of 4, and +0.9 % time on config 2); they keep requesting axis by axis.
-            // The 4-D unaccelerated and the 3-D FISTA forms gain (variants alternating on one allocation,
-            // profiles/r03_ab_inproc_loadfirst.jsonl, r03_ab_inproc_early_vs_head.jsonl): 3-D 128x128x512 -7...9.5 %,
-            // 4-D unaccelerated f32 -2.9...4.1 %, f64 (config 3) -0.8...1.5 %, 3-D 512^3 -1.6...1.9 %.
-            // (3-D unaccelerated, the lightest form, is the one exception the other way: +1.4 % with early loads.)
-            constexpr bool EARLY = HAS_A != MT::kIn2;   // 4-D unaccelerated and 3-D FISTA forms
+            // With 64-bit addresses per load this needed 144-163 VGPRs in the 4-D FISTA forms (3 waves per SIMD); with the
+            // row-based buffer addressing above it is 112 (f32) / 113 (f64) there and 68-87 elsewhere.  Against the
+            // axis-by-axis build of the same day, variants alternating on ONE allocation (profiles/r03_ab_inproc_buffer_
+            // addressing.jsonl): 4-D unaccelerated f32 -4.3 %, 3-D 128x128x512 -6.8 %, 3-D 512^3 -2.6 %, config-4 slab
+            // -1.3 %, config 2 and config 3 -0.6 %, 4-D FISTA f64 +0.4 %, 3-D unaccelerated +-0.
+            constexpr bool EARLY = true;
             PackLoads<T, VEC> lA, lB;
             ContigLoads<T, VEC> lC;
             P og;
-            auto loadA = [&]() { load_pack<T, VEC, MODE, (kNtMask & 4) != 0, (kNtMask & 16) != 0>(lA, p.r_in, p.ax[iA], x, offA_prev, offA_next); };
-            auto loadB = [&]() { load_pack<T, VEC, MODE, (kNtMask & 1) != 0, (kNtMask & 8) != 0>(lB, p.r_in, p.ax[iB], x, offB_prev, offB_next); };
-            auto loadC = [&]() { load_contig<T, VEC, MODE, (kNtMask & 2) != 0>(lC, p.r_in, p.ax[iC], x, offC_prev, offC_next); };
-            auto loadO = [&]() { og = ldv_nt<T, VEC>(p.orig + (RING ? row_slot<RING>(m, p.ring_orig) * SM + xs : x)); };
+            auto loadA = [&]() { load_pack<T, VEC, MODE, (kNtMask & 4) != 0, (kNtMask & 16) != 0>(lA, r_row, p.ax[iA], row, e0, eA_prev, eA_next); };
+            auto loadB = [&]() { load_pack<T, VEC, MODE, (kNtMask & 1) != 0, (kNtMask & 8) != 0>(lB, r_row, p.ax[iB], row, e0, eB_prev, eB_next); };
+            auto loadC = [&]() { load_contig<T, VEC, MODE, (kNtMask & 2) != 0>(lC, r_row, p.ax[iC], row, e0, eC_prev, eC_next); };
+            auto loadO = [&]() { og = ldb<T, VEC, kNtLoads>(p.orig + (RING ? row_slot<RING>(m, p.ring_orig) * SM : row), e0); };
             if (EARLY) {
                 if (HAS_A) loadA();
                 loadB();
@@ -372,8 +432,8 @@ __global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
                                                     MT::kIn2 ? mv2.v[j] : (T)0, tk, tkp, clM, o1.v[j], o2.v[j]);
                 // rows inside the chunk are owned here, and so is a halo row sitting at row_hi
                 if (!last || (at_end && p.hi_mode == TVDN_EDGE_HALO)) {
-                    if (MT::kOut1) stv<T, VEC>(sM.out1 + xn, o1);
-                    if (MT::kOut2) stv<T, VEC>(sM.out2 + xn, o2);
+                    if (MT::kOut1) stb<T, VEC>(sM.out1 + rown, e0, o1);
+                    if (MT::kOut2) stb<T, VEC>(sM.out2 + rown, e0, o2);
                 }
                 if (!last) {
 #pragma unroll
@@ -387,12 +447,12 @@ __global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
             for (int j = 0; j < VEC; ++j) sum.v[j] = lmM * (bM_cur.v[j] - bM_next.v[j]);
             if (HAS_A) {
                 if (!EARLY) loadA();
-                axis_pack<T, VEC, MODE>(r_cur, lA, p.ax[iA], x, selfA, tk, tkp, p.clip[iA], p.lm[iA], sum, acc[0]);
+                axis_pack<T, VEC, MODE>(r_cur, lA, p.ax[iA], row, e0, selfA, tk, tkp, p.clip[iA], p.lm[iA], sum, acc[0]);
             }
             if (!EARLY) loadB();
-            axis_pack<T, VEC, MODE>(r_cur, lB, p.ax[iB], x, selfB, tk, tkp, clB, lmB, sum, acc[0]);
+            axis_pack<T, VEC, MODE>(r_cur, lB, p.ax[iB], row, e0, selfB, tk, tkp, clB, lmB, sum, acc[0]);
             if (!EARLY) loadC();
-            axis_contig<T, VEC, MODE>(r_cur, lC, p.ax[iC], x, selfC, tk, tkp, clC, lmC, sum, acc[0]);
+            axis_contig<T, VEC, MODE>(r_cur, lC, p.ax[iC], row, e0, selfC, tk, tkp, clC, lmC, sum, acc[0]);
 
             // (3) reconstruction update at row m (utils.pyx:90-104)
             if (!EARLY) loadO();
@@ -404,7 +464,7 @@ __global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
                 acc[1] += fabs((double)df);
                 acc[2] += fabs((double)r_cur.v[j]);
             }
-            stv<T, VEC>(p.r_out + x, r_new);
+            stb<T, VEC>(p.r_out + row, e0, r_new);
 
             r_cur = r_next;
             bM_cur = bM_next;
@@ -488,6 +548,9 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
     p.partials = ctx->partials;
 
     const int vec = (al && (p.C % VMAX == 0)) ? VMAX : 1;
+    TVDN_REQUIRE((unsigned long long)(p.A * p.B * p.C) * sizeof(T) < (1ull << 32),
+                 "a row-plane (shape[1:]) of %lld elements is 4 GiB or more: positions inside a plane are 32-bit byte offsets",
+                 (long long)(p.A * p.B * p.C));
     p.units = p.A * p.B * (p.C / vec);
     const long long rows = p.sweep_hi - p.sweep_lo;
     // tuning knobs (measurement only): TVDN_CHUNK = rows per march, TVDN_XCD = 0 / 1 forces the XCD remap off / on,
