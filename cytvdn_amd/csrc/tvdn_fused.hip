@@ -400,20 +400,13 @@ __global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
             // axis-by-axis build of the same day, variants alternating on ONE allocation (profiles/r03_ab_inproc_buffer_
             // addressing.jsonl): 4-D unaccelerated f32 -4.3 %, 3-D 128x128x512 -6.8 %, 3-D 512^3 -2.6 %, config-4 slab
             // -1.3 %, config 2 and config 3 -0.6 %, 4-D FISTA f64 +0.4 %, 3-D unaccelerated +-0.
-            constexpr bool EARLY = true;
             PackLoads<T, VEC> lA, lB;
             ContigLoads<T, VEC> lC;
-            P og;
-            auto loadA = [&]() { load_pack<T, VEC, MODE, (kNtMask & 4) != 0, (kNtMask & 16) != 0>(lA, r_row, p.ax[iA], row, e0, eA_prev, eA_next); };
-            auto loadB = [&]() { load_pack<T, VEC, MODE, (kNtMask & 1) != 0, (kNtMask & 8) != 0>(lB, r_row, p.ax[iB], row, e0, eB_prev, eB_next); };
-            auto loadC = [&]() { load_contig<T, VEC, MODE, (kNtMask & 2) != 0>(lC, r_row, p.ax[iC], row, e0, eC_prev, eC_next); };
-            auto loadO = [&]() { og = ldb<T, VEC, kNtLoads>(p.orig + (RING ? row_slot<RING>(m, p.ring_orig) * SM : row), e0); };
-            if (EARLY) {
-                if (HAS_A) loadA();
-                loadB();
-                loadC();
-                loadO();
-            }
+            if (HAS_A)
+                load_pack<T, VEC, MODE, (kNtMask & 4) != 0, (kNtMask & 16) != 0>(lA, r_row, p.ax[iA], row, e0, eA_prev, eA_next);
+            load_pack<T, VEC, MODE, (kNtMask & 1) != 0, (kNtMask & 8) != 0>(lB, r_row, p.ax[iB], row, e0, eB_prev, eB_next);
+            load_contig<T, VEC, MODE, (kNtMask & 2) != 0>(lC, r_row, p.ax[iC], row, e0, eC_prev, eC_next);
+            const P og = ldb<T, VEC, kNtLoads>(p.orig + (RING ? row_slot<RING>(m, p.ring_orig) * SM : row), e0);
 
             // (1) M-axis accumulator of the next row (look-ahead by one row)
             if (look) {
@@ -445,17 +438,12 @@ __global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
             P sum;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) sum.v[j] = lmM * (bM_cur.v[j] - bM_next.v[j]);
-            if (HAS_A) {
-                if (!EARLY) loadA();
+            if (HAS_A)
                 axis_pack<T, VEC, MODE>(r_cur, lA, p.ax[iA], row, e0, selfA, tk, tkp, p.clip[iA], p.lm[iA], sum, acc[0]);
-            }
-            if (!EARLY) loadB();
             axis_pack<T, VEC, MODE>(r_cur, lB, p.ax[iB], row, e0, selfB, tk, tkp, clB, lmB, sum, acc[0]);
-            if (!EARLY) loadC();
             axis_contig<T, VEC, MODE>(r_cur, lC, p.ax[iC], row, e0, selfC, tk, tkp, clC, lmC, sum, acc[0]);
 
             // (3) reconstruction update at row m (utils.pyx:90-104)
-            if (!EARLY) loadO();
             P r_new;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
