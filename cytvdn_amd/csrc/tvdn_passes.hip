@@ -245,44 +245,49 @@ __global__ void __launch_bounds__(kBlock) recon_update_kernel(ReconParams<T> p)
                 for (int t = 0; t < TA; ++t) bA[t] = ldv<T, VEC>(p.b[iA] + x0 + t * SA);
                 bA[TA] = ldv<T, VEC>(p.b[iA] + x0 + (TA - 1) * SA + offA);
             }
+            // every load of the row before the first use (a wave then has the whole row's requests in flight instead of one
+            // axis at a time: the compiler keeps source order across the arithmetic, csrc/tvdn_fused.hip has the same)
+            P bM_next[TA], bBo[TA], bBn[TA], bCo[TA], og[TA], old[TA];
+            T bCafter[TA];
 #pragma unroll
             for (int t = 0; t < TA; ++t) {
                 const long long x = x0 + t * SA;
-                const P bM_next = ldv_m<T, VEC>(bM + xn0 + t * SA);
+                bM_next[t] = ldv_m<T, VEC>(bM + xn0 + t * SA);
+                bBo[t] = ldv<T, VEC>(bB + x);
+                bBn[t] = ldv<T, VEC>(bB + x + offB);
+                bCo[t] = ldv<T, VEC>(bC + x);
+                bCafter[t] = bC[x + offC];
+                og[t] = ldv_nt<T, VEC>(p.orig + x);
+                old[t] = ldv_nt<T, VEC>(p.recon + x);
+            }
+#pragma unroll
+            for (int t = 0; t < TA; ++t) {
+                const long long x = x0 + t * SA;
                 P s;
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) s.v[j] = lmM * (bM_cur[t].v[j] - bM_next.v[j]);
+                for (int j = 0; j < VEC; ++j) s.v[j] = lmM * (bM_cur[t].v[j] - bM_next[t].v[j]);
                 if (HAS_A) {
                     const T lmA = p.lm[iA];
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) s.v[j] = s.v[j] + lmA * (bA[t].v[j] - bA[t + 1].v[j]);
                 }
-                {
-                    const P o = ldv<T, VEC>(bB + x), n = ldv<T, VEC>(bB + x + offB);
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) s.v[j] = s.v[j] + lmB * (o.v[j] - n.v[j]);
-                }
-                {
-                    const P o = ldv<T, VEC>(bC + x);
-                    const T after = bC[x + offC];
+                for (int j = 0; j < VEC; ++j) s.v[j] = s.v[j] + lmB * (bBo[t].v[j] - bBn[t].v[j]);
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) {
-                        const T nx = (j + 1 < VEC) ? o.v[j + 1 < VEC ? j + 1 : 0] : after;
-                        s.v[j] = s.v[j] + lmC * (o.v[j] - nx);
-                    }
+                for (int j = 0; j < VEC; ++j) {
+                    const T nx = (j + 1 < VEC) ? bCo[t].v[j + 1 < VEC ? j + 1 : 0] : bCafter[t];
+                    s.v[j] = s.v[j] + lmC * (bCo[t].v[j] - nx);
                 }
-                const P og = ldv_nt<T, VEC>(p.orig + x);
-                const P old = ldv_nt<T, VEC>(p.recon + x);
                 P nw;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    nw.v[j] = og.v[j] - s.v[j];
-                    const T df = nw.v[j] - old.v[j];
+                    nw.v[j] = og[t].v[j] - s.v[j];
+                    const T df = nw.v[j] - old[t].v[j];
                     acc[0] += fabs((double)df);
-                    acc[1] += fabs((double)old.v[j]);
+                    acc[1] += fabs((double)old[t].v[j]);
                 }
                 stv<T, VEC>(p.recon + x, nw);
-                bM_cur[t] = bM_next;
+                bM_cur[t] = bM_next[t];
             }
         }
     }
