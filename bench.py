@@ -35,7 +35,7 @@ At N = 1 the line also carries
   placement     the sweep's speed depends on which physical pages the state's allocation got (same clocks, same virtual
                 address, 11.2 / 12.1 / 12.6 ms for config 2: profiles/r03_placement_audition_*.jsonl), so the engine tries
                 --audition N placements (default 4, as many as fit the HBM) and keeps the fastest -- as denoise3D/4D do
-                for runs of >= 100 iterations; config.placement_audition_ms lists the candidates' probe times (kept one
+                for runs of >= 400 iterations; config.placement_audition_ms lists the candidates' probe times (kept one
                 first), so the spread of the box is in the line.  Untimed set-up, like the allocation itself.
 Every roofline object carries the per-step sweep-kernel time as mean, minimum, median and maximum (HIP events per launch).
 """

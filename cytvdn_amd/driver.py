@@ -61,14 +61,15 @@ def _split_iterations(iterations, FISTA):
 
 
 def _audition_candidates(n_total: int) -> int:
-    """How many placements of the state `HipBackend.best_of` may try before an in-core run: a candidate costs about
-    three sweeps and the spread between placements is ~10 % of a sweep (engine.HipBackend.best_of), so three
-    candidates pay for themselves from ~100 iterations on (four from 200); shorter runs take the first allocation.
-    TVDN_AUDITION=n overrides (1 = never)."""
+    """How many placements of the state `HipBackend.best_of` may try before an in-core run.  A further candidate costs
+    about five sweeps' time (allocate, zero, three probe sweeps, free) and the expected gain of the best of three or four
+    over a single draw is 3.5-4 % of a sweep (engine.HipBackend.best_of; profiles/r03_placement_audition_*.jsonl), so
+    two extra candidates pay for themselves from ~400 iterations on and three from ~800; shorter runs take the first
+    allocation.  TVDN_AUDITION=n overrides (1 = never)."""
     e = os.environ.get("TVDN_AUDITION")
     if e is not None:
         return max(1, int(e))
-    return 4 if n_total >= 200 else (3 if n_total >= 100 else 1)
+    return 4 if n_total >= 800 else (3 if n_total >= 400 else 1)
 
 
 def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, reference_data, BC_mode, quiet,
