@@ -4,7 +4,9 @@
 // copy stream per slab while the interior rows are swept.  One host thread drives every device; nothing here
 // needs Python, torch or RCCL.
 #include <cmath>
+#include <cstdlib>
 #include <memory>
+#include <vector>
 
 #include "tvdn_common.hpp"
 
@@ -41,6 +43,17 @@ struct Slab {
     tvdn_many_args roles;  // arrays and who plays which role (tvdn_common.hpp roles_bind / roles_advance); .base = the sweep's fixed arguments
     char *orig = nullptr;
     char *recon(int i) const { return (char *)roles.recon[i]; }
+    // carve one allocation into the arrays of the state: per axis 2-3 rotating arrays, recon[1], orig, recon[0]
+    void assign(char *base, size_t stride, int nd, int per_axis)
+    {
+        int k = 0;
+        for (int q = 0; q < nd; ++q)
+            for (int j = 0; j < per_axis; ++j) roles.S[q][j] = base + stride * (size_t)(k++);
+        roles.recon[1] = base + stride * (size_t)(k++);
+        orig = base + stride * (size_t)(k++);
+        roles.recon[0] = base + stride * (size_t)(k++);
+        roles.base.orig = orig;
+    }
     int64_t rows() const { return halo_lo + (g1 - g0) + halo_hi; }
     int64_t row_lo() const { return halo_lo; }
     int64_t row_hi() const { return halo_lo + (g1 - g0); }
@@ -117,15 +130,9 @@ static int run_impl(const tvdn_run_args *a)
         s.state.device = s.device;
         TVDN_HIP(hipMalloc(&s.state.p, stride * (size_t)n_arr));
         TVDN_HIP(hipMemsetAsync(s.state.p, 0, stride * (size_t)(n_arr - 2), s.main));
-        char *base = (char *)s.state.p;
-        int k = 0;
         std::memset(&s.roles, 0, sizeof s.roles);
         roles_reset(s.roles, fista);
-        for (int q = 0; q < nd; ++q)
-            for (int j = 0; j < per_axis; ++j) s.roles.S[q][j] = base + stride * (size_t)(k++);
-        s.roles.recon[1] = base + stride * (size_t)(k++);
-        s.orig = base + stride * (size_t)(k++);
-        s.roles.recon[0] = base + stride * (size_t)(k++);
+        s.assign((char *)s.state.p, stride, nd, per_axis);
         s.sums.device = s.device;
         TVDN_HIP(hipMalloc(&s.sums.p, sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1)));
         TVDN_HIP(hipMemsetAsync(s.sums.p, 0, sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1), s.main));
@@ -157,17 +164,6 @@ static int run_impl(const tvdn_run_args *a)
     };
     for (int r = 0; r < world; ++r) {
         Slab &s = sl[r];
-        int rc = rows_to_device(s, s.orig, a->data);
-        if (rc) return rc;
-        TVDN_HIP(hipMemcpyAsync(s.recon(0), s.orig, (size_t)s.rows() * row_bytes, hipMemcpyDeviceToDevice, s.main));
-        if (want_mse) {
-            s.ref.device = s.mse.device = s.device;
-            TVDN_HIP(hipMalloc(&s.ref.p, (size_t)s.rows() * row_bytes));
-            rc = rows_to_device(s, (char *)s.ref.p, a->reference);
-            if (rc) return rc;
-            TVDN_HIP(hipMalloc(&s.mse.p, sizeof(double) * (size_t)(n_total + 1)));
-            TVDN_HIP(hipMemsetAsync(s.mse.p, 0, sizeof(double) * (size_t)(n_total + 1), s.main));
-        }
         tvdn_iter_args &it = s.roles.base;
         it.dtype = a->dtype;
         it.ndim = nd;
@@ -184,6 +180,98 @@ static int run_impl(const tvdn_run_args *a)
             it.lambda_mu[q] = a->lambda_mu[q];
         }
         it.orig = s.orig;
+    }
+
+    // ---- placement audition (one device, long runs) -----------------------------------------------------------------
+    // The sweep's speed depends on which physical pages the state's allocation received (11.2 /
+    // 12.1 / 12.6 ms for the same 60 GiB at identical clocks).  Before a run long enough to pay for it, further
+    // candidates are allocated beside the first while they fit 80 % of the free HBM, each is timed for two sweeps on a
+    // zero-filled state (the sweep is branch-free), the fastest is kept.  cytvdn_amd/engine.py HipBackend.best_of is the
+    // same thing for the Python engines; TVDN_AUDITION=n overrides the count (1 = take the first allocation).
+    if (world == 1) {
+        Slab &s = sl[0];
+        const char *e = getenv("TVDN_AUDITION");
+        const int want = e ? atoi(e) : (n_total >= 800 ? 4 : (n_total >= 400 ? 3 : 1));
+        const size_t bytes = (size_t)s.rows() * row_bytes;
+        const size_t stride = (bytes + 255) / 256 * 256 + 4096;
+        const size_t total = stride * (size_t)(3 + nd * per_axis);
+        TVDN_HIP(hipSetDevice(s.device));
+        std::vector<std::unique_ptr<DevBuf>> held;  // candidates other than the one in s.state
+        void *best = s.state.p;
+        double best_ms = -1.0;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        auto probe = [&](void *base, double *ms) -> int {
+            s.assign((char *)base, stride, nd, per_axis);
+            roles_reset(s.roles, fista);
+            TVDN_HIP(hipMemsetAsync(base, 0, total, s.main));
+            for (int i = 0; i < 3; ++i) {
+                if (i == 1) TVDN_HIP(hipEventRecord(e0, s.main));
+                tvdn_iter_args &it = s.roles.base;
+                roles_bind(s.roles, fista, 0.5, it);
+                it.sweep_lo = it.sweep_hi = 0;
+                it.accumulate = 0;
+                const int rc = tvdn_iterate_fused(s.ctx, &it, (double *)s.sums.p, s.main);
+                if (rc) return rc;
+                roles_advance(s.roles, fista, 0.5);
+            }
+            TVDN_HIP(hipEventRecord(e1, s.main));
+            TVDN_HIP(hipEventSynchronize(e1));
+            float t = 0.f;
+            TVDN_HIP(hipEventElapsedTime(&t, e0, e1));
+            *ms = t;
+            return TVDN_OK;
+        };
+        if (want > 1 && n_total > 0) {
+            TVDN_HIP(hipEventCreate(&e0));
+            TVDN_HIP(hipEventCreate(&e1));
+            int rc = probe(s.state.p, &best_ms);
+            for (int c = 1; c < want && !rc; ++c) {
+                size_t free_b = 0, total_b = 0;
+                TVDN_HIP(hipMemGetInfo(&free_b, &total_b));
+                if ((double)total > 0.8 * (double)free_b) break;
+                std::unique_ptr<DevBuf> b(new DevBuf);
+                b->device = s.device;
+                if (hipMalloc(&b->p, total) != hipSuccess) {
+                    (void)hipGetLastError();
+                    break;
+                }
+                double ms = 0.0;
+                rc = probe(b->p, &ms);
+                if (!rc && ms < best_ms) {
+                    best_ms = ms;
+                    best = b->p;
+                }
+                held.push_back(std::move(b));
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            if (rc) return rc;
+            if (best != s.state.p)  // keep the winner in s.state (freed with the slab), the former first one among the losers
+                for (auto &b : held)
+                    if (b->p == best) std::swap(b->p, s.state.p);
+            held.clear();  // frees every loser
+            s.assign((char *)s.state.p, stride, nd, per_axis);
+            roles_reset(s.roles, fista);
+            // as after the constructor: everything zero but orig and recon[0] (the last two arrays), which the upload below
+            // fills on streams of its own -- a fill of those on s.main could land on top of the uploaded rows
+            TVDN_HIP(hipMemsetAsync(s.state.p, 0, stride * (size_t)(nd * per_axis + 1), s.main));
+            TVDN_HIP(hipMemsetAsync(s.sums.p, 0, sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1), s.main));
+        }
+    }
+
+    for (int r = 0; r < world; ++r) {
+        Slab &s = sl[r];
+        int rc = rows_to_device(s, s.orig, a->data);
+        if (rc) return rc;
+        TVDN_HIP(hipMemcpyAsync(s.recon(0), s.orig, (size_t)s.rows() * row_bytes, hipMemcpyDeviceToDevice, s.main));
+        if (want_mse) {
+            s.ref.device = s.mse.device = s.device;
+            TVDN_HIP(hipMalloc(&s.ref.p, (size_t)s.rows() * row_bytes));
+            rc = rows_to_device(s, (char *)s.ref.p, a->reference);
+            if (rc) return rc;
+            TVDN_HIP(hipMalloc(&s.mse.p, sizeof(double) * (size_t)(n_total + 1)));
+            TVDN_HIP(hipMemsetAsync(s.mse.p, 0, sizeof(double) * (size_t)(n_total + 1), s.main));
+        }
     }
     // sum of squared errors over the own rows of every slab, into mse[slot]
     auto sse_all = [&](int cur, int slot) -> int {

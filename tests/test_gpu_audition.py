@@ -43,3 +43,31 @@ def test_best_of_reports_its_candidates_and_frees_the_losers():
     assert free0 - free1 < 2 * be.state_bytes()                    # the two losers went back to the driver
     one = HipBackend.best_of(1, lay, np.float32, True, device=0, max_iters=4)
     assert one.audition == []
+
+
+@pytest.mark.parametrize("shape,dtype,n_f,n_p", [((9, 5, 8, 16), np.float32, 6, 0), ((11, 6, 16), np.float64, 3, 3), ((7, 3, 4, 8), np.float32, 0, 5)])
+def test_tvdn_run_auditions_too(oracle, monkeypatch, shape, dtype, n_f, n_p):
+    """The C entry point tries several placements of its state before long runs as well (csrc/tvdn_run.hip); forced here
+    on small cubes: same bits, same traces as the oracle, with and without."""
+    import ctypes as C
+    from cytvdn_amd import _lib, synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=23, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    lam = mu / dt.type(32.0 if nd == 4 else 16.0)
+    ref = oracle.denoise(x, mu, [n_f, n_p] if (n_f and n_p) else (n_f or n_p), bool(n_f))
+    for cand in ("1", "3"):
+        monkeypatch.setenv("TVDN_AUDITION", cand)
+        a = _lib.RunArgs(dtype=_lib.dtype_code(dt), ndim=nd, bc_mode=2, device=0, n_fista=n_f, n_plain=n_p)
+        for i, s_ in enumerate(shape):
+            a.shape[i] = s_
+        for q in range(nd):
+            a.clip[q] = float((1.0 / lam)[q])
+            a.lambda_mu[q] = float((lam / mu).astype(dt)[q])
+        recon, sums = np.empty_like(x), np.zeros((n_f + n_p, 3))
+        a.data, a.recon_out, a.sums_out = x.ctypes.data, recon.ctypes.data, sums.ctypes.data
+        _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+        assert bits_equal(recon, ref["recon"]), cand
+        np.testing.assert_allclose(sums[:, 0], ref["b_norm64"], rtol=1e-9)
+        np.testing.assert_allclose(sums[:, 1], ref["delta64"], rtol=1e-9)
