@@ -28,7 +28,7 @@ EXPORTS = (
     "tvdn_abi_version", "tvdn_last_error", "tvdn_device_count", "tvdn_ctx_create", "tvdn_ctx_destroy",
     "tvdn_ctx_timing_enable", "tvdn_ctx_timing_read", "tvdn_ctx_timing_read_each",
     "tvdn_accumulator_update", "tvdn_datacube_update", "tvdn_sum_square_error", "tvdn_iterate_fused",
-    "tvdn_synth_fill", "tvdn_run", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many", "tvdn_plan", "tvdn_copy_many", "tvdn_stream_mix",
+    "tvdn_synth_fill", "tvdn_run", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many", "tvdn_plan", "tvdn_copy_many", "tvdn_stream_mix", "tvdn_stream_mix_march",
     "tvdn_stream_host_need", "tvdn_fista_ratios", "tvdn_iter_mode", "tvdn_roles_bind", "tvdn_roles_advance",
 )
 
@@ -129,6 +129,8 @@ def lib():
     L.tvdn_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     L.tvdn_copy_many.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_void_p]
     L.tvdn_stream_mix.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.c_int64, C.c_void_p]
+    L.tvdn_stream_mix_march.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.c_int64, C.c_int64,
+                                        C.c_int32, C.c_void_p]
     L.tvdn_synth_fill.argtypes = [C.c_int, C.c_int, i64p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     L.tvdn_stream_host_need.argtypes = [C.POINTER(RunArgs), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.tvdn_fista_ratios.argtypes = [C.c_int32, C.POINTER(C.c_double)]

@@ -248,7 +248,55 @@ __global__ void __launch_bounds__(256) stream_mix_kernel(MixPtrs p, long long n1
         __builtin_nontemporal_store(o, reinterpret_cast<f4 *>(p.out[k]) + i);
     }
 }
+// The same stream in the SWEEP's traversal: a workgroup owns one 4 KiB tile of a row-plane and marches `chunk` rows along
+// axis 0 (stride = one plane), workgroup ids remapped per XCD like the sweep's -- the ceiling of that structure, apart
+// from neighbour re-reads and arithmetic.
+template <int NR, int NW>
+__global__ void __launch_bounds__(256) stream_mix_march_kernel(MixPtrs p, long long plane16, long long rows, long long tiles, int chunk)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const long long L = xcd_remap(blockIdx.x, gridDim.x);
+    const long long chunk_id = L / tiles, tile = L % tiles;
+    const long long u = tile * 256 + threadIdx.x;
+    if (u >= plane16) return;
+    const long long m0 = chunk_id * chunk, m1 = (m0 + chunk < rows) ? m0 + chunk : rows;
+    for (long long m = m0; m < m1; ++m) {
+        const long long i = m * plane16 + u;
+        f4 v[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p.in[k]) + i);
+        f4 s = v[0];
+#pragma unroll
+        for (int k = 1; k < NR; ++k) s += v[k];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            f4 o = s;
+            o.x += (float)k;
+            __builtin_nontemporal_store(o, reinterpret_cast<f4 *>(p.out[k]) + i);
+        }
+    }
+}
 }  // namespace tvdn
+
+extern "C" int tvdn_stream_mix_march(int32_t n_read, const void *const *in, int32_t n_write, void *const *out, int64_t bytes_each,
+                                     int64_t rows, int32_t chunk, void *stream)
+{
+    TVDN_REQUIRE(in && out && bytes_each > 0 && rows >= 1 && chunk >= 1 && bytes_each % (16 * rows) == 0, "bad argument");
+    TVDN_REQUIRE(n_read == 10 && n_write == 5 || n_read == 6 && n_write == 5, "instantiated for 10/5 and 6/5");
+    tvdn::MixPtrs p;
+    std::memset(&p, 0, sizeof p);
+    for (int k = 0; k < n_read; ++k) p.in[k] = (const float4 *)in[k];
+    for (int k = 0; k < n_write; ++k) p.out[k] = (float4 *)out[k];
+    const long long plane16 = bytes_each / 16 / rows, tiles = (plane16 + 255) / 256;
+    const long long grid = tiles * ((rows + chunk - 1) / chunk);
+    TVDN_REQUIRE(grid < (1LL << 31), "grid too large");
+    if (n_read == 10)
+        hipLaunchKernelGGL((tvdn::stream_mix_march_kernel<10, 5>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, plane16, (long long)rows, tiles, chunk);
+    else
+        hipLaunchKernelGGL((tvdn::stream_mix_march_kernel<6, 5>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, plane16, (long long)rows, tiles, chunk);
+    TVDN_HIP(hipGetLastError());
+    return TVDN_OK;
+}
 
 extern "C" int tvdn_stream_mix(int32_t n_read, const void *const *in, int32_t n_write, void *const *out, int64_t bytes_each,
                                void *stream)

@@ -344,6 +344,10 @@ int tvdn_copy_many(int32_t n, void *const *dst, const void *const *src, int64_t 
  * puts the two side by side.  Instantiated for the mixes of the fused sweep: 10/5, 6/5, 8/4, 5/4, and 1/1. */
 int tvdn_stream_mix(int32_t n_read, const void *const *in, int32_t n_write, void *const *out, int64_t bytes_each,
                     void *stream);
+/* The same stream in the sweep's own traversal: a workgroup owns a 4 KiB tile of a row-plane and marches `chunk` of the
+ * `rows` rows (10/5 and 6/5 mixes): what that structure reaches before neighbour re-reads and arithmetic. */
+int tvdn_stream_mix_march(int32_t n_read, const void *const *in, int32_t n_write, void *const *out, int64_t bytes_each,
+                          int64_t rows, int32_t chunk, void *stream);
 
 /* Synthetic input (cytvdn_amd/synth.py restated on the device, bit-identical): fills rows
  * [row0, row0+rows) of the GLOBAL cube `shape` into `out` (rows*prod(shape[1:]) elements). */

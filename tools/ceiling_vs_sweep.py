@@ -66,6 +66,8 @@ def main():
         v = np.array(each[:nl.value])
         return float(v.mean()), float(v.min())
 
+    self_march = {}
+
     def mix_ms(be):
         # the arrays the NEXT sweep would read and write, in its roles
         if fista:
@@ -85,6 +87,20 @@ def main():
             torch.cuda.synchronize()
             if i >= 2:
                 ts.append(e0.elapsed_time(e1))
+        tm = {}
+        if dt.itemsize == 4 and (len(ins), len(outs)) in ((10, 5), (6, 5)):
+            for chunk in (8, 1, 32):      # the same stream walked like the sweep: 4 KiB tiles marching `chunk` rows
+                tt = []
+                for i in range(a.steps + 2):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    _lib.check(L.tvdn_stream_mix_march(len(ins), pi, len(outs), po, n_bytes, shape[0], chunk, _lib.current_stream(0)))
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if i >= 2:
+                        tt.append(e0.elapsed_time(e1))
+                tm[f"march{chunk}_ms"] = round(float(np.mean(tt)), 4)
+        self_march.update(tm)
         return float(np.mean(ts)), float(np.min(ts)), len(ins), len(outs)
 
     for rep in range(2):
@@ -95,7 +111,8 @@ def main():
             print(json.dumps({"config": a.config, "placement": j, "rep": rep, "sweep_ms": round(s_mean, 4), "sweep_min_ms": round(s_min, 4),
                               "stream_mix": f"{nr}R/{nw}W", "mix_ms": round(m_mean, 4), "mix_min_ms": round(m_min, 4),
                               "sweep_over_mix": round(s_mean / m_mean, 4),
-                              "mix_GBps": round(moved / (m_mean * 1e-3) / 1e9), "sweep_moved_GBps": round(moved / (s_mean * 1e-3) / 1e9)}),
+                              "mix_GBps": round(moved / (m_mean * 1e-3) / 1e9), "sweep_moved_GBps": round(moved / (s_mean * 1e-3) / 1e9),
+                              **self_march}),
                   flush=True)
 
 
