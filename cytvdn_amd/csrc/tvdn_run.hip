@@ -513,8 +513,7 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
         for (int i = 0; i < world; ++i) same += (a->n_devices == 0 || a->devices[i] == a->devices[0]) ? 1 : 0;
         // ONE threshold (tvdn_plan's `fits`): a state beyond 90 % of the free HBM streams when asked to decide, else is refused
         const bool over = pl.bytes_per_slab * same > (int64_t)(0.9 * (double)pl.free_bytes);
-        if (stream_auto && over && world == 1 &&
-            a->bc_mode == TVDN_BC_JIA_ZHAO) {
+        if (stream_auto && over && world == 1) {
             // asked to decide: one device, state beyond its HBM -> stream it (tvdn_stream.hip; it refuses, before it
             // touches the caller's arrays, what the host cannot hold either)
             size_t row_bytes = a->dtype == TVDN_F32 ? 4 : 8;

@@ -242,7 +242,10 @@ extern "C" int tvdn_stream_host_need(const tvdn_run_args *a, int64_t *need_bytes
     const int n_state = a->n_fista > 0 ? 2 : 1;
     const bool want_mse = a->mse_out != nullptr && a->reference != nullptr;
     const bool aliased = a->data && a->recon_out && cube < 9.0e18 && tvdn::arrays_overlap(a->data, a->recon_out, cube_b);
-    const double need = (double)(a->ndim * n_state + 2 + (want_mse ? 1 : 0) + (aliased ? 1 : 0)) * cube;
+    // periodic boundaries: the rows at one end are the other end's halo, uploaded late in a pass that has already sent
+    // their new values home -- old and new state are then two sets of arrays instead of one updated in place
+    const int twice = a->bc_mode == TVDN_BC_PERIODIC ? 2 : 1;
+    const double need = (double)((a->ndim * n_state + 1) * twice + 1 + (want_mse ? 1 : 0) + (aliased ? 1 : 0)) * cube;
     const size_t avail = tvdn::host_available_bytes();
     if (need_bytes) *need_bytes = need < 9.0e18 ? (int64_t)need : INT64_MAX;
     if (avail_bytes) *avail_bytes = (int64_t)avail;
@@ -272,11 +275,16 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
     const int n_state = fista ? 2 : 1;
     const bool want_mse = a->mse_out != nullptr && a->reference != nullptr;
     const int device = a->n_devices > 0 ? a->devices[0] : a->device;
-    TVDN_REQUIRE(a->bc_mode == TVDN_BC_JIA_ZHAO, "the streamed tvdn_run handles Jia-Zhao boundaries (bc_mode 2); periodic cubes beyond "
-                 "HBM go through cytvdn_amd.wavefront (Python), which extends the cube by k wrapped rows");
+    const bool periodic = a->bc_mode == TVDN_BC_PERIODIC;
+    TVDN_REQUIRE(periodic || a->bc_mode == TVDN_BC_JIA_ZHAO, "the streamed tvdn_run handles bc_mode 0 and 2");
     TVDN_REQUIRE(R >= 1 && K >= 1, "stream_rows and stream_k must be >= 1");
     if (a->use_stop) K = 1;  // the stopping rule needs a decision after every iteration: one level per pass
     K = std::min<int64_t>(K, std::max<int64_t>(1, n_total));
+    // Periodic boundaries along axis 0: the sweeps see a virtual cube of N0 + 2 K rows -- the cube between K wrapped rows
+    // at either end, which are each other's halo -- and, as at the face between two slabs, give up one row per level at
+    // the two artificial faces; the wrap itself is never swept (cytvdn_amd/wavefront.py does the same).
+    if (periodic) K = std::min<int64_t>(K, N0);
+    const int64_t KX = periodic ? K : 0, NV = N0 + 2 * KX, G0 = KX, G1 = KX + N0;
     // BEFORE anything of the caller's is touched: can the host hold the state at all?  (page-locked: it cannot swap)
     {
         int64_t need = 0, avail = 0;
@@ -306,7 +314,9 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
 
     // Jia-Zhao wrap at the top face: exact (TVDN_EDGE_WRAP, row 0 of every level kept aside) when row 0 is not finite
     bool exact_wrap = false;
-    if (a->dtype == TVDN_F32) {
+    if (periodic) {
+        // the wrap is swept for real on the extended cube
+    } else if (a->dtype == TVDN_F32) {
         const float *p0 = (const float *)a->data;
         for (size_t i = 0; i < plane && !exact_wrap; ++i) exact_wrap = !std::isfinite(p0[i]);
     } else {
@@ -343,6 +353,20 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
             if (rc) return rc;
             parallel_copy(state_h[(size_t)q * 2 + s].p, nullptr, cube_bytes);
         }
+    // periodic: a second set (new state of a pass); Jia-Zhao runs update the one set in place
+    HostArr recon2_h;
+    std::unique_ptr<HostArr[]> state2_h(new HostArr[(size_t)nd * 2]);
+    if (periodic) {
+        if ((rc = recon2_h.alloc(cube_bytes))) return rc;
+        for (int q = 0; q < nd; ++q)
+            for (int s = 0; s < n_state; ++s)
+                if ((rc = state2_h[(size_t)q * 2 + s].alloc(cube_bytes))) return rc;
+    }
+    int h_old = 0;  // which set holds the current state (periodic); 0 = recon_h / state_h
+    auto recon_of = [&](int set) -> char * { return (periodic && set) ? recon2_h.p : recon_h.p; };
+    auto state_of = [&](int set, int q, int s) -> char * {
+        return (periodic && set) ? state2_h[(size_t)q * 2 + s].p : state_h[(size_t)q * 2 + s].p;
+    };
 
     // ---- device: rings, staging boxes, sums ----------------------------------------------------------------------------
     CtxHolder ctx;
@@ -374,8 +398,10 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
         for (int64_t j = 0; j <= K; ++j) row0.push_back(take(plane_b));
     auto A = [&](int64_t level, int q) -> Ring & { return Aw[(size_t)(level + 1) * nd + q]; };
 
-    TVDN_HIP(hipMalloc(&sums_d.p, sizeof(double) * 3 * (size_t)std::max(1, n_total)));
-    TVDN_HIP(hipMemsetAsync(sums_d.p, 0, sizeof(double) * 3 * (size_t)std::max(1, n_total), st.main));
+    // one slot per iteration, and a last one that takes the sums of halo rows (periodic: the wrapped rows are swept too)
+    TVDN_HIP(hipMalloc(&sums_d.p, sizeof(double) * 3 * (size_t)(n_total + 1)));
+    TVDN_HIP(hipMemsetAsync(sums_d.p, 0, sizeof(double) * 3 * (size_t)(n_total + 1), st.main));
+    const int discard = n_total;
     // squared errors per (slot, row): summed in row order on the host at the end
     if (want_mse) {
         TVDN_HIP(hipMalloc(&mse_d.p, sizeof(double) * (size_t)(n_total + 1) * (size_t)N0));
@@ -394,12 +420,12 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
     std::memset(&it, 0, sizeof it);
     it.dtype = a->dtype;
     it.ndim = nd;
-    it.shape[0] = N0;
+    it.shape[0] = NV;
     for (int i = 1; i < nd; ++i) it.shape[i] = a->shape[i];
     it.row_lo = 0;
-    it.row_hi = N0;
+    it.row_hi = NV;
     it.lo_mode = TVDN_EDGE_BC;
-    it.hi_mode = exact_wrap ? TVDN_EDGE_WRAP : TVDN_EDGE_ZERO;
+    it.hi_mode = periodic ? TVDN_EDGE_BC : (exact_wrap ? TVDN_EDGE_WRAP : TVDN_EDGE_ZERO);
     it.bc_mode = a->bc_mode;
     it.accumulate = 1;
     it.ring_rows = cap;
@@ -438,21 +464,36 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
             if (acc) prev = ratios[j];
         }
         const int n_in_state = forms[0] ? 2 : 1, n_out_state = forms[kk] ? 2 : 1;
-        const int64_t n_chunks = (N0 + kk + R - 1) / R;
+        // rows of the (virtual) cube this pass works on, and what each level can reach at an artificial face
+        const int64_t E0 = periodic ? KX - kk : 0, E1 = periodic ? G1 + kk : N0;
+        auto lo_bound = [&](int64_t level) { return periodic ? E0 + level : (int64_t)0; };
+        auto hi_bound = [&](int64_t level) { return periodic ? E1 - level : N0; };
+        const int64_t n_chunks = (E1 - E0 + kk + R - 1) / R;
+        const int h_new = periodic ? h_old ^ 1 : h_old;
 
+        // virtual rows [v0, v1) of a host array -> box: host row = (v - KX) mod N0, i.e. up to three contiguous pieces
+        auto up_rows = [&](char *box, const char *host, int64_t v0, int64_t v1) -> int {
+            for (int64_t v = v0; v < v1;) {
+                const int64_t hrow = ((v - KX) % N0 + N0) % N0;
+                const int64_t n = std::min(v1 - v, N0 - hrow);
+                TVDN_HIP(hipMemcpyAsync(box + (size_t)(v - v0) * row_bytes, host + (size_t)hrow * row_bytes, (size_t)n * row_bytes,
+                                        hipMemcpyHostToDevice, st.up));
+                v += n;
+            }
+            return TVDN_OK;
+        };
         auto upload = [&](int64_t c) -> int {
-            const int64_t u0 = c * R, u1 = std::min((c + 1) * R, N0);
+            const int64_t u0 = E0 + c * R, u1 = std::min(E0 + (c + 1) * R, E1);
             if (u0 >= u1) return TVDN_OK;
             const int h = (int)(c % 2);
             if (in_free_set[h]) TVDN_HIP(hipStreamWaitEvent(st.up, in_free[h], 0));
-            const size_t off = (size_t)u0 * row_bytes, len = (size_t)(u1 - u0) * row_bytes;
-            int i = 0;
-            TVDN_HIP(hipMemcpyAsync(inbox[h][i++], orig_h.p + off, len, hipMemcpyHostToDevice, st.up));
-            TVDN_HIP(hipMemcpyAsync(inbox[h][i++], recon_h.p + off, len, hipMemcpyHostToDevice, st.up));
+            int i = 0, rcu;
+            if ((rcu = up_rows(inbox[h][i++], orig_h.p, u0, u1))) return rcu;
+            if ((rcu = up_rows(inbox[h][i++], recon_of(h_old), u0, u1))) return rcu;
             for (int q = 0; q < nd; ++q)
                 for (int s = 0; s < n_in_state; ++s)
-                    TVDN_HIP(hipMemcpyAsync(inbox[h][i++], state_h[(size_t)q * 2 + s].p + off, len, hipMemcpyHostToDevice, st.up));
-            if (want_mse) TVDN_HIP(hipMemcpyAsync(inbox[h][i++], ref_h.p + off, len, hipMemcpyHostToDevice, st.up));
+                    if ((rcu = up_rows(inbox[h][i++], state_of(h_old, q, s), u0, u1))) return rcu;
+            if (want_mse && (rcu = up_rows(inbox[h][i++], ref_h.p, u0, u1))) return rcu;
             TVDN_HIP(hipEventRecord(in_ready[h], st.up));
             return TVDN_OK;
         };
@@ -462,7 +503,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
         for (int64_t c = 0; c < n_chunks; ++c) {
             if ((rc2 = upload(c + 1))) return rc2;  // the next chunk crosses PCIe while this one is swept
             const int h = (int)(c % 2);
-            const int64_t u0 = c * R, u1 = std::min((c + 1) * R, N0);
+            const int64_t u0 = E0 + c * R, u1 = std::min(E0 + (c + 1) * R, E1);
             if (u0 < u1) {
                 TVDN_HIP(hipStreamWaitEvent(st.main, in_ready[h], 0));
                 cdst.clear();
@@ -485,18 +526,16 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
                 if (rc2) return rc2;
                 if (exact_wrap && u0 == 0)
                     TVDN_HIP(hipMemcpyAsync(row0[0], Rw[0].row(0), row_bytes, hipMemcpyDeviceToDevice, st.main));
-                if (want_mse && done == 0)  // MSE[0]: the input against the reference (cyTVDN.py:124-125)
-                    for (int64_t g = u0; g < u1; ++g)
-                        if ((rc2 = sse_row(Rw[0].row(g), Fw.row(g), 0, g))) return rc2;
+                if (want_mse && done == 0)  // MSE[0]: the input against the reference (cyTVDN.py:124-125), own rows
+                    for (int64_t g = std::max(u0, G0); g < std::min(u1, G1); ++g)
+                        if ((rc2 = sse_row(Rw[0].row(g), Fw.row(g), 0, g - KX))) return rc2;
                 TVDN_HIP(hipEventRecord(in_free[h], st.main));
                 in_free_set[h] = true;
             }
             // the wavefront: level j+1 trails level j by one row
             for (int j = 0; j < kk; ++j) {
-                const int64_t lo = std::max<int64_t>(0, c * R - (j + 1)), hi = std::min<int64_t>(N0, (c + 1) * R - (j + 1));
+                const int64_t lo = std::max(lo_bound(j + 1), E0 + c * R - (j + 1)), hi = std::min(hi_bound(j + 1), E0 + (c + 1) * R - (j + 1));
                 if (lo >= hi) continue;
-                it.sweep_lo = lo;
-                it.sweep_hi = hi;
                 it.mode = modes[j];
                 it.tk = modes[j] == TVDN_ITER_FISTA_D ? ratios[j] : 0.0;
                 it.tk_prev = tkp[j];
@@ -515,16 +554,25 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
                         it.b_in[q] = cur; it.b_out[q] = nxt;
                     }
                 }
-                rc2 = tvdn_iterate_fused(ctx.c, &it, (double *)sums_d.p + 3 * (size_t)(done + j), st.main);
-                if (rc2) return rc2;
+                // the sums count the cube's own rows once: wrapped rows (periodic) go to the discard slot
+                const int64_t parts[3][2] = {{lo, std::min(hi, G0)}, {std::max(lo, G0), std::min(hi, G1)}, {std::max(lo, G1), hi}};
+                for (int part = 0; part < 3; ++part) {
+                    const int64_t x0 = parts[part][0], x1 = parts[part][1];
+                    if (x0 >= x1) continue;
+                    it.sweep_lo = x0;
+                    it.sweep_hi = x1;
+                    const int slot = part == 1 ? done + j : discard;
+                    rc2 = tvdn_iterate_fused(ctx.c, &it, (double *)sums_d.p + 3 * (size_t)slot, st.main);
+                    if (rc2) return rc2;
+                    if (want_mse && part == 1)
+                        for (int64_t g = x0; g < x1; ++g)
+                            if ((rc2 = sse_row(Fw.row(g), Rw[j + 1].row(g), done + j + 1, g - KX))) return rc2;
+                }
                 if (exact_wrap && lo == 0)
                     TVDN_HIP(hipMemcpyAsync(row0[j + 1], Rw[j + 1].row(0), row_bytes, hipMemcpyDeviceToDevice, st.main));
-                if (want_mse)
-                    for (int64_t g = lo; g < hi; ++g)
-                        if ((rc2 = sse_row(Fw.row(g), Rw[j + 1].row(g), done + j + 1, g))) return rc2;
             }
             // rows that have reached the last level go home
-            const int64_t lo = std::max<int64_t>(0, c * R - kk), hi = std::min<int64_t>(N0, (c + 1) * R - kk);
+            const int64_t lo = std::max(G0, E0 + c * R - kk), hi = std::min(G1, E0 + (c + 1) * R - kk);
             if (lo < hi) {
                 if (out_free_set[h]) TVDN_HIP(hipStreamWaitEvent(st.main, out_free[h], 0));
                 cdst.clear();
@@ -545,25 +593,25 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
                 if (rc2) return rc2;
                 TVDN_HIP(hipEventRecord(out_ready[h], st.main));
                 TVDN_HIP(hipStreamWaitEvent(st.down, out_ready[h], 0));
-                const size_t off = (size_t)lo * row_bytes, len = (size_t)(hi - lo) * row_bytes;
+                const size_t off = (size_t)(lo - KX) * row_bytes, len = (size_t)(hi - lo) * row_bytes;
                 i = 0;
                 if (down_blocks > 0 && len % 16 == 0) {  // measurement knob: one capped copy launch writing pinned memory
                     cdst.clear();
                     csrc.clear();
-                    cdst.push_back(recon_h.p + off);
+                    cdst.push_back(recon_of(h_new) + off);
                     csrc.push_back(outbox[h][i++]);
                     for (int q = 0; q < nd; ++q)
                         for (int s = 0; s < n_out_state; ++s) {
-                            cdst.push_back(state_h[(size_t)q * 2 + s].p + off);
+                            cdst.push_back(state_of(h_new, q, s) + off);
                             csrc.push_back(outbox[h][i++]);
                         }
                     rc2 = tvdn_copy_many((int32_t)cdst.size(), cdst.data(), csrc.data(), (int64_t)len, down_blocks, st.down);
                     if (rc2) return rc2;
                 } else {
-                    TVDN_HIP(hipMemcpyAsync(recon_h.p + off, outbox[h][i++], len, hipMemcpyDeviceToHost, st.down));
+                    TVDN_HIP(hipMemcpyAsync(recon_of(h_new) + off, outbox[h][i++], len, hipMemcpyDeviceToHost, st.down));
                     for (int q = 0; q < nd; ++q)
                         for (int s = 0; s < n_out_state; ++s)
-                            TVDN_HIP(hipMemcpyAsync(state_h[(size_t)q * 2 + s].p + off, outbox[h][i++], len, hipMemcpyDeviceToHost, st.down));
+                            TVDN_HIP(hipMemcpyAsync(state_of(h_new, q, s) + off, outbox[h][i++], len, hipMemcpyDeviceToHost, st.down));
                 }
                 TVDN_HIP(hipEventRecord(out_free[h], st.down));
                 out_free_set[h] = true;
@@ -575,6 +623,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
         d_form = forms[kk];
         tk_prev = prev;
         done += kk;
+        h_old = h_new;
         return TVDN_OK;
     };
 
@@ -623,7 +672,10 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
                 std::chrono::duration<double>(t_passes - t_start).count(), std::chrono::duration<double>(now - t_passes).count());
     }
     // ---- results home -------------------------------------------------------------------------------------------------------
-    if (recon_h.owned) parallel_copy(a->recon_out, recon_h.p, cube_bytes);
+    if (periodic && h_old == 1)
+        parallel_copy(a->recon_out, recon2_h.p, cube_bytes);  // the last pass wrote the second set
+    else if (recon_h.owned)
+        parallel_copy(a->recon_out, recon_h.p, cube_bytes);
     if (n_total > 0) TVDN_HIP(hipMemcpy(a->sums_out, sums_d.p, sizeof(double) * 3 * (size_t)n_total, hipMemcpyDeviceToHost));
     if (want_mse) {
         std::vector<double> per_row((size_t)(n_total + 1) * (size_t)N0);

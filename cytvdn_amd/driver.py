@@ -275,14 +275,13 @@ def _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fi
                    reference_data=None, out=None, exact_wrap=False):
     """Host-resident state, wavefront schedule: anything but a stopping rule.  An in-memory cube with Jia-Zhao
     boundaries goes through the library's own streamed loop (tvdn_run, csrc/tvdn_stream.hip; same rate as the
-    Python-driven one, measured); cubes on disk, periodic boundaries and TVDN_STREAM_ENGINE=python take
+    Python-driven one, measured), with either boundary condition; cubes on disk and TVDN_STREAM_ENGINE=python take
     cytvdn_amd/wavefront.py, the same schedule driven from Python."""
     from .wavefront import WavefrontRunner
     dtype = datacube.dtype
     n_total = n_fista + n_plain
     rows, k = plan
-    if isinstance(datacube, np.ndarray) and out is None and int(BC_mode) == 2 \
-            and os.environ.get("TVDN_STREAM_ENGINE", "native") == "native":
+    if isinstance(datacube, np.ndarray) and out is None and os.environ.get("TVDN_STREAM_ENGINE", "native") == "native":
         return _run_device_list([device], datacube, lambdaInv, lam_mu, n_fista if FISTA else 0,
                                 n_plain if unaccelerated else 0, None, reference_data, BC_mode, True,
                                 stream=(max(1, rows), max(1, k)))

@@ -263,7 +263,8 @@ typedef struct tvdn_run_args {
      * 0 / 0: never (a state beyond the HBM is refused with TVDN_ERR_UNSUPPORTED and the arithmetic in the message);
      * -1 / -1: decided here -- resident when it fits, else the deepest stream_k whose rings fit 70 % of the free HBM;
      * both > 0: stream with exactly these.  A cube whose state the host cannot hold page-locked either is refused
-     * before any of the caller's arrays is touched.  Jia-Zhao boundaries; with use_stop one iteration per
+     * before any of the caller's arrays is touched.  Both boundary conditions (periodic: the cube is swept between
+     * stream_k wrapped rows at either end, and old and new host state are two sets of arrays); with use_stop one iteration per
      * pass.  `data` / `recon_out` / `reference` are page-locked in place for the duration of the call when they are
      * large (>= 256 MiB) and the runtime allows it, else staged through pinned copies; recon_out then doubles as
      * the host copy of the state. */

@@ -55,9 +55,14 @@ def test_staged_early_stop_matches(monkeypatch):
     ((17, 6, 16), "float64", [4, 3], True, 4, 6, 0),
     ((6, 3, 4, 8), "float32", 7, True, 2, 9, 0),              # k capped at the cube height
     ((15, 3, 4, 8), "float32", 8, True, 1, 5, 0),             # one-row chunks
+    ((12, 5, 8, 12), "float32", 6, False, 3, 2, 0),           # unaccelerated
 ])
-def test_wavefront_periodic(oracle, monkeypatch, shape, dtype, its, fista, rows, k, bc):
+@pytest.mark.parametrize("engine", ["native", "python"])
+def test_wavefront_periodic(oracle, monkeypatch, shape, dtype, its, fista, rows, k, bc, engine):
+    """Periodic boundaries beyond HBM, by the library's own streamed loop (csrc/tvdn_stream.hip: virtual cube between k
+    wrapped rows, old and new host state apart) and by the Python-driven engine: the oracle's bits."""
     import cytvdn_amd as tv
+    monkeypatch.setenv("TVDN_STREAM_ENGINE", engine)
     from cytvdn_amd import synth
     dt = np.dtype(dtype)
     nd = len(shape)

@@ -14,6 +14,12 @@ from golden_util import bits_equal
 pytestmark = pytest.mark.gpu
 
 
+def _oracle_bc(oracle, x, mu, n_f, n_p, bc, **kw):
+    if n_f and n_p:
+        return oracle.denoise(x, mu, [n_f, n_p], True, BC_mode=bc, **kw)
+    return oracle.denoise(x, mu, n_f or n_p, bool(n_f), BC_mode=bc, **kw)
+
+
 def _oracle(oracle, x, mu, n_f, n_p, **kw):
     """The CPU oracle on the same schedule (lam = mu/32 for 4-D, mu/16 for 3-D, as `_run` sets it)."""
     if n_f and n_p:
@@ -27,13 +33,13 @@ def _check_traces(sums, ref, n):
     np.testing.assert_allclose(sums[:n, 2], ref["rnorm64"][:n], rtol=1e-9)
 
 
-def _run(x, mu, n_f, n_p, stop=None, ref=None, stream=None, device=0):
+def _run(x, mu, n_f, n_p, stop=None, ref=None, stream=None, device=0, bc=2):
     from cytvdn_amd import _lib
     dt = x.dtype
     nd = x.ndim
     lam = mu / dt.type(32.0 if nd == 4 else 16.0)
     n = n_f + n_p
-    a = _lib.RunArgs(dtype=_lib.dtype_code(dt), ndim=nd, bc_mode=2, device=device, n_fista=n_f, n_plain=n_p,
+    a = _lib.RunArgs(dtype=_lib.dtype_code(dt), ndim=nd, bc_mode=bc, device=device, n_fista=n_f, n_plain=n_p,
                      use_stop=int(stop is not None), stop=float(stop or 0.0))
     if stream:
         a.stream_rows, a.stream_k = stream
@@ -188,3 +194,39 @@ def test_streamed_run_in_place(oracle):
         _lib.check(_lib.lib().tvdn_run(C.byref(a)))
         assert bits_equal(buf, ref["recon"]), stream
         _check_traces(sums, ref, 7)
+
+
+@pytest.mark.parametrize("shape,dtype,n_f,n_p,rows,k,stop", [
+    ((23, 3, 4, 8), np.float32, 9, 0, 5, 3, None),         # three passes; the two ends are each other's halo
+    ((17, 6, 16), np.float64, 4, 3, 4, 6, None),           # hybrid, the d -> b transition inside the second pass
+    ((6, 3, 4, 8), np.float32, 7, 0, 2, 9, None),          # k capped at the cube height
+    ((15, 3, 4, 8), np.float32, 0, 8, 1, 5, None),         # one-row chunks, unaccelerated
+    ((11, 2, 5, 7), np.float32, 6, 0, 3, 2, None),         # scalar packs
+    ((12, 5, 8, 12), np.float32, 0, 40, 4, 6, 0.02),       # stopping rule: one level per pass
+])
+def test_streamed_run_with_periodic_boundaries(oracle, shape, dtype, n_f, n_p, rows, k, stop):
+    """bc_mode 0 through the streamed tvdn_run: the cube between k wrapped rows at either end (which give up a row per
+    level, like the face between two slabs), old and new host state in separate arrays.  Recon and traces are the
+    oracle's (reference loop with BC_mode=0: cyTVDN.py:148-242, anisotropic.pyx:65-73, utils.pyx:98-101), the sums count
+    every row of the cube exactly once, and an MSE trace counts own rows only."""
+    from cytvdn_amd import synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=71, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    refc = synth.cube(shape, seed=71, dtype=dt, kind="mean")
+    x_before = x.copy()
+    got = _run(x, mu, n_f, n_p, stop=stop, ref=refc, stream=(rows, k), bc=0)
+    want = _run(x, mu, n_f, n_p, stop=stop, ref=refc, bc=0)              # the resident run wraps for real
+    assert bits_equal(x, x_before)
+    assert got[3] == want[3] and bits_equal(got[0], want[0])
+    ref = _oracle_bc(oracle, x, mu, n_f, n_p, 0, stopping_relative_change=stop, reference_data=refc)
+    assert bits_equal(got[0], ref["recon"]) and ref["iters_done"] == got[3]
+    ran = got[1][:, 2] != 0
+    assert ran.sum() == got[3]
+    np.testing.assert_allclose(got[1][ran, 0], ref["b_norm64"][ran], rtol=1e-9)
+    np.testing.assert_allclose(got[1][ran, 1], ref["delta64"][ran], rtol=1e-9)
+    np.testing.assert_allclose(got[1][ran, 2], ref["rnorm64"][ran], rtol=1e-9)
+    n_run = np.nonzero(ran)[0]
+    np.testing.assert_allclose(got[2][0], ref["MSE64"][0], rtol=2e-7)
+    np.testing.assert_allclose(got[2][n_run + 1], ref["MSE64"][n_run + 1], rtol=2e-7)

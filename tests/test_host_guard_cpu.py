@@ -42,6 +42,17 @@ def test_need_counts_the_arrays_a_streamed_run_pins(monkeypatch, shape, dtype, n
     assert rc == 0 and need == cubes * int(np.prod(shape)) * (4 if dtype == 0 else 8) and 0 < avail <= GiB
 
 
+def test_periodic_runs_keep_old_and_new_state_apart(monkeypatch):
+    monkeypatch.setenv("TVDN_HOST_LIMIT", "1G")
+    cube = 8 * 4 * 4 * 8 * 4
+    a = _args((8, 4, 4, 8))
+    a.bc_mode = 0
+    assert _need(a)[1] == (2 * (4 * 2 + 1) + 1) * cube          # data + 2 x (recon + 2 state arrays per axis)
+    a = _args((8, 4, 8), dtype=1, n_fista=0, n_plain=3)
+    a.bc_mode = 0
+    assert _need(a)[1] == (2 * (3 + 1) + 1) * 8 * 4 * 8 * 8
+
+
 def test_aliased_data_and_result_cost_one_more_cube(monkeypatch):
     monkeypatch.setenv("TVDN_HOST_LIMIT", "1G")
     cube = 8 * 4 * 4 * 8 * 4
