@@ -146,8 +146,25 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
     be = HipBackend.best_of(_audition_candidates(n_total), layout, dtype, FISTA, device=device,
                             max_iters=n_total)                                # raises without a GPU
     be.set_params(lambdaInv, lam_mu)
-    be.set_input(datacube)
     runner = SlabRunner(be)
+    # A NumPy cube, nothing watching the iterations, Jia-Zhao boundaries, a finite first row: the first iterations run
+    # under the upload and the last ones over the download (cytvdn_amd/pipelined.py); TVDN_PIPELINE=0 keeps the plain order
+    pipe = None
+    if isinstance(datacube, np.ndarray) and out is None and reference_data is None and stopping_relative_change is None \
+            and (quiet or _tqdm is None) and int(BC_mode) == 2 and not exact_wrap and be.state == "compact" \
+            and os.environ.get("TVDN_PIPELINE", "1") != "0":
+        from . import pipelined
+        pipe = pipelined.plan(datacube.shape[0], n_total, datacube.nbytes)
+        if os.environ.get("TVDN_PIPELINE", "1") not in ("0", "1"):        # "rows,k_start,k_end": forced (tests)
+            pipe = tuple(int(v) for v in os.environ["TVDN_PIPELINE"].split(","))
+    if pipe is not None:
+        recon = pipelined.run(be, runner, datacube, n_fista if FISTA else 0, n_plain if unaccelerated else 0, *pipe)
+        sums = be.sums.cpu().numpy()[:n_total]
+        b_norm = sums[:, 0].astype(dtype)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            delta_recon = (sums[:, 1].astype(dtype) / sums[:, 2].astype(dtype)).astype(dtype)
+        return recon, b_norm, delta_recon
+    be.set_input(datacube)
 
     calculate_MSE = reference_data is not None
     mse_dev = ref_dev = None
