@@ -43,7 +43,9 @@ def test_pipelined_run_matches_the_oracle(oracle, monkeypatch, shape, dtype, its
     np.testing.assert_allclose(dl.astype(np.float64), want, rtol=1e-6 if dt == np.float32 else 1e-9)
     monkeypatch.setenv("TVDN_PIPELINE", "0")
     plain = fn(x, mu, its, FISTA=fista, quiet=True)
-    assert bits_equal(recon, plain[0]) and np.array_equal(bn, plain[1])
+    assert bits_equal(recon, plain[0])
+    # the same f64 sums, folded per partial launch instead of per sweep: the last bits may differ
+    np.testing.assert_allclose(bn.astype(np.float64), plain[1].astype(np.float64), rtol=1e-6 if dt == np.float32 else 1e-12)
 
 
 def test_the_plan_switches_itself_on_for_large_cubes_only():
