@@ -84,6 +84,10 @@ def plan(n_rows: int, n_total: int, cube_bytes: int):
 def run(be, runner, x: np.ndarray, n_fista: int, n_plain: int, R: int, k_start: int, k_end: int) -> np.ndarray:
     """n_fista FISTA iterations then n_plain unaccelerated ones on the (fresh) backend `be`, input `x` still on the host;
     returns the reconstruction as a new host array.  `runner` (engine.SlabRunner) runs the iterations in between."""
+    import os
+    import time
+    timing = os.environ.get("TVDN_PIPE_TIMING")
+    t0 = time.perf_counter()
     L = _lib.lib()
     N0 = x.shape[0]
     n_total = n_fista + n_plain
@@ -128,6 +132,9 @@ def run(be, runner, x: np.ndarray, n_fista: int, n_plain: int, R: int, k_start: 
         raise err[0]
     runner.ran.extend(range(k_start))
     runner.iter = k_start
+    if timing:
+        main.synchronize()
+        t1 = time.perf_counter()
 
     # ---- middle: whole sweeps ------------------------------------------------------------------------------------------------
     mid = n_total - k_start - k_end
@@ -135,6 +142,9 @@ def run(be, runner, x: np.ndarray, n_fista: int, n_plain: int, R: int, k_start: 
     if mid > 0:
         runner.run(mid_f, mid - mid_f, None, first_fista=k_start if mid_f else 0)
 
+    if timing:
+        main.synchronize()
+        t2 = time.perf_counter()
     # ---- end: the last levels as a wavefront, finished rows go home chunk by chunk ---------------------------------------------
     out = np.empty(x.shape, x.dtype)
     if k_end <= 0:
@@ -179,4 +189,9 @@ def run(be, runner, x: np.ndarray, n_fista: int, n_plain: int, R: int, k_start: 
     runner.ran.extend(range(first, n_total))
     runner.iter = n_total
     main.synchronize()
+    if timing:
+        import sys
+        t3 = time.perf_counter()
+        print(f"pipelined: start ({k_start} levels under the upload) {t1 - t0:.3f} s, middle {t2 - t1:.3f} s, "
+              f"end ({k_end} levels over the download) {t3 - t2:.3f} s", file=sys.stderr)
     return out
