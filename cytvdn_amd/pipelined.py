@@ -118,9 +118,13 @@ def run(be, runner, x: np.ndarray, n_fista: int, n_plain: int, R: int, k_start: 
     th.start()
     cur0 = be.cur
 
+    waited = [0.0]
+
     def before(c):
         if c < n_up:
+            tw = time.perf_counter()
             arrived[c].wait()
+            waited[0] += time.perf_counter() - tw
             if err:
                 raise err[0]
             a, b = c * R, min((c + 1) * R, N0)
@@ -192,6 +196,6 @@ def run(be, runner, x: np.ndarray, n_fista: int, n_plain: int, R: int, k_start: 
     if timing:
         import sys
         t3 = time.perf_counter()
-        print(f"pipelined: start ({k_start} levels under the upload) {t1 - t0:.3f} s, middle {t2 - t1:.3f} s, "
+        print(f"pipelined: start ({k_start} levels under the upload) {t1 - t0:.3f} s (of which {waited[0]:.3f} s waiting for rows), middle {t2 - t1:.3f} s, "
               f"end ({k_end} levels over the download) {t3 - t2:.3f} s", file=sys.stderr)
     return out
