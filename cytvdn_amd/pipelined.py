@@ -88,6 +88,21 @@ def run(be, runner, x: np.ndarray, n_fista: int, n_plain: int, R: int, k_start: 
     import time
     timing = os.environ.get("TVDN_PIPE_TIMING")
     t0 = time.perf_counter()
+    # Transfers that run beside the sweeps' launches: six staging lanes instead of eight.  With eight host threads copying
+    # through their pinned buffers the launching thread falls behind and the overlap is lost (config 2, 50 iterations:
+    # 0.72-0.76 s with 8 lanes = no gain, 0.62-0.64 s with 4-6; profiles/r03_e2e_pipelined.txt).  TVDN_IO_LANES overrides.
+    lanes_set = "TVDN_IO_LANES" not in os.environ
+    if lanes_set:
+        os.environ["TVDN_IO_LANES"] = "6"
+    try:
+        return _run(be, runner, x, n_fista, n_plain, R, k_start, k_end, timing, t0)
+    finally:
+        if lanes_set:
+            os.environ.pop("TVDN_IO_LANES", None)
+
+
+def _run(be, runner, x, n_fista, n_plain, R, k_start, k_end, timing, t0):
+    import time
     L = _lib.lib()
     N0 = x.shape[0]
     n_total = n_fista + n_plain
