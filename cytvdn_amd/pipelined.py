@@ -16,7 +16,7 @@ writes the buffer level j+1 reads, stays two rows behind it.  The sweeps at the 
 wrapped axis-0 accumulator of a Jia-Zhao run is identically zero while row 0 is finite; tvdn.h), since row 0 of the
 buffers belongs to a later level by then: the caller (driver._run) takes this path only for Jia-Zhao runs whose first row
 is finite.  The launches are tvdn_iterate_fused launches with the library's own role binding, so the bits are those of the
-plain loop (tests/test_gpu_pipelined.py against the oracle)."""
+plain loop (tests/test_gpu_pipelined.py checks them against the CPU restatement of the reference)."""
 from __future__ import annotations
 
 import ctypes as C
