@@ -28,7 +28,7 @@ EXPORTS = (
     "tvdn_abi_version", "tvdn_last_error", "tvdn_device_count", "tvdn_ctx_create", "tvdn_ctx_destroy",
     "tvdn_ctx_timing_enable", "tvdn_ctx_timing_read", "tvdn_ctx_timing_read_each",
     "tvdn_accumulator_update", "tvdn_datacube_update", "tvdn_sum_square_error", "tvdn_iterate_fused",
-    "tvdn_synth_fill", "tvdn_run", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many", "tvdn_plan", "tvdn_copy_many", "tvdn_stream_mix", "tvdn_stream_mix_march",
+    "tvdn_synth_fill", "tvdn_run", "tvdn_pipeline_plan", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many", "tvdn_plan", "tvdn_copy_many", "tvdn_stream_mix", "tvdn_stream_mix_march",
     "tvdn_stream_host_need", "tvdn_fista_ratios", "tvdn_iter_mode", "tvdn_roles_bind", "tvdn_roles_advance",
 )
 
@@ -80,6 +80,8 @@ class RunArgs(C.Structure):
         ("devices", C.c_int32 * 16),
         ("stream_rows", C.c_int32), ("stream_k", C.c_int32),
         ("phase_iters", C.c_void_p),
+        ("progress", C.c_void_p),
+        ("progress_user", C.c_void_p),
     ]
 
 
@@ -137,9 +139,10 @@ def lib():
     L.tvdn_iter_mode.argtypes = [C.c_int32, C.c_int32]
     L.tvdn_roles_bind.argtypes = [C.POINTER(ManyArgs), C.c_int32, C.c_double, C.POINTER(IterArgs)]
     L.tvdn_roles_advance.argtypes = [C.POINTER(ManyArgs), C.c_int32, C.c_double]
+    L.tvdn_pipeline_plan.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.POINTER(C.c_int32)]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header and library out of step
-    if L.tvdn_abi_version() != 4:
+    if L.tvdn_abi_version() != 5:
         raise TvdnError("libtvdn_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -163,6 +166,14 @@ def fista_ratios(n: int) -> np.ndarray:
     if n:
         check(lib().tvdn_fista_ratios(n, out.ctypes.data_as(C.POINTER(C.c_double))))
     return out
+
+
+def pipeline_plan(n0: int, n_iters: int, cube_bytes: int):
+    """(rows per chunk, iterations under the upload, iterations over the download) of a resident tvdn_run, or None for the
+    plain order (csrc/tvdn_run.hip pipeline_plan; honours TVDN_PIPELINE).  Host arithmetic: no GPU needed."""
+    out = (C.c_int32 * 3)()
+    check(lib().tvdn_pipeline_plan(int(n0), int(n_iters), int(cube_bytes), out))
+    return tuple(out) if out[0] > 0 else None
 
 
 def iter_mode(use_fista: bool, d_form: bool) -> int:

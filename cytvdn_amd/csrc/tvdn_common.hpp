@@ -194,6 +194,14 @@ int ensure_partials(tvdn_ctx *ctx, long long nblocks);
 int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_bytes, bool mse, bool wrap, int64_t *rows_out,
                         int64_t *k_out);
 int run_streamed(const tvdn_run_args *a, int64_t rows, int64_t k);
+void io_cap_lanes(int n);  // tvdn_hostio.hip: at most n staging lanes per transfer (0 = no cap)
+// A non-blocking stream in a hardware-queue class of its own.  The runtime multiplexes streams onto a few hardware queues
+// per PRIORITY level; two streams that share one execute in submission order, so a transfer's completion marker can sit
+// behind every sweep already queued (tvdn_run's last iterations over the download: the first chunk's copy "took" 90 ms,
+// exactly until the 72 queued sweeps had drained, 12 ms for every later one; profiles/r03_e2e_pipelined.txt).  Sweeps go
+// on a HIGH-priority stream, downloads of the streamed engine on a LOW-priority one, everything else stays normal:
+// different pools, no false ordering.  level +1 / 0 / -1; TVDN_STREAM_PRIO=0 makes every level normal (measurement).
+int make_stream(hipStream_t *s, int level);
 int launch_finalize(tvdn_ctx *ctx, int nblocks, int nv, double *out, hipStream_t s, bool accumulate = false);
 
 // ---- 16-byte packs ---------------------------------------------------------------------------

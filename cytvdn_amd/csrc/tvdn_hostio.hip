@@ -11,6 +11,7 @@
 // Both entry points are synchronous (they return when the bytes have arrived) and order themselves only against
 // their own streams: the caller synchronises the stream that produced / will consume the device buffer.
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <thread>
 
@@ -36,12 +37,36 @@ struct HostIo {
 static std::mutex g_io_mutex;       // one transfer at a time per process: the bounce buffers are shared
 static HostIo g_io[16];
 
+static std::atomic<int> g_lanes_cap{0};
+
+// Transfers that run BESIDE a thread launching sweeps (tvdn_run's pipelined start and end) use fewer staging lanes: with
+// eight host threads copying through their pinned buffers the launching thread falls behind and the overlap is lost
+// (config 2, 50 iterations from host memory: 0.72-0.76 s with 8 lanes, 0.62-0.64 s with 4-6; profiles/r03_e2e_pipelined.txt).
+void io_cap_lanes(int n) { g_lanes_cap.store(n); }
+
+int make_stream(hipStream_t *s, int level)
+{
+    const char *e = getenv("TVDN_STREAM_PRIO");
+    int least = 0, greatest = 0;
+    if (level != 0 && !(e && atoi(e) == 0)) TVDN_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const int prio = level > 0 ? greatest : (level < 0 ? least : 0);
+    if (prio == 0) {
+        TVDN_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    } else {
+        TVDN_HIP(hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio));
+    }
+    return TVDN_OK;
+}
+
 static int lanes_wanted()
 {
     unsigned hc = std::thread::hardware_concurrency();
     int n = hc ? (int)hc : 4;
     const char *e = getenv("TVDN_IO_LANES");
-    if (e && atoi(e) > 0) n = atoi(e);
+    if (e && atoi(e) > 0)
+        n = atoi(e);
+    else if (g_lanes_cap.load() > 0)
+        n = std::min(n, g_lanes_cap.load());
     return std::max(1, std::min(n, kLanes));
 }
 

@@ -3,9 +3,15 @@
 // slab of axis 0 per entry of the device list, halo rows moved device-to-device (peer copies over xGMI) on a
 // copy stream per slab while the interior rows are swept.  One host thread drives every device; nothing here
 // needs Python, torch or RCCL.
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
+#include <deque>
+#include <functional>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "tvdn_common.hpp"
@@ -75,7 +81,46 @@ static int64_t edge_block(int64_t own)
     return cap < 1 ? 1 : (e < cap ? e : cap);
 }
 
-static int run_impl(const tvdn_run_args *a)
+// Shape of a resident run's pipelined transfers (see run_impl): out = {rows per chunk, iterations that follow the upload,
+// iterations that run over the download}, {0, 0, 0} = plain order.  Eight chunks (~12 ms of PCIe each for a 4 GiB cube), as
+// many iterations at either end as a chunk's transfer pays for; cubes under 256 MiB move in milliseconds and runs under four
+// iterations have nothing to hide a transfer under.  TVDN_PIPELINE=0 keeps the plain order, "R,k0,k1" forces a shape (tests).
+static void pipeline_plan(int64_t n0, int64_t n_total, int64_t cube_bytes, int32_t out[3])
+{
+    out[0] = out[1] = out[2] = 0;
+    if (n_total <= 0 || n0 <= 0) return;
+    const char *e = getenv("TVDN_PIPELINE");
+    if (e && strchr(e, ',')) {
+        int r_ = 0, k0_ = 0, k1_ = 0;
+        if (sscanf(e, "%d,%d,%d", &r_, &k0_, &k1_) == 3 && r_ >= 1 && k0_ >= 0 && k1_ >= 0) {
+            out[0] = r_;
+            out[1] = (int32_t)std::min<int64_t>(k0_, n_total);
+            out[2] = (int32_t)std::min<int64_t>(k1_, n_total - out[1]);
+        }
+        return;
+    }
+    if ((e && atoi(e) == 0) || n_total < 4 || n0 < 32 || cube_bytes < (int64_t(256) << 20)) return;
+    out[0] = (int32_t)std::max<int64_t>(8, (n0 + 7) / 8);
+    out[1] = (int32_t)std::min<int64_t>(8, n_total / 2);
+    out[2] = (int32_t)std::min<int64_t>(8, n_total - out[1]);
+}
+
+// TVDN_RUN_TIMING=1: where a resident run's wall time goes (stderr; the device is drained at every mark, so the phases
+// are honest and the total a little longer than an untimed run's).
+struct RunClock {
+    bool on = getenv("TVDN_RUN_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char *what)
+    {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "tvdn_run: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
+static int run_impl(const tvdn_run_args *a, RunClock &clk)
 {
     const int nd = a->ndim;
     const size_t item = a->dtype == TVDN_F32 ? 4 : 8;
@@ -99,16 +144,17 @@ static int run_impl(const tvdn_run_args *a)
     // accumulator of global row 0, which is zero for finite data (TVDN_EDGE_ZERO).  If the cube's first row holds an
     // Inf or a NaN, upstream gets NaN there (anisotropic.pyx:65-73): the last slab then keeps row 0's current recon
     // as one more halo row, refreshed like any other, and forms the accumulator from it (TVDN_EDGE_WRAP).
-    bool exact_wrap = false;
-    if (world > 1 && !periodic) {
+    bool row0_bad = false;
+    if (!periodic) {
         if (a->dtype == TVDN_F32) {
             const float *p0 = (const float *)a->data;
-            for (size_t i = 0; i < plane && !exact_wrap; ++i) exact_wrap = !std::isfinite(p0[i]);
+            for (size_t i = 0; i < plane && !row0_bad; ++i) row0_bad = !std::isfinite(p0[i]);
         } else {
             const double *p0 = (const double *)a->data;
-            for (size_t i = 0; i < plane && !exact_wrap; ++i) exact_wrap = !std::isfinite(p0[i]);
+            for (size_t i = 0; i < plane && !row0_bad; ++i) row0_bad = !std::isfinite(p0[i]);
         }
     }
+    const bool exact_wrap = world > 1 && row0_bad;
     for (int r = 0; r < world; ++r) {
         Slab &s = sl[r];
         s.device = a->n_devices > 0 ? a->devices[r] : a->device;
@@ -119,8 +165,9 @@ static int run_impl(const tvdn_run_args *a)
         TVDN_HIP(hipSetDevice(s.device));
         int rc = tvdn_ctx_create(&s.ctx, s.device);
         if (rc) return rc;
-        TVDN_HIP(hipStreamCreateWithFlags(&s.main, hipStreamNonBlocking));
-        TVDN_HIP(hipStreamCreateWithFlags(&s.copy, hipStreamNonBlocking));
+        rc = make_stream(&s.main, +1);  // sweeps: a hardware queue no transfer shares (tvdn_common.hpp)
+        if (!rc) rc = make_stream(&s.copy, 0);
+        if (rc) return rc;
         TVDN_HIP(hipEventCreateWithFlags(&s.edge_done, hipEventDisableTiming));
         TVDN_HIP(hipEventCreateWithFlags(&s.halo_done, hipEventDisableTiming));
         // state: one allocation, 256-byte aligned arrays; everything but orig and recon[0] zeroed in one fill
@@ -146,6 +193,7 @@ static int run_impl(const tvdn_run_args *a)
                     (void)hipGetLastError();                            // without it the peer copy is staged, still correct
                 }
 
+    clk.mark("contexts, state allocated");
     // ---- upload: own rows + halo rows, straight from the caller's array ---------------------------------------
     auto rows_to_device = [&](Slab &s, char *dst, const void *src_cube) -> int {
         TVDN_HIP(hipSetDevice(s.device));
@@ -259,7 +307,132 @@ static int run_impl(const tvdn_run_args *a)
         }
     }
 
-    for (int r = 0; r < world; ++r) {
+    clk.mark("placement audition");
+    // ---- pipelined transfers (one device, resident) ------------------------------------------------------------------------
+    // The call takes host arrays and returns one (cyTVDN.py:19-31, :244-247): 2 x the cube over PCIe around the iterations --
+    // 0.17 s of the 0.75 s a 50-iteration run of BASELINE config 2 takes.  Both transfers hide under iterations that do
+    // not wait for the whole cube:
+    //   start  the cube goes up in chunks of R rows (a helper thread, the library's pinned multi-lane staging); when chunk c
+    //          has arrived, iteration level j advances rows [c R - (j+1), (c+1) R - (j+1)) for j = 0 .. k0-1: the wavefront
+    //          of tvdn_stream.hip (level j+1 trails level j by one row, every row of every level swept once), here as partial
+    //          sweeps on the RESIDENT arrays.  Two recon buffers and three rotating accumulator arrays per axis suffice because
+    //          level j+2, which writes what level j+1 reads, stays two rows behind it;
+    //   end    the last k1 iterations run the same way, and every chunk's finished rows go home (a second helper thread)
+    //          while the chunks after it are still being swept.
+    // The sweeps at the cube's top face take the Jia-Zhao zero (TVDN_EDGE_ZERO) because row 0 of the buffers belongs to a
+    // later level by then: Jia-Zhao runs with a finite first row only; no stopping rule, no MSE trace (both need whole
+    // iterations).  TVDN_PIPELINE=0 keeps the plain order, "R,k0,k1" forces a shape (tests).
+    int64_t pipe_R = 0;
+    int pipe_k0 = 0, pipe_k1 = 0;
+    if (world == 1 && a->bc_mode == TVDN_BC_JIA_ZHAO && !a->use_stop && !want_mse && !row0_bad) {
+        int32_t pl[3];
+        pipeline_plan(N0, n_total, (int64_t)N0 * (int64_t)row_bytes, pl);
+        pipe_R = pl[0];
+        pipe_k0 = pl[1];
+        pipe_k1 = pl[2];
+    }
+    const bool pipelined = pipe_R > 0;
+    struct LaneCap {  // fewer staging lanes while transfers run beside the launching thread (tvdn_hostio.hip)
+        bool on;
+        explicit LaneCap(bool o) : on(o) { if (on) io_cap_lanes(6); }
+        ~LaneCap() { if (on) io_cap_lanes(0); }
+    } lane_cap(pipelined);
+
+    // the schedule as one list: iteration i is a FISTA iteration with ratio_of[i], or an unaccelerated one
+    std::unique_ptr<double[]> ratios(new double[(size_t)(n_total > 0 ? n_total : 1)]);
+    fista_ratios(a->n_fista, ratios.get());  // float64 on the host, cyTVDN.py:153-156
+    for (int i = a->n_fista; i < n_total; ++i) ratios[i] = 0.0;
+    auto is_fista = [&](int i) { return i < a->n_fista; };
+    auto tick = [&](int slots_done) {  // the caller's progress bar (tvdn_run_args.progress)
+        if (a->progress) a->progress((int32_t)slots_done, a->progress_user);
+    };
+
+    // K = kk levels from iteration `first` on, over the whole cube, chunk by chunk
+    auto wavefront = [&](int first, int kk, const std::function<int(int64_t)> &before_chunk,
+                         const std::function<int(int64_t)> &after_chunk) -> int {
+        Slab &s = sl[0];
+        std::vector<tvdn_many_args> snap((size_t)kk);
+        tvdn_many_args m = s.roles;
+        for (int j = 0; j < kk; ++j) {
+            snap[(size_t)j] = m;
+            roles_advance(m, is_fista(first + j), ratios[first + j]);
+        }
+        const int64_t n_chunks = (N0 + kk + pipe_R - 1) / pipe_R;
+        for (int64_t c = 0; c < n_chunks; ++c) {
+            int rc = before_chunk ? before_chunk(c) : TVDN_OK;
+            if (rc) return rc;
+            for (int j = 0; j < kk; ++j) {
+                const int64_t lo = std::max<int64_t>(0, c * pipe_R - (j + 1)), hi = std::min<int64_t>(N0, (c + 1) * pipe_R - (j + 1));
+                if (lo >= hi) continue;
+                tvdn_iter_args it = snap[(size_t)j].base;
+                roles_bind(snap[(size_t)j], is_fista(first + j), ratios[first + j], it);
+                it.hi_mode = TVDN_EDGE_ZERO;
+                it.sweep_lo = lo;
+                it.sweep_hi = hi;
+                it.accumulate = 1;
+                rc = tvdn_iterate_fused(s.ctx, &it, (double *)s.sums.p + 3 * (size_t)(first + j), s.main);
+                if (rc) return rc;
+            }
+            rc = after_chunk ? after_chunk(c) : TVDN_OK;
+            if (rc) return rc;
+        }
+        const tvdn_iter_args keep = s.roles.base;
+        s.roles = m;
+        s.roles.base = keep;
+        return TVDN_OK;
+    };
+
+    if (pipelined) {
+        // ---- start: chunks go up on a helper thread; the first k0 iterations follow them ---------------------------------
+        Slab &s = sl[0];
+        TVDN_HIP(hipSetDevice(s.device));
+        TVDN_HIP(hipStreamSynchronize(s.main));  // the fills of the state are done before rows land beside them
+        const int64_t n_up = (N0 + pipe_R - 1) / pipe_R;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<char> arrived((size_t)n_up, 0);
+        int up_rc = TVDN_OK;
+        std::thread up([&] {
+            for (int64_t c = 0; c < n_up; ++c) {
+                const int64_t r0 = c * pipe_R, r1 = std::min((c + 1) * pipe_R, N0);
+                const auto w0 = std::chrono::steady_clock::now();
+                const int rc = tvdn_copy_to_device(s.orig + (size_t)r0 * row_bytes, (const char *)a->data + (size_t)r0 * row_bytes,
+                                                   (size_t)(r1 - r0) * row_bytes, s.device);
+                if (clk.on)
+                    fprintf(stderr, "tvdn_run:   rows %lld..%lld up in %.2f ms\n", (long long)r0, (long long)r1,
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
+                std::lock_guard<std::mutex> lk(mu);
+                if (rc) {
+                    up_rc = rc;
+                    std::fill(arrived.begin(), arrived.end(), 1);
+                } else {
+                    arrived[(size_t)c] = 1;
+                }
+                cv.notify_all();
+                if (rc) return;
+            }
+        });
+        struct Joiner {
+            std::thread &t;
+            ~Joiner() { if (t.joinable()) t.join(); }
+        } join_up{up};
+        int rc = wavefront(0, pipe_k0, [&](int64_t c) -> int {
+            if (c >= n_up) return TVDN_OK;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return arrived[(size_t)c] != 0; });
+                if (up_rc) return up_rc;
+            }
+            const int64_t r0 = c * pipe_R, r1 = std::min((c + 1) * pipe_R, N0);  // recon = datacube.copy() (cyTVDN.py:145)
+            TVDN_HIP(hipMemcpyAsync(s.recon(0) + (size_t)r0 * row_bytes, s.orig + (size_t)r0 * row_bytes, (size_t)(r1 - r0) * row_bytes,
+                                    hipMemcpyDeviceToDevice, s.main));
+            return TVDN_OK;
+        }, nullptr);
+        if (rc) return rc;
+        up.join();
+        clk.mark("upload + first iterations");
+    }
+    for (int r = 0; r < world && !pipelined; ++r) {
         Slab &s = sl[r];
         int rc = rows_to_device(s, s.orig, a->data);
         if (rc) return rc;
@@ -273,6 +446,7 @@ static int run_impl(const tvdn_run_args *a)
             TVDN_HIP(hipMemsetAsync(s.mse.p, 0, sizeof(double) * (size_t)(n_total + 1), s.main));
         }
     }
+    if (!pipelined) clk.mark("upload");
     // sum of squared errors over the own rows of every slab, into mse[slot]
     auto sse_all = [&](int cur, int slot) -> int {
         for (int r = 0; r < world; ++r) {
@@ -384,29 +558,122 @@ static int run_impl(const tvdn_run_args *a)
         return TVDN_OK;
     };
 
-    std::unique_ptr<double[]> ratios(new double[(size_t)(a->n_fista > 0 ? a->n_fista : 1)]);
-    fista_ratios(a->n_fista, ratios.get());  // float64 on the host, cyTVDN.py:153-156
-    for (int i = 0; i < a->n_fista; ++i) {
-        const double ratio = ratios[i];
-        int rc = one(i, true, ratio);
-        if (rc) return rc;
-        ++ran_phase[0];
-        bool st;
-        rc = stopped(i, st);
-        if (rc) return rc;
-        if (st) break;
-    }
-    for (int j = 0; j < a->n_plain; ++j) {
-        const int slot = j + a->n_fista;
-        int rc = one(slot, false, 0.0);
-        if (rc) return rc;
-        ++ran_phase[1];
-        bool st;
-        rc = stopped(slot, st);
-        if (rc) return rc;
-        if (st) break;
+    bool recon_home = false;
+    if (pipelined) {
+        // ---- middle: whole sweeps; end: the last k1 levels as a wavefront, finished rows go home chunk by chunk ----------
+        Slab &s = sl[0];
+        ran = pipe_k0;
+        if (pipe_k0 > 0) tick(pipe_k0);
+        for (int i = pipe_k0; i < n_total - pipe_k1; ++i) {
+            const int rc = one(i, is_fista(i), ratios[i]);
+            if (rc) return rc;
+            tick(i + 1);
+        }
+        clk.mark("middle iterations");
+        if (pipe_k1 > 0) {
+            struct Job {
+                hipEvent_t ev;
+                int64_t r0, r1;
+            };
+            std::mutex mu;
+            std::condition_variable cv;
+            std::deque<Job> jobs;
+            bool closed = false;
+            int down_rc = TVDN_OK;
+            const char *final_buf = s.recon(cur_of() ^ (pipe_k1 % 2));  // level j writes recon[cur ^ ((j + 1) % 2)]
+            std::thread down([&] {
+                for (;;) {
+                    Job job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return closed || !jobs.empty(); });
+                        if (jobs.empty()) return;
+                        job = jobs.front();
+                        jobs.pop_front();
+                    }
+                    const auto w0 = std::chrono::steady_clock::now();
+                    int rc = hipEventSynchronize(job.ev) == hipSuccess ? TVDN_OK : TVDN_ERR_HIP;  // the last level has written these rows
+                    const auto w1 = std::chrono::steady_clock::now();
+                    if (!rc)
+                        rc = tvdn_copy_to_host((char *)a->recon_out + (size_t)job.r0 * row_bytes, final_buf + (size_t)job.r0 * row_bytes,
+                                               (size_t)(job.r1 - job.r0) * row_bytes, s.device);
+                    if (clk.on)
+                        fprintf(stderr, "tvdn_run:   rows %lld..%lld waited %.2f ms, copied in %.2f ms\n", (long long)job.r0, (long long)job.r1,
+                                std::chrono::duration<double, std::milli>(w1 - w0).count(),
+                                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w1).count());
+                    (void)hipEventDestroy(job.ev);
+                    if (rc) {
+                        std::lock_guard<std::mutex> lk(mu);
+                        down_rc = rc;
+                    }
+                }
+            });
+            struct Closer {
+                std::thread &t;
+                std::mutex &mu;
+                std::condition_variable &cv;
+                bool &closed;
+                ~Closer()
+                {
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        closed = true;
+                    }
+                    cv.notify_all();
+                    if (t.joinable()) t.join();
+                }
+            };
+            int rc;
+            {
+                Closer closer{down, mu, cv, closed};
+                rc = wavefront(n_total - pipe_k1, pipe_k1, nullptr, [&](int64_t c) -> int {
+                    const int64_t r0 = std::max<int64_t>(0, c * pipe_R - pipe_k1), r1 = std::min<int64_t>(N0, (c + 1) * pipe_R - pipe_k1);
+                    if (r0 >= r1) return TVDN_OK;
+                    hipEvent_t ev;
+                    TVDN_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                    TVDN_HIP(hipEventRecord(ev, s.main));
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        jobs.push_back(Job{ev, r0, r1});
+                    }
+                    cv.notify_all();
+                    return TVDN_OK;
+                });
+            }  // every queued row is home (or failed) here
+            if (rc) return rc;
+            if (down_rc) return down_rc;
+            recon_home = true;
+            tick(n_total);
+            clk.mark("last iterations + download");
+        }
+        ran = n_total;
+        ran_phase[0] = a->n_fista;
+        ran_phase[1] = a->n_plain;
+    } else {
+        for (int i = 0; i < a->n_fista; ++i) {
+            int rc = one(i, true, ratios[i]);
+            if (rc) return rc;
+            ++ran_phase[0];
+            tick(i + 1);
+            bool st;
+            rc = stopped(i, st);
+            if (rc) return rc;
+            if (st) break;
+        }
+        for (int j = 0; j < a->n_plain; ++j) {
+            const int slot = j + a->n_fista;
+            int rc = one(slot, false, 0.0);
+            if (rc) return rc;
+            ++ran_phase[1];
+            tick(slot + 1);
+            bool st;
+            rc = stopped(slot, st);
+            if (rc) return rc;
+            if (st) break;
+        }
     }
 
+    if (!pipelined) clk.mark("iterations");
     // ---- results home ---------------------------------------------------------------------------------
     if (n_total > 0) std::memset(a->sums_out, 0, sizeof(double) * 3 * (size_t)n_total);
     if (want_mse) std::memset(a->mse_out, 0, sizeof(double) * (size_t)(n_total + 1));
@@ -416,8 +683,9 @@ static int run_impl(const tvdn_run_args *a)
         TVDN_HIP(hipSetDevice(s.device));
         TVDN_HIP(hipStreamSynchronize(s.main));
         TVDN_HIP(hipStreamSynchronize(s.copy));
-        int rc = tvdn_copy_to_host((char *)a->recon_out + (size_t)s.g0 * row_bytes, s.recon(cur_of()) + (size_t)s.row_lo() * row_bytes,
-                                   (size_t)(s.g1 - s.g0) * row_bytes, s.device);
+        int rc = recon_home ? TVDN_OK
+                            : tvdn_copy_to_host((char *)a->recon_out + (size_t)s.g0 * row_bytes, s.recon(cur_of()) + (size_t)s.row_lo() * row_bytes,
+                                                (size_t)(s.g1 - s.g0) * row_bytes, s.device);
         if (rc) return rc;
         if (n_total > 0) {
             TVDN_HIP(hipMemcpy(tmp.get(), s.sums.p, sizeof(double) * 3 * (size_t)n_total, hipMemcpyDeviceToHost));
@@ -433,6 +701,7 @@ static int run_impl(const tvdn_run_args *a)
         a->phase_iters[0] = ran_phase[0];
         a->phase_iters[1] = ran_phase[1];
     }
+    clk.mark("results home");
     return TVDN_OK;
 }
 
@@ -468,6 +737,14 @@ extern "C" int tvdn_plan(int dtype, int ndim, const int64_t *shape, int fista, i
             out->min_slabs = (int32_t)s;
             break;
         }
+    return TVDN_OK;
+}
+
+extern "C" int tvdn_pipeline_plan(int64_t n0, int32_t n_iters, int64_t cube_bytes, int32_t *out)
+{
+    TVDN_REQUIRE(out != nullptr, "NULL argument");
+    TVDN_REQUIRE(n0 >= 1 && n_iters >= 0 && cube_bytes >= 0, "bad argument");
+    tvdn::pipeline_plan(n0, n_iters, cube_bytes, out);
     return TVDN_OK;
 }
 
@@ -532,5 +809,8 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
             return TVDN_ERR_UNSUPPORTED;
         }
     }
-    return tvdn::run_impl(a);
+    tvdn::RunClock clk;
+    const int rc = tvdn::run_impl(a, clk);
+    clk.mark("release");
+    return rc;
 }

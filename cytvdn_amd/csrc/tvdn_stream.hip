@@ -373,9 +373,9 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
     rc = tvdn_ctx_create(&ctx.c, device);
     if (rc) return rc;
     Streams st;
-    TVDN_HIP(hipStreamCreateWithFlags(&st.main, hipStreamNonBlocking));
-    TVDN_HIP(hipStreamCreateWithFlags(&st.up, hipStreamNonBlocking));
-    TVDN_HIP(hipStreamCreateWithFlags(&st.down, hipStreamNonBlocking));
+    if ((rc = make_stream(&st.main, +1))) return rc;  // three queue classes: no false ordering between sweeps, uploads and
+    if ((rc = make_stream(&st.up, 0))) return rc;     // downloads whatever other streams the process holds (tvdn_common.hpp)
+    if ((rc = make_stream(&st.down, -1))) return rc;
     const size_t dev_bytes = dev_bytes_max - (exact_wrap ? 0 : (size_t)(K + 1) * plane_b);
     DevMem mem, sums_d, mse_d;
     TVDN_HIP(hipMalloc(&mem.p, dev_bytes));
@@ -647,6 +647,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
             if ((rc = pass(ratios.data() + i, kk))) return rc;
             ran += kk;
             i += kk;
+            if (a->progress) a->progress((int32_t)i, a->progress_user);
         }
     } else {
         // one level per pass; phases as upstream runs them (cyTVDN.py:148-242): an early stop ends the FISTA phase, the
@@ -659,6 +660,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
                 if ((rc = pass(ratios.data() + i, 1))) return rc;
                 ++ran;
                 ++ran_phase[phase];
+                if (a->progress) a->progress((int32_t)(i + 1), a->progress_user);
                 bool stop;
                 if ((rc = stop_after(i, stop))) return rc;
                 if (stop) break;

@@ -24,7 +24,7 @@ from typing import Optional, Tuple
 import numpy as np
 import torch
 
-from .engine import HipBackend, SlabLayout, SlabRunner, hbm_plan
+from .engine import DEFAULT_STATE, HipBackend, SlabLayout, SlabRunner, hbm_plan
 from .planner import check_host_fits, plan_run
 
 try:  # tqdm is what upstream shows (cyTVDN.py:148-152); it is optional here
@@ -70,6 +70,35 @@ def _audition_candidates(n_total: int) -> int:
     if e is not None:
         return max(1, int(e))
     return 4 if n_total >= 800 else (3 if n_total >= 400 else 1)
+
+
+class _ProgressBars:
+    """Upstream's two tqdm bars (cyTVDN.py:148-151, :196-199) fed from tvdn_run's progress callback, which reports the
+    number of the last iteration slot handed to the GPU (the unaccelerated phase counts on from n_fista)."""
+
+    def __init__(self, n_fista, n_plain, quiet):
+        self.active = _tqdm is not None and not quiet
+        self.n_fista, self.n_plain = n_fista, n_plain
+        self.bars = [None, None]
+        self.seen = [0, 0]
+
+    def update(self, slots_done):
+        phase = 0 if slots_done <= self.n_fista and self.n_fista and not self.bars[1] else 1
+        if phase == 1 and self.bars[0] is not None:
+            self.bars[0].close()
+            self.bars[0] = None
+        if self.bars[phase] is None:
+            self.bars[phase] = _tqdm(total=self.n_fista if phase == 0 else self.n_plain,
+                                     desc="FISTA Accelerated TV Denoising" if phase == 0 else "Unaccelerated TV Denoising")
+        done = slots_done - (self.n_fista if phase else 0)
+        self.bars[phase].update(done - self.seen[phase])
+        self.seen[phase] = done
+
+    def close(self):
+        for b in self.bars:
+            if b is not None:
+                b.close()
+        self.bars = [None, None]
 
 
 def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, reference_data, BC_mode, quiet,
@@ -142,28 +171,25 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
             k = 1      # the stopping test is per iteration (cyTVDN.py:189-194): no temporal blocking then
         return _run_staged((max(1, rows), max(1, k)), datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista,
                            n_plain, stop, reference_data, BC_mode, quiet, device, out, exact_wrap)
+    if isinstance(datacube, np.ndarray) and out is None and DEFAULT_STATE == "compact" \
+            and os.environ.get("TVDN_LOOP", "run") == "run":
+        # A NumPy cube that fits: the whole call behind the library's entry point (tvdn_run, csrc/tvdn_run.hip) -- state
+        # allocation and placement audition, the loop, stopping rule and MSE trace, and for long-enough Jia-Zhao runs
+        # the first iterations under the upload and the last ones over the download.  The progress bars are fed from
+        # the library's callback.  TVDN_LOOP=native|python keeps the loop here (engine.SlabRunner; measurement, tests).
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()       # the library allocates with hipMalloc: hand it what torch's cache holds
+        bars = _ProgressBars(n_fista, n_plain, quiet)
+        try:
+            return _run_device_list([int(device)], datacube, lambdaInv, lam_mu, n_fista, n_plain, stop, reference_data,
+                                    BC_mode, quiet, progress=bars.update if bars.active else None, announce=False)
+        finally:
+            bars.close()
     layout = SlabLayout(tuple(datacube.shape), 0, 1, int(BC_mode))
     be = HipBackend.best_of(_audition_candidates(n_total), layout, dtype, FISTA, device=device,
                             max_iters=n_total)                                # raises without a GPU
     be.set_params(lambdaInv, lam_mu)
     runner = SlabRunner(be)
-    # A NumPy cube, nothing watching the iterations, Jia-Zhao boundaries, a finite first row: the first iterations run
-    # under the upload and the last ones over the download (cytvdn_amd/pipelined.py); TVDN_PIPELINE=0 keeps the plain order
-    pipe = None
-    if isinstance(datacube, np.ndarray) and out is None and reference_data is None and stopping_relative_change is None \
-            and (quiet or _tqdm is None) and int(BC_mode) == 2 and not exact_wrap and be.state == "compact" \
-            and os.environ.get("TVDN_PIPELINE", "1") != "0":
-        from . import pipelined
-        pipe = pipelined.plan(datacube.shape[0], n_total, datacube.nbytes)
-        if os.environ.get("TVDN_PIPELINE", "1") not in ("0", "1"):        # "rows,k_start,k_end": forced (tests)
-            pipe = tuple(int(v) for v in os.environ["TVDN_PIPELINE"].split(","))
-    if pipe is not None:
-        recon = pipelined.run(be, runner, datacube, n_fista if FISTA else 0, n_plain if unaccelerated else 0, *pipe)
-        sums = be.sums.cpu().numpy()[:n_total]
-        b_norm = sums[:, 0].astype(dtype)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            delta_recon = (sums[:, 1].astype(dtype) / sums[:, 2].astype(dtype)).astype(dtype)
-        return recon, b_norm, delta_recon
     be.set_input(datacube)
 
     calculate_MSE = reference_data is not None
@@ -231,7 +257,7 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
 
 
 def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, stop, reference_data, BC_mode, quiet,
-                     stream=None):
+                     stream=None, progress=None, announce=True):
     """`device=[0, 1, ...]`: one slab of axis 0 per listed GPU inside THIS process -- the library's whole-loop entry
     (tvdn_run, csrc/tvdn_run.hip): state in HBM of each device, halo rows by peer copies over xGMI under the interior
     sweeps, global sums, global stopping rule.  No torchrun, no RCCL; every slab must fit its device (tvdn_plan says so
@@ -243,7 +269,7 @@ def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, sto
     dtype = datacube.dtype
     nd = datacube.ndim
     n = n_fista + n_plain
-    if not quiet and stream is None:
+    if not quiet and stream is None and announce:
         print(f"Cutting axis 0 into {len(devices)} slabs on devices {devices} (one process, peer copies)", flush=True)
     a = _lib.RunArgs(dtype=_lib.dtype_code(dtype), ndim=nd, bc_mode=int(BC_mode), device=devices[0], n_fista=n_fista,
                      n_plain=n_plain, use_stop=int(stop is not None), stop=float(stop or 0.0),
@@ -271,6 +297,9 @@ def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, sto
         ref = np.ascontiguousarray(reference_data)
         a.reference, a.mse_out = ref.ctypes.data, mse.ctypes.data
     a.iters_run = C.addressof(ran)
+    if progress is not None:
+        hook = C.CFUNCTYPE(None, C.c_int32, C.c_void_p)(lambda slots_done, _user: progress(int(slots_done)))
+        a.progress = C.cast(hook, C.c_void_p)
     _lib.check(_lib.lib().tvdn_run(C.byref(a)))
     sums = sums[:n]
     # which slots ran, from the library's own per-phase counts (not guessed from the values: an all-zero cube has zero

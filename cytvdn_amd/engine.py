@@ -662,14 +662,13 @@ class SlabRunner:
             self.be.step(tk_ratio, slot)
             self.exchange_halos()
 
-    def run(self, n_fista: int, n_plain: int, on_iter=None, first_fista: int = 0):
+    def run(self, n_fista: int, n_plain: int, on_iter=None):
         """n_fista FISTA iterations then n_plain unaccelerated ones (hybrid mode of the reference,
-        cyTVDN.py:99-108).  `on_iter(slot)` may return True to stop the current phase early.  `first_fista`: the FISTA
-        iterations are numbers first_fista .. of the schedule (a run continued after cytvdn_amd.pipelined's start)."""
+        cyTVDN.py:99-108).  `on_iter(slot)` may return True to stop the current phase early."""
         slot = self.iter
-        ratios = fista_ratios(first_fista + n_fista)[first_fista:]
+        ratios = fista_ratios(n_fista)
         if on_iter is None and self.layout.world == 1 and getattr(self.be, "state", None) == "compact" \
-                and hasattr(self.be, "run_many") and os.environ.get("TVDN_LOOP", "native") == "native":
+                and hasattr(self.be, "run_many") and os.environ.get("TVDN_LOOP", "run") != "python":
             # nobody watches the iterations: the whole schedule behind one library call
             if n_fista + n_plain:
                 self.be.run_many(ratios, n_plain, slot)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TVDN_ABI_VERSION 4
+#define TVDN_ABI_VERSION 5
 
 typedef enum tvdn_dtype { TVDN_F32 = 0, TVDN_F64 = 1 } tvdn_dtype;
 
@@ -274,9 +274,26 @@ typedef struct tvdn_run_args {
      * use_stop either may end early; the unaccelerated phase writes its sums from slot n_fista on regardless,
      * cyTVDN.py:201).  What tells a caller which sums_out rows are real without guessing from their values. */
     int32_t *phase_iters;
+    /* ABI 5.  Optional: called on the CALLING thread as the run advances, with the number of the last iteration slot
+     * handed to the GPU so far (1 .. n_fista + n_plain; the unaccelerated phase counts on from n_fista even when the
+     * FISTA phase stopped early) -- what upstream's progress bars show (tqdm, cyTVDN.py:150 / :203).  Launches are
+     * asynchronous: without a stopping rule the count runs ahead of the GPU by the depth of its queue.  A resident run
+     * whose first iterations follow the upload reports them together once the last chunk has been swept, a streamed run
+     * reports a pass at a time.  Must not call back into the library. */
+    void (*progress)(int32_t slots_done, void *user);
+    void *progress_user;
 } tvdn_run_args;
 
 int tvdn_run(const tvdn_run_args *args);
+
+/* How a RESIDENT one-device tvdn_run overlaps its two transfers with iterations (what upstream does one after the other:
+ * datacube in, cyTVDN.py:145; recon out, :244-247): out[0] = rows per chunk, out[1] = iterations that follow the upload
+ * chunk by chunk, out[2] = iterations that run over the download; all 0 = plain order (upload, iterate, download).  Pure
+ * host arithmetic, the very function tvdn_run asks: cubes from 256 MiB and 32 rows on, runs from 4 iterations on, eight
+ * chunks, at most 8 iterations at either end.  tvdn_run applies it to Jia-Zhao runs without stopping rule or MSE trace
+ * whose first row is finite; the result is bit-identical to the plain order either way.  Environment: TVDN_PIPELINE=0
+ * (never), "rows,k_start,k_end" (forced). */
+int tvdn_pipeline_plan(int64_t n0, int32_t n_iters, int64_t cube_bytes, int32_t *out);
 
 /* Host side of a STREAMED tvdn_run as arithmetic only -- no HIP call, no device needed, none of the caller's arrays
  * dereferenced: *need_bytes = the page-locked host memory the run would hold (data term, recon = recon_out, the

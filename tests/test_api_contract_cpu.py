@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/tvdn.h but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert _lib.lib().tvdn_abi_version() == 4
+    assert _lib.lib().tvdn_abi_version() == 5
 
 
 def test_iter_args_struct_matches_header_layout():
@@ -166,7 +166,7 @@ def test_struct_layouts_match_the_c_header(tmp_path):
                    '  P(tvdn_iter_args, orig_ring_rows); P(tvdn_iter_args, accumulate);\n'
                    '  printf("tvdn_many_args %zu\\n", sizeof(tvdn_many_args)); P(tvdn_many_args, recon); P(tvdn_many_args, S); P(tvdn_many_args, tk_prev);\n'
                    '  printf("tvdn_run_args %zu\\n", sizeof(tvdn_run_args)); P(tvdn_run_args, stop); P(tvdn_run_args, data); P(tvdn_run_args, devices);\n'
-                   '  P(tvdn_run_args, stream_rows); P(tvdn_run_args, stream_k); P(tvdn_run_args, phase_iters); P(tvdn_run_args, n_devices);\n'
+                   '  P(tvdn_run_args, stream_rows); P(tvdn_run_args, stream_k); P(tvdn_run_args, phase_iters); P(tvdn_run_args, progress_user); P(tvdn_run_args, n_devices);\n'
                    '  printf("tvdn_plan_out %zu\\n", sizeof(tvdn_plan_out)); P(tvdn_plan_out, fits); P(tvdn_plan_out, min_slabs);\n'
                    '  return 0; }\n')
     exe = tmp_path / "layout"

@@ -1,8 +1,8 @@
-"""cytvdn_amd/pipelined.py: an in-core denoise3D/4D from NumPy whose first iterations run under the upload and whose last
-ones run over the download (a wavefront of partial sweeps on the resident arrays) gives the bits of the plain loop, i.e.
-the oracle's (reference loop: cyTVDN/cyTVDN.py:148-242) -- recon and the b_norm / delta_recon traces -- for every chunk
-height and depth, FISTA / unaccelerated / hybrid schedules (a transition inside the start or the end wavefront), f32 /
-f64, 3-D / 4-D, scalar packs."""
+"""tvdn_run's pipelined transfers (csrc/tvdn_run.hip): a resident denoise3D/4D from NumPy whose first iterations run under
+the upload and whose last ones run over the download (a wavefront of partial sweeps on the resident arrays) gives the bits
+of the plain loop, i.e. the oracle's (reference loop: cyTVDN/cyTVDN.py:148-242) -- recon and the b_norm / delta_recon
+traces -- for every chunk height and depth, FISTA / unaccelerated / hybrid schedules (a transition inside the start or the
+end wavefront), f32 / f64, 3-D / 4-D, scalar packs; through the Python API and through the C entry point directly."""
 import numpy as np
 import pytest
 
@@ -48,13 +48,83 @@ def test_pipelined_run_matches_the_oracle(oracle, monkeypatch, shape, dtype, its
     np.testing.assert_allclose(bn.astype(np.float64), plain[1].astype(np.float64), rtol=1e-6 if dt == np.float32 else 1e-12)
 
 
-def test_the_plan_switches_itself_on_for_large_cubes_only():
-    from cytvdn_amd import pipelined
-    assert pipelined.plan(256, 50, 4 << 30) == (32, 8, 8)
-    assert pipelined.plan(256, 6, 4 << 30) == (32, 3, 3)
-    assert pipelined.plan(256, 3, 4 << 30) is None            # too few iterations to hide anything under
-    assert pipelined.plan(16, 50, 4 << 30) is None
-    assert pipelined.plan(256, 50, 64 << 20) is None          # small cubes: two transfers of milliseconds
+@pytest.mark.parametrize("shape,dtype,n_f,n_p,pipe", [
+    ((40, 4, 8, 16), np.float32, 12, 0, "8,4,4"),
+    ((23, 6, 16), np.float64, 2, 7, "4,4,3"),
+    ((19, 3, 5, 7), np.float32, 0, 9, "3,2,5"),
+    ((33, 3, 4, 8), np.float32, 7, 0, "1,3,2"),
+    ((16, 3, 4, 8), np.float32, 5, 0, "4,0,5"),            # no start wavefront: whole-cube upload
+    ((16, 3, 4, 8), np.float32, 6, 0, "4,9,9"),            # more levels asked for than iterations
+])
+def test_tvdn_run_pipelined_against_the_oracle_directly(oracle, monkeypatch, shape, dtype, n_f, n_p, pipe):
+    """The C entry point itself (no Python driver in between), sums against the oracle's f64 yardsticks."""
+    from test_gpu_run_streamed import _check_traces, _oracle, _run
+    from cytvdn_amd import synth
+    dt = np.dtype(dtype)
+    x = synth.cube(shape, seed=31, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:len(shape)], dt)
+    ref = _oracle(oracle, x, mu, n_f, n_p)
+    monkeypatch.setenv("TVDN_PIPELINE", pipe)
+    recon, sums, _, ran = _run(x, mu, n_f, n_p)
+    assert ran == n_f + n_p and bits_equal(recon, ref["recon"])
+    _check_traces(sums, ref, n_f + n_p)
+    recon2 = x.copy()                                          # in place: data and recon_out the same array
+    got = _run_in_place(recon2, mu, n_f, n_p)
+    assert bits_equal(got, ref["recon"])
+
+
+def _run_in_place(x, mu, n_f, n_p):
+    import ctypes as C
+    from cytvdn_amd import _lib
+    dt, nd = x.dtype, x.ndim
+    lam = mu / dt.type(32.0 if nd == 4 else 16.0)
+    a = _lib.RunArgs(dtype=_lib.dtype_code(dt), ndim=nd, bc_mode=2, device=0, n_fista=n_f, n_plain=n_p)
+    for i, s in enumerate(x.shape):
+        a.shape[i] = s
+    for q in range(nd):
+        a.clip[q] = float((1.0 / lam)[q])
+        a.lambda_mu[q] = float((lam / mu).astype(dt)[q])
+    sums = np.zeros((n_f + n_p, 3))
+    a.data = a.recon_out = x.ctypes.data
+    a.sums_out = sums.ctypes.data
+    _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+    return x
+
+
+def test_progress_callback_counts_every_slot(monkeypatch):
+    """tvdn_run_args.progress: monotone slot counts ending at n_fista + n_plain, plain order and pipelined; the
+    unaccelerated phase counts on from n_fista after an early FISTA stop."""
+    import ctypes as C
+    from cytvdn_amd import _lib, synth
+    dt = np.dtype(np.float32)
+    x = synth.cube((24, 3, 4, 8), seed=3, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6], dt)
+    lam = mu / dt.type(32.0)
+
+    def run(n_f, n_p, stop=None):
+        seen = []
+        hook = C.CFUNCTYPE(None, C.c_int32, C.c_void_p)(lambda n, _u: seen.append(int(n)))
+        a = _lib.RunArgs(dtype=0, ndim=4, bc_mode=2, device=0, n_fista=n_f, n_plain=n_p, use_stop=int(stop is not None),
+                         stop=float(stop or 0.0))
+        for i, s in enumerate(x.shape):
+            a.shape[i] = s
+        for q in range(4):
+            a.clip[q] = float((1.0 / lam)[q])
+            a.lambda_mu[q] = float((lam / mu).astype(dt)[q])
+        recon = np.empty_like(x)
+        sums = np.zeros((n_f + n_p, 3))
+        a.data, a.recon_out, a.sums_out = x.ctypes.data, recon.ctypes.data, sums.ctypes.data
+        a.progress = C.cast(hook, C.c_void_p)
+        _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+        return seen
+
+    monkeypatch.setenv("TVDN_PIPELINE", "0")
+    assert run(5, 3) == list(range(1, 9))
+    monkeypatch.setenv("TVDN_PIPELINE", "4,3,2")
+    assert run(5, 3) == [3, 4, 5, 6, 8]
+    monkeypatch.setenv("TVDN_PIPELINE", "0")
+    seen = run(6, 4, stop=1e30)                                # both phases stop after their first iteration
+    assert seen == [1, 7]
 
 
 def test_a_nonfinite_first_row_takes_the_plain_order(oracle, monkeypatch):

@@ -170,3 +170,21 @@ def test_role_rotation_against_an_independent_model(nd, n_fista, n_plain):
     assert m.cur == (n_fista + n_plain) % 2 and bool(m.d_form) == (n_plain == 0 and n_fista > 0)
     if n_plain:
         assert L.tvdn_roles_bind(C.byref(m), 1, 0.5, C.byref(it)) == -1      # FISTA after unaccelerated: refused
+
+
+def test_the_pipelining_plan_switches_itself_on_for_large_cubes_only(monkeypatch):
+    """tvdn_pipeline_plan (csrc/tvdn_run.hip): the shape tvdn_run gives a resident run's overlapped transfers."""
+    from cytvdn_amd import _lib
+    monkeypatch.delenv("TVDN_PIPELINE", raising=False)
+    assert _lib.pipeline_plan(256, 50, 4 << 30) == (32, 8, 8)
+    assert _lib.pipeline_plan(256, 6, 4 << 30) == (32, 3, 3)
+    assert _lib.pipeline_plan(256, 3, 4 << 30) is None          # too few iterations to hide anything under
+    assert _lib.pipeline_plan(16, 50, 4 << 30) is None
+    assert _lib.pipeline_plan(256, 50, 64 << 20) is None        # small cubes: two transfers of milliseconds
+    assert _lib.pipeline_plan(40, 50, 4 << 30) == (8, 8, 8)     # never chunks under eight rows
+    monkeypatch.setenv("TVDN_PIPELINE", "0")
+    assert _lib.pipeline_plan(256, 50, 4 << 30) is None
+    monkeypatch.setenv("TVDN_PIPELINE", "5,6,6")
+    assert _lib.pipeline_plan(40, 9, 1 << 20) == (5, 6, 3)      # forced: clipped to the iterations there are
+    monkeypatch.setenv("TVDN_PIPELINE", "1")
+    assert _lib.pipeline_plan(256, 50, 4 << 30) == (32, 8, 8)
