@@ -196,8 +196,13 @@ class WavefrontRunner:
         self.down_kernel = os.environ.get("TVDN_WF_DOWN", "dma") == "kernel"
         self.io_blocks = int(os.environ.get("TVDN_WF_IO_BLOCKS", "16"))
         n_io = max(1, int(os.environ.get("TVDN_IO_STREAMS", str(IO_STREAMS))))
+        # Upload and download streams come from DIFFERENT priority pools: the runtime multiplexes streams onto a few
+        # hardware queues per priority level, and two streams that land on the same one execute in submission order
+        # (csrc/tvdn_common.hpp make_stream; tvdn_run's pipelined download waited behind every queued sweep that way).
+        # The sweeps run on the default stream, which has a queue of its own.  TVDN_WF_DOWN_PRIO=0: one pool (measurement).
+        down_prio = int(os.environ.get("TVDN_WF_DOWN_PRIO", "-1"))
         self.ups = [torch.cuda.Stream(device=dev) for _ in range(n_io)]
-        self.downs = [torch.cuda.Stream(device=dev) for _ in range(n_io)]
+        self.downs = [torch.cuda.Stream(device=dev, priority=down_prio) for _ in range(n_io)]
         self._args = _lib.IterArgs()
         # Jia-Zhao, `exact_wrap` (single process): the sweeps at the cube's top face form the wrapped axis-0 accumulator
         # from the recon of global row 0 AT THEIR OWN LEVEL (TVDN_EDGE_WRAP) instead of taking it as zero, which it is
