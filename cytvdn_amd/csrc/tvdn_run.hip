@@ -30,6 +30,17 @@ struct DevBuf {
     }
 };
 
+// The state's allocation.  TVDN_MALLOC=contiguous | uncached | finegrained asks the runtime for another kind of device memory
+// (measurement: does a physically contiguous state take the placement lottery out of the sweep's speed?  DESIGN.md section 3).
+static hipError_t state_malloc(void **p, size_t bytes)
+{
+    const char *e = getenv("TVDN_MALLOC");
+    if (e && !strcmp(e, "contiguous")) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous);
+    if (e && !strcmp(e, "uncached")) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached);
+    if (e && !strcmp(e, "finegrained")) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
+    return hipMalloc(p, bytes);
+}
+
 template <typename T>
 static T delta_in_dtype(const double s[3])
 {
@@ -175,7 +186,7 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
         const size_t stride = (bytes + 255) / 256 * 256 + 4096;  // staggered by 4 KiB, as engine.ARRAY_SKEW
         const int n_arr = 3 + nd * per_axis;
         s.state.device = s.device;
-        TVDN_HIP(hipMalloc(&s.state.p, stride * (size_t)n_arr));
+        TVDN_HIP(state_malloc(&s.state.p, stride * (size_t)n_arr));
         TVDN_HIP(hipMemsetAsync(s.state.p, 0, stride * (size_t)(n_arr - 2), s.main));
         std::memset(&s.roles, 0, sizeof s.roles);
         roles_reset(s.roles, fista);
@@ -273,18 +284,20 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
             TVDN_HIP(hipEventCreate(&e0));
             TVDN_HIP(hipEventCreate(&e1));
             int rc = probe(s.state.p, &best_ms);
+            if (clk.on) fprintf(stderr, "tvdn_run:   candidate 0 at %p: %.3f ms per sweep\n", s.state.p, best_ms / 2.0);
             for (int c = 1; c < want && !rc; ++c) {
                 size_t free_b = 0, total_b = 0;
                 TVDN_HIP(hipMemGetInfo(&free_b, &total_b));
                 if ((double)total > 0.8 * (double)free_b) break;
                 std::unique_ptr<DevBuf> b(new DevBuf);
                 b->device = s.device;
-                if (hipMalloc(&b->p, total) != hipSuccess) {
+                if (state_malloc(&b->p, total) != hipSuccess) {
                     (void)hipGetLastError();
                     break;
                 }
                 double ms = 0.0;
                 rc = probe(b->p, &ms);
+                if (clk.on) fprintf(stderr, "tvdn_run:   candidate %d at %p: %.3f ms per sweep\n", c, b->p, ms / 2.0);
                 if (!rc && ms < best_ms) {
                     best_ms = ms;
                     best = b->p;

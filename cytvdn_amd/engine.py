@@ -172,7 +172,9 @@ class HipBackend:
     supports_partial_sweeps = True
 
     def __init__(self, layout: SlabLayout, dtype, fista: bool, device: int = 0, max_iters: int = 1,
-                 state: str = None, private_ctx: bool = False):
+                 state: str = None, private_ctx: bool = False, slab=None):
+        """`slab` (measurement, tools/layout_probe.py): a 1-D device tensor of the data dtype to carve the arrays from
+        instead of a fresh allocation -- several layouts of the state timed on the very same pages."""
         state = DEFAULT_STATE if state is None else state
         if state not in ("compact", "reference"):
             raise ValueError("state must be 'compact' or 'reference'")
@@ -221,7 +223,12 @@ class HipBackend:
                 off = (i * skew) // item
                 return t[off:off + n_el].view(ls)
         else:
-            self._slab = torch.empty(n_arr * stride_el, dtype=tdt, device=dev)
+            if slab is not None:
+                if slab.dtype != tdt or slab.numel() < n_arr * stride_el:
+                    raise ValueError(f"slab must hold {n_arr * stride_el} elements of {tdt}")
+                self._slab = slab[:n_arr * stride_el]
+            else:
+                self._slab = torch.empty(n_arr * stride_el, dtype=tdt, device=dev)
             self._slab[:(n_arr - 2) * stride_el].zero_()
 
             def arr():
