@@ -28,7 +28,7 @@ EXPORTS = (
     "tvdn_abi_version", "tvdn_last_error", "tvdn_device_count", "tvdn_ctx_create", "tvdn_ctx_destroy",
     "tvdn_ctx_timing_enable", "tvdn_ctx_timing_read", "tvdn_ctx_timing_read_each",
     "tvdn_accumulator_update", "tvdn_datacube_update", "tvdn_sum_square_error", "tvdn_iterate_fused",
-    "tvdn_synth_fill", "tvdn_run", "tvdn_pipeline_plan", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many", "tvdn_plan", "tvdn_copy_many", "tvdn_stream_mix", "tvdn_stream_mix_march",
+    "tvdn_synth_fill", "tvdn_run", "tvdn_pipeline_plan", "tvdn_run_workspace_bytes", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many", "tvdn_plan", "tvdn_copy_many", "tvdn_stream_mix", "tvdn_stream_mix_march",
     "tvdn_stream_host_need", "tvdn_fista_ratios", "tvdn_iter_mode", "tvdn_roles_bind", "tvdn_roles_advance",
 )
 
@@ -82,6 +82,8 @@ class RunArgs(C.Structure):
         ("phase_iters", C.c_void_p),
         ("progress", C.c_void_p),
         ("progress_user", C.c_void_p),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -139,6 +141,7 @@ def lib():
     L.tvdn_iter_mode.argtypes = [C.c_int32, C.c_int32]
     L.tvdn_roles_bind.argtypes = [C.POINTER(ManyArgs), C.c_int32, C.c_double, C.POINTER(IterArgs)]
     L.tvdn_roles_advance.argtypes = [C.POINTER(ManyArgs), C.c_int32, C.c_double]
+    L.tvdn_run_workspace_bytes.argtypes = [C.POINTER(RunArgs), C.POINTER(C.c_int64)]
     L.tvdn_pipeline_plan.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.POINTER(C.c_int32)]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header and library out of step

@@ -11,6 +11,7 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -21,9 +22,10 @@ namespace tvdn {
 struct DevBuf {
     void *p = nullptr;
     int device = 0;
+    bool owned = true;  // false: the caller's workspace
     ~DevBuf()
     {
-        if (p) {
+        if (p && owned) {
             (void)hipSetDevice(device);
             (void)hipFree(p);
         }
@@ -186,7 +188,15 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
         const size_t stride = (bytes + 255) / 256 * 256 + 4096;  // staggered by 4 KiB, as engine.ARRAY_SKEW
         const int n_arr = 3 + nd * per_axis;
         s.state.device = s.device;
-        TVDN_HIP(state_malloc(&s.state.p, stride * (size_t)n_arr));
+        if (a->workspace && world == 1) {  // the caller's device memory (tvdn_run_args.workspace): nothing allocated, nothing freed
+            TVDN_REQUIRE(((uintptr_t)a->workspace & 255) == 0, "workspace must be 256-byte aligned");
+            TVDN_REQUIRE(a->workspace_bytes >= (int64_t)(stride * (size_t)n_arr), "workspace of %lld bytes, the state needs %lld (tvdn_run_workspace_bytes)",
+                         (long long)a->workspace_bytes, (long long)(stride * (size_t)n_arr));
+            s.state.p = a->workspace;
+            s.state.owned = false;
+        } else {
+            TVDN_HIP(state_malloc(&s.state.p, stride * (size_t)n_arr));
+        }
         TVDN_HIP(hipMemsetAsync(s.state.p, 0, stride * (size_t)(n_arr - 2), s.main));
         std::memset(&s.roles, 0, sizeof s.roles);
         roles_reset(s.roles, fista);
@@ -250,7 +260,8 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
     if (world == 1) {
         Slab &s = sl[0];
         const char *e = getenv("TVDN_AUDITION");
-        const int want = e ? atoi(e) : (n_total >= 800 ? 4 : (n_total >= 400 ? 3 : 1));
+        // a caller that brings the state's memory has chosen its placement: no audition then
+        const int want = !s.state.owned ? 1 : (e ? atoi(e) : (n_total >= 800 ? 4 : (n_total >= 400 ? 3 : 1)));
         const size_t bytes = (size_t)s.rows() * row_bytes;
         const size_t stride = (bytes + 255) / 256 * 256 + 4096;
         const size_t total = stride * (size_t)(3 + nd * per_axis);
@@ -405,6 +416,7 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
         std::condition_variable cv;
         std::vector<char> arrived((size_t)n_up, 0);
         int up_rc = TVDN_OK;
+        std::string up_msg;  // the last-error text is per thread: a helper's failure is handed to the calling thread
         std::thread up([&] {
             for (int64_t c = 0; c < n_up; ++c) {
                 const int64_t r0 = c * pipe_R, r1 = std::min((c + 1) * pipe_R, N0);
@@ -417,6 +429,7 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
                 std::lock_guard<std::mutex> lk(mu);
                 if (rc) {
                     up_rc = rc;
+                    up_msg = tvdn_last_error();
                     std::fill(arrived.begin(), arrived.end(), 1);
                 } else {
                     arrived[(size_t)c] = 1;
@@ -434,7 +447,10 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return arrived[(size_t)c] != 0; });
-                if (up_rc) return up_rc;
+                if (up_rc) {
+                    set_error("%s", up_msg.c_str());
+                    return up_rc;
+                }
             }
             const int64_t r0 = c * pipe_R, r1 = std::min((c + 1) * pipe_R, N0);  // recon = datacube.copy() (cyTVDN.py:145)
             TVDN_HIP(hipMemcpyAsync(s.recon(0) + (size_t)r0 * row_bytes, s.orig + (size_t)r0 * row_bytes, (size_t)(r1 - r0) * row_bytes,
@@ -593,6 +609,7 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
             std::deque<Job> jobs;
             bool closed = false;
             int down_rc = TVDN_OK;
+            std::string down_msg;
             const char *final_buf = s.recon(cur_of() ^ (pipe_k1 % 2));  // level j writes recon[cur ^ ((j + 1) % 2)]
             std::thread down([&] {
                 for (;;) {
@@ -617,6 +634,7 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
                     (void)hipEventDestroy(job.ev);
                     if (rc) {
                         std::lock_guard<std::mutex> lk(mu);
+                        if (!down_rc) down_msg = rc == TVDN_ERR_HIP && !*tvdn_last_error() ? "hipEventSynchronize failed" : tvdn_last_error();
                         down_rc = rc;
                     }
                 }
@@ -654,7 +672,10 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
                 });
             }  // every queued row is home (or failed) here
             if (rc) return rc;
-            if (down_rc) return down_rc;
+            if (down_rc) {
+                set_error("%s", down_msg.c_str());
+                return down_rc;
+            }
             recon_home = true;
             tick(n_total);
             clk.mark("last iterations + download");
@@ -750,6 +771,21 @@ extern "C" int tvdn_plan(int dtype, int ndim, const int64_t *shape, int fista, i
             out->min_slabs = (int32_t)s;
             break;
         }
+    return TVDN_OK;
+}
+
+extern "C" int tvdn_run_workspace_bytes(const tvdn_run_args *a, int64_t *bytes)
+{
+    TVDN_REQUIRE(a != nullptr && bytes != nullptr, "NULL argument");
+    TVDN_REQUIRE(a->dtype == TVDN_F32 || a->dtype == TVDN_F64, "bad dtype %d", a->dtype);
+    TVDN_REQUIRE(a->ndim == 3 || a->ndim == 4, "ndim must be 3 or 4, got %d", a->ndim);
+    size_t b = a->dtype == TVDN_F32 ? 4 : 8;
+    for (int i = 0; i < a->ndim; ++i) {
+        TVDN_REQUIRE(a->shape[i] >= 1, "shape[%d] must be >= 1", i);
+        b *= (size_t)a->shape[i];
+    }
+    const size_t stride = (b + 255) / 256 * 256 + 4096;  // as run_impl lays the state out
+    *bytes = (int64_t)(stride * (size_t)(3 + a->ndim * (a->n_fista > 0 ? 3 : 2)));
     return TVDN_OK;
 }
 

@@ -76,21 +76,26 @@ class _ProgressBars:
     """Upstream's two tqdm bars (cyTVDN.py:148-151, :196-199) fed from tvdn_run's progress callback, which reports the
     number of the last iteration slot handed to the GPU (the unaccelerated phase counts on from n_fista)."""
 
-    def __init__(self, n_fista, n_plain, quiet):
+    def __init__(self, n_fista, n_plain, quiet, may_stop=False):
         self.active = _tqdm is not None and not quiet
         self.n_fista, self.n_plain = n_fista, n_plain
+        self.may_stop = may_stop          # without a stopping rule a phase that is left has run all its iterations
         self.bars = [None, None]
         self.seen = [0, 0]
 
     def update(self, slots_done):
         phase = 0 if slots_done <= self.n_fista and self.n_fista and not self.bars[1] else 1
+        if phase == 1 and self.n_fista and not self.may_stop and self.seen[0] < self.n_fista:
+            self._advance(0, self.n_fista)     # one report may cover the end of one phase and the start of the next
         if phase == 1 and self.bars[0] is not None:
             self.bars[0].close()
             self.bars[0] = None
+        self._advance(phase, slots_done - (self.n_fista if phase else 0))
+
+    def _advance(self, phase, done):
         if self.bars[phase] is None:
             self.bars[phase] = _tqdm(total=self.n_fista if phase == 0 else self.n_plain,
                                      desc="FISTA Accelerated TV Denoising" if phase == 0 else "Unaccelerated TV Denoising")
-        done = slots_done - (self.n_fista if phase else 0)
         self.bars[phase].update(done - self.seen[phase])
         self.seen[phase] = done
 
@@ -177,9 +182,7 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
         # allocation and placement audition, the loop, stopping rule and MSE trace, and for long-enough Jia-Zhao runs
         # the first iterations under the upload and the last ones over the download.  The progress bars are fed from
         # the library's callback.  TVDN_LOOP=native|python keeps the loop here (engine.SlabRunner; measurement, tests).
-        if torch.cuda.is_available():
-            torch.cuda.empty_cache()       # the library allocates with hipMalloc: hand it what torch's cache holds
-        bars = _ProgressBars(n_fista, n_plain, quiet)
+        bars = _ProgressBars(n_fista, n_plain, quiet, may_stop=stop is not None)
         try:
             return _run_device_list([int(device)], datacube, lambdaInv, lam_mu, n_fista, n_plain, stop, reference_data,
                                     BC_mode, quiet, progress=bars.update if bars.active else None, announce=False)
@@ -256,6 +259,25 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
     return recon, b_norm, delta_recon
 
 
+def _state_workspace(args, shape, dtype, fista, n_total, device, BC_mode):
+    """Device memory for the state of a resident tvdn_run, from torch's caching allocator: `hipMalloc` of tens of GiB
+    takes 11 ms most times and 3-5 s some times, and a process that denoises cube after cube should pay that once
+    (tvdn.h, tvdn_run_args.workspace).  Long runs get the best of a few placements (`HipBackend.best_of`, DESIGN.md
+    section 3) -- the library's own audition is off when it is handed a workspace."""
+    import ctypes as C
+    from . import _lib
+    need = C.c_int64(0)
+    _lib.check(_lib.lib().tvdn_run_workspace_bytes(C.byref(args), C.byref(need)))
+    cands = _audition_candidates(n_total)
+    if cands > 1:
+        be = HipBackend.best_of(cands, SlabLayout(tuple(shape), 0, 1, int(BC_mode)), dtype, fista, device=device, max_iters=1)
+        slab = getattr(be, "_slab", None)
+        if slab is not None and slab.numel() * slab.element_size() >= need.value and slab.data_ptr() % 256 == 0:
+            return slab
+    _lib.ctx(device)                             # raises without a GPU: no CPU fallback
+    return torch.empty(need.value, dtype=torch.uint8, device=torch.device("cuda", int(device)))
+
+
 def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, stop, reference_data, BC_mode, quiet,
                      stream=None, progress=None, announce=True):
     """`device=[0, 1, ...]`: one slab of axis 0 per listed GPU inside THIS process -- the library's whole-loop entry
@@ -297,10 +319,15 @@ def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, sto
         ref = np.ascontiguousarray(reference_data)
         a.reference, a.mse_out = ref.ctypes.data, mse.ctypes.data
     a.iters_run = C.addressof(ran)
+    workspace = None
+    if len(devices) == 1 and stream is None:
+        workspace = _state_workspace(a, datacube.shape, dtype, n_fista > 0, n, devices[0], BC_mode)
+        a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     if progress is not None:
         hook = C.CFUNCTYPE(None, C.c_int32, C.c_void_p)(lambda slots_done, _user: progress(int(slots_done)))
         a.progress = C.cast(hook, C.c_void_p)
     _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+    del workspace
     sums = sums[:n]
     # which slots ran, from the library's own per-phase counts (not guessed from the values: an all-zero cube has zero
     # sums in slots that DID run, and upstream reports 0/0 = NaN there); the rest keep the reference's zero tail

@@ -282,9 +282,22 @@ typedef struct tvdn_run_args {
      * reports a pass at a time.  Must not call back into the library. */
     void (*progress)(int32_t slots_done, void *user);
     void *progress_user;
+    /* ABI 5.  Optional device memory for the state of a RESIDENT ONE-DEVICE run (ignored by device lists and streamed
+     * runs): 256-byte aligned, at least tvdn_run_workspace_bytes() bytes, on the run's device, contents arbitrary;
+     * NULL = the library allocates and frees its own.  Why a caller would: hipMalloc of tens of GiB takes 11 ms most
+     * times and 3-5 s some times (profiles/r03_e2e_pipelined.txt: 3 of 10 back-to-back 60 GiB calls), so a process
+     * that calls repeatedly keeps the memory (cytvdn_amd passes a block of torch's caching allocator); and a caller
+     * that has tried several allocations passes the one that sweeps fastest -- with a workspace
+     * the library's own placement audition is off. */
+    void *workspace;
+    int64_t workspace_bytes;
 } tvdn_run_args;
 
 int tvdn_run(const tvdn_run_args *args);
+
+/* Bytes of device memory the state of a resident one-device run of these args takes (dtype, ndim, shape, n_fista > 0
+ * are read): what tvdn_run allocates itself, or expects behind tvdn_run_args.workspace.  Pure host arithmetic. */
+int tvdn_run_workspace_bytes(const tvdn_run_args *args, int64_t *bytes);
 
 /* How a RESIDENT one-device tvdn_run overlaps its two transfers with iterations (what upstream does one after the other:
  * datacube in, cyTVDN.py:145; recon out, :244-247): out[0] = rows per chunk, out[1] = iterations that follow the upload

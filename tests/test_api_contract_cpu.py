@@ -166,7 +166,7 @@ def test_struct_layouts_match_the_c_header(tmp_path):
                    '  P(tvdn_iter_args, orig_ring_rows); P(tvdn_iter_args, accumulate);\n'
                    '  printf("tvdn_many_args %zu\\n", sizeof(tvdn_many_args)); P(tvdn_many_args, recon); P(tvdn_many_args, S); P(tvdn_many_args, tk_prev);\n'
                    '  printf("tvdn_run_args %zu\\n", sizeof(tvdn_run_args)); P(tvdn_run_args, stop); P(tvdn_run_args, data); P(tvdn_run_args, devices);\n'
-                   '  P(tvdn_run_args, stream_rows); P(tvdn_run_args, stream_k); P(tvdn_run_args, phase_iters); P(tvdn_run_args, progress_user); P(tvdn_run_args, n_devices);\n'
+                   '  P(tvdn_run_args, stream_rows); P(tvdn_run_args, stream_k); P(tvdn_run_args, phase_iters); P(tvdn_run_args, progress_user); P(tvdn_run_args, workspace_bytes); P(tvdn_run_args, n_devices);\n'
                    '  printf("tvdn_plan_out %zu\\n", sizeof(tvdn_plan_out)); P(tvdn_plan_out, fits); P(tvdn_plan_out, min_slabs);\n'
                    '  return 0; }\n')
     exe = tmp_path / "layout"
@@ -192,3 +192,41 @@ def test_tvdn_run_checks_its_arguments_before_it_looks_for_a_device():
     assert L.tvdn_run(ctypes.byref(a)) == -1 and "must both be 0" in L.tvdn_last_error().decode()
     a.stream_rows = a.stream_k = -1
     assert L.tvdn_run(ctypes.byref(a)) == -4 and "no CPU fallback" in L.tvdn_last_error().decode()
+
+
+def test_progress_bars_follow_the_library_reports(monkeypatch):
+    """driver._ProgressBars turns tvdn_run's slot counts into upstream's two bars (cyTVDN.py:148-151, :196-199): per
+    iteration, per pipelined phase (one report may end the FISTA phase and start the unaccelerated one), and with a
+    stopping rule, where a phase that is left early keeps its count."""
+    from cytvdn_amd import driver
+    closed = []
+
+    class Bar:
+        def __init__(self, total, desc):
+            self.total, self.desc, self.n = total, desc, 0
+
+        def update(self, k):
+            assert k >= 0
+            self.n += k
+
+        def close(self):
+            closed.append((self.desc.split()[0], self.n, self.total))
+
+    monkeypatch.setattr(driver, "_tqdm", Bar)
+
+    def play(n_f, n_p, reports, **kw):
+        closed.clear()
+        b = driver._ProgressBars(n_f, n_p, False, **kw)
+        assert b.active
+        for r in reports:
+            b.update(r)
+        b.close()
+        return list(closed)
+
+    assert play(6, 4, range(1, 11)) == [("FISTA", 6, 6), ("Unaccelerated", 4, 4)]
+    assert play(6, 4, [3, 4, 10]) == [("FISTA", 6, 6), ("Unaccelerated", 4, 4)]
+    assert play(6, 4, [10]) == [("FISTA", 6, 6), ("Unaccelerated", 4, 4)]
+    assert play(6, 4, [1, 7], may_stop=True) == [("FISTA", 1, 6), ("Unaccelerated", 1, 4)]
+    assert play(0, 4, [2, 4]) == [("Unaccelerated", 4, 4)]
+    assert play(5, 0, [5]) == [("FISTA", 5, 5)]
+    assert not driver._ProgressBars(5, 0, True).active

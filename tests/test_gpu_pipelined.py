@@ -140,3 +140,65 @@ def test_a_nonfinite_first_row_takes_the_plain_order(oracle, monkeypatch):
     got = tv.denoise4D(x, mu, 8, quiet=True)
     ref = oracle.denoise(x, mu, 8, True)
     assert np.isnan(ref["recon"][-1]).any() and bits_equal(got[0], ref["recon"])
+
+
+def test_upstream_progress_bars_are_fed_from_the_library(oracle, capfd, monkeypatch):
+    """quiet=False: the two tqdm bars of cyTVDN.py:148-151 / :196-199 advance from tvdn_run's callback and end at their
+    totals; the results are those of the quiet call."""
+    pytest.importorskip("tqdm")
+    import cytvdn_amd as tv
+    from cytvdn_amd import synth
+    dt = np.dtype(np.float32)
+    x = synth.cube((24, 3, 4, 8), seed=11, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6], dt)
+    monkeypatch.setenv("TVDN_PIPELINE", "4,3,2")
+    loud = tv.denoise4D(x, mu, [6, 4], FISTA=True, quiet=False)
+    err = capfd.readouterr().err
+    assert "FISTA Accelerated TV Denoising: 100%" in err and "6/6" in err
+    assert "Unaccelerated TV Denoising: 100%" in err and "4/4" in err
+    quiet = tv.denoise4D(x, mu, [6, 4], FISTA=True, quiet=True)
+    ref = oracle.denoise(x, mu, [6, 4], True)
+    assert bits_equal(loud[0], ref["recon"]) and bits_equal(quiet[0], ref["recon"])
+    for u, v in zip(loud[1:], quiet[1:]):
+        assert bits_equal(u, v)
+
+
+@pytest.mark.parametrize("shape,dtype,n_f,n_p,pipe", [
+    ((24, 3, 4, 8), np.float32, 7, 0, "0"), ((24, 3, 4, 8), np.float32, 5, 3, "4,3,2"), ((13, 6, 16), np.float64, 0, 6, "0"),
+])
+def test_tvdn_run_in_the_callers_workspace(oracle, monkeypatch, shape, dtype, n_f, n_p, pipe):
+    """tvdn_run_args.workspace: the state in device memory the caller brings (here a torch block full of 0xFF bytes, i.e.
+    NaNs: whatever the run needs zeroed it zeroes itself) -- the oracle's bits; too small or misaligned is refused."""
+    import ctypes as C
+    import torch
+    from test_gpu_run_streamed import _check_traces, _oracle
+    from cytvdn_amd import _lib, synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=37, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    lam = mu / dt.type(32.0 if nd == 4 else 16.0)
+    ref = _oracle(oracle, x, mu, n_f, n_p)
+    monkeypatch.setenv("TVDN_PIPELINE", pipe)
+    a = _lib.RunArgs(dtype=_lib.dtype_code(dt), ndim=nd, bc_mode=2, device=0, n_fista=n_f, n_plain=n_p)
+    for i, s in enumerate(shape):
+        a.shape[i] = s
+    for q in range(nd):
+        a.clip[q] = float((1.0 / lam)[q])
+        a.lambda_mu[q] = float((lam / mu).astype(dt)[q])
+    need = C.c_int64()
+    _lib.check(_lib.lib().tvdn_run_workspace_bytes(C.byref(a), C.byref(need)))
+    n_arr = 3 + nd * (3 if n_f else 2)
+    assert need.value == n_arr * (-(-x.nbytes // 256) * 256 + 4096)
+    ws = torch.full((need.value + 256,), 0xFF, dtype=torch.uint8, device="cuda")
+    recon, sums = np.empty_like(x), np.zeros((n_f + n_p, 3))
+    a.data, a.recon_out, a.sums_out = x.ctypes.data, recon.ctypes.data, sums.ctypes.data
+    a.workspace, a.workspace_bytes = ws.data_ptr(), need.value
+    for _ in range(2):                                         # the second run finds the first one's leftovers
+        _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+        assert bits_equal(recon, ref["recon"])
+        _check_traces(sums, ref, n_f + n_p)
+    a.workspace_bytes = need.value - 1
+    assert _lib.lib().tvdn_run(C.byref(a)) == -1 and b"workspace" in _lib.lib().tvdn_last_error()
+    a.workspace, a.workspace_bytes = ws.data_ptr() + 64, need.value
+    assert _lib.lib().tvdn_run(C.byref(a)) == -1 and b"aligned" in _lib.lib().tvdn_last_error()

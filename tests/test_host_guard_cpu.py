@@ -188,3 +188,21 @@ def test_the_pipelining_plan_switches_itself_on_for_large_cubes_only(monkeypatch
     assert _lib.pipeline_plan(40, 9, 1 << 20) == (5, 6, 3)      # forced: clipped to the iterations there are
     monkeypatch.setenv("TVDN_PIPELINE", "1")
     assert _lib.pipeline_plan(256, 50, 4 << 30) == (32, 8, 8)
+
+
+def test_workspace_bytes_is_the_layout_of_the_resident_state():
+    """tvdn_run_workspace_bytes: arrays of the cube's size rounded up to 256 bytes and staggered by 4 KiB, 3 + ndim x (3 with
+    FISTA iterations, else 2) of them -- host arithmetic, no GPU."""
+    import ctypes as C
+    from cytvdn_amd import _lib
+    for shape, dtype, n_f, want_arrays in (((256, 256, 128, 128), 0, 50, 15), ((256, 256, 128, 128), 1, 0, 11),
+                                           ((128, 128, 512), 0, 200, 12), ((5, 3, 7), 1, 0, 9)):
+        a = _lib.RunArgs(dtype=dtype, ndim=len(shape), n_fista=n_f, n_plain=3)
+        for i, s in enumerate(shape):
+            a.shape[i] = s
+        need = C.c_int64()
+        _lib.check(_lib.lib().tvdn_run_workspace_bytes(C.byref(a), C.byref(need)))
+        cube = int(np.prod(shape)) * (4 if dtype == 0 else 8)
+        assert need.value == want_arrays * (-(-cube // 256) * 256 + 4096)
+    a = _lib.RunArgs(dtype=0, ndim=5)
+    assert _lib.lib().tvdn_run_workspace_bytes(C.byref(a), C.byref(need)) == -1
