@@ -192,6 +192,12 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
             TVDN_REQUIRE(((uintptr_t)a->workspace & 255) == 0, "workspace must be 256-byte aligned");
             TVDN_REQUIRE(a->workspace_bytes >= (int64_t)(stride * (size_t)n_arr), "workspace of %lld bytes, the state needs %lld (tvdn_run_workspace_bytes)",
                          (long long)a->workspace_bytes, (long long)(stride * (size_t)n_arr));
+            hipPointerAttribute_t at;  // a host pointer here would fault on the GPU: ask the runtime what it is
+            if (hipPointerGetAttributes(&at, a->workspace) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != s.device) {
+                (void)hipGetLastError();
+                set_error("workspace %p is not device memory of device %d", a->workspace, s.device);
+                return TVDN_ERR_INVALID;
+            }
             s.state.p = a->workspace;
             s.state.owned = false;
         } else {

@@ -202,3 +202,6 @@ def test_tvdn_run_in_the_callers_workspace(oracle, monkeypatch, shape, dtype, n_
     assert _lib.lib().tvdn_run(C.byref(a)) == -1 and b"workspace" in _lib.lib().tvdn_last_error()
     a.workspace, a.workspace_bytes = ws.data_ptr() + 64, need.value
     assert _lib.lib().tvdn_run(C.byref(a)) == -1 and b"aligned" in _lib.lib().tvdn_last_error()
+    host = np.zeros(need.value + 512, np.uint8)                # host memory is refused, not dereferenced by a kernel
+    a.workspace = (host.ctypes.data + 255) // 256 * 256
+    assert _lib.lib().tvdn_run(C.byref(a)) == -1 and b"not device memory" in _lib.lib().tvdn_last_error()
