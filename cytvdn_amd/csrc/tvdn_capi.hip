@@ -61,6 +61,82 @@ __global__ void __launch_bounds__(1024) finalize_kernel(const double *partials, 
     }
 }
 
+struct DeferTable {
+    int rows[kDeferSlots];
+    double *out[kDeferSlots];
+};
+
+// finalize_kernel for a batch: workgroup b folds the rows of ring slot b into table.out[b] (same tree, never accumulating)
+__global__ void __launch_bounds__(1024) finalize_many_kernel(const double *ring, DeferTable table, int nv)
+{
+    __shared__ double red[kPartialWidth][16];
+    const double *partials = ring + (size_t)blockIdx.x * kFoldDirect * kPartialWidth;
+    const int nblocks = table.rows[blockIdx.x];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int q = 0; q < nv; ++q) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < nblocks; i += 1024) s += partials[(size_t)i * kPartialWidth + q];
+        s = wave_sum(s);
+        if (lane == 0) red[q][w] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nv) {
+        double s = 0.0;
+        for (int i = 0; i < 16; ++i) s += red[threadIdx.x][i];
+        table.out[blockIdx.x][threadIdx.x] = s;
+    }
+}
+
+void sums_defer_begin(tvdn_ctx *ctx)
+{
+    ctx->n_pend = 0;
+    ctx->deferring = getenv("TVDN_DEFER_SUMS") ? atoi(getenv("TVDN_DEFER_SUMS")) != 0 : true;
+}
+
+double *sums_defer_slot(tvdn_ctx *ctx, long long nblocks, bool accumulate)
+{
+    if (!ctx->deferring || accumulate || nblocks > kFoldDirect) return nullptr;
+    if (!ctx->ring) {
+        if (hipMalloc((void **)&ctx->ring, sizeof(double) * (size_t)kDeferSlots * kFoldDirect * kPartialWidth) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->ring = nullptr;
+            ctx->deferring = false;  // no room for the ring: finalize at once, as outside the loops
+            return nullptr;
+        }
+    }
+    return ctx->ring + (size_t)ctx->n_pend * kFoldDirect * kPartialWidth;
+}
+
+int sums_defer_flush(tvdn_ctx *ctx, hipStream_t s)
+{
+    if (ctx->n_pend == 0) return TVDN_OK;
+    DeferTable t;
+    for (int i = 0; i < kDeferSlots; ++i) {
+        t.rows[i] = i < ctx->n_pend ? ctx->pend_rows[i] : 0;
+        t.out[i] = i < ctx->n_pend ? ctx->pend_out[i] : nullptr;
+    }
+    hipLaunchKernelGGL(finalize_many_kernel, dim3(ctx->n_pend), dim3(1024), 0, s, (const double *)ctx->ring, t, 3);
+    ctx->n_pend = 0;
+    TVDN_HIP(hipGetLastError());
+    return TVDN_OK;
+}
+
+int sums_defer_push(tvdn_ctx *ctx, int nblocks, double *out, hipStream_t s)
+{
+    ctx->pend_rows[ctx->n_pend] = nblocks;
+    ctx->pend_out[ctx->n_pend] = out;
+    if (++ctx->n_pend == kDeferSlots) return sums_defer_flush(ctx, s);
+    return TVDN_OK;
+}
+
+int sums_defer_end(tvdn_ctx *ctx, hipStream_t s)
+{
+    const int rc = sums_defer_flush(ctx, s);
+    ctx->deferring = false;
+    ctx->n_pend = 0;
+    return rc;
+}
+
 int ensure_partials(tvdn_ctx *ctx, long long nblocks)
 {
     TVDN_REQUIRE(nblocks >= 1 && nblocks <= kMaxPartialBlocks, "launch of %lld workgroups exceeds the reduction scratch",
@@ -214,6 +290,9 @@ int tvdn_ctx_create(tvdn_ctx **out, int device)
     c->partials = nullptr;
     c->partials2 = nullptr;
     c->partial_cap = kInitPartialBlocks;
+    c->ring = nullptr;
+    c->deferring = false;
+    c->n_pend = 0;
     c->timing = false;
     hipError_t e = hipMalloc((void **)&c->partials, sizeof(double) * (size_t)kInitPartialBlocks * kPartialWidth);
     if (e == hipSuccess)
@@ -282,6 +361,7 @@ int tvdn_ctx_destroy(tvdn_ctx *ctx)
     }
     hipError_t e = hipFree(ctx->partials);
     (void)hipFree(ctx->partials2);
+    if (ctx->ring) (void)hipFree(ctx->ring);
     delete ctx;
     if (e != hipSuccess) {
         set_error("hipFree failed: %s", hipGetErrorString(e));

@@ -152,6 +152,13 @@ struct tvdn_ctx {
     double *partials;   // [partial_cap][kPartialWidth]
     double *partials2;  // [kMaxPartialBlocks / kFoldSegment][kPartialWidth]: output of the first finalize stage
     long long partial_cap;
+    // Deferred finalize (small grids inside the library's own loops, tvdn_capi.hip sums_defer_*): the sweeps of up to
+    // kDeferSlots iterations park their partial rows in `ring` and ONE launch folds them all
+    double *ring;  // [kDeferSlots][kFoldDirect][kPartialWidth], allocated on first use
+    bool deferring;
+    int n_pend;
+    int pend_rows[32];
+    double *pend_out[32];
     bool timing;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // pending (start, stop) pairs
 };
@@ -187,6 +194,22 @@ __device__ __forceinline__ void block_store_partials(const double (&v)[NV], doub
         partials[(size_t)blockIdx.x * kPartialWidth + threadIdx.x] = s;
     }
 }
+
+// Deferred finalize.  A sweep over a small cube is followed by a finalize launch that costs 3.5-5 us of a 15-90 us iteration
+// (64x64x256: 18.0 -> 14.6 us without it) although nothing in the NEXT iteration depends on it.  Inside the library's own
+// loops (tvdn_iterate_many, the resident tvdn_run without a stopping rule) the sweeps therefore park their partial rows in a
+// ring of kDeferSlots slots and one launch folds a whole batch -- the same tree per iteration, so the same bits.
+//   sums_defer_begin   from now on launches of <= kFoldDirect workgroups with accumulate == 0 are parked
+//   sums_defer_slot    where the next such launch writes its rows (nullptr: not deferring / not eligible)
+//   sums_defer_push    the launch has been queued: remember (rows, out); folds the batch when the ring is full
+//   sums_defer_flush   fold what is parked (also called before any launch that is finalized at once, to keep the order)
+//   sums_defer_end     flush and leave the mode
+constexpr int kDeferSlots = 32;
+void sums_defer_begin(tvdn_ctx *ctx);
+double *sums_defer_slot(tvdn_ctx *ctx, long long nblocks, bool accumulate);
+int sums_defer_push(tvdn_ctx *ctx, int nblocks, double *out, hipStream_t s);
+int sums_defer_flush(tvdn_ctx *ctx, hipStream_t s);
+int sums_defer_end(tvdn_ctx *ctx, hipStream_t s);
 
 // Makes room for `nblocks` partial rows (grows the scratch buffer; a growth synchronises the device once).
 int ensure_partials(tvdn_ctx *ctx, long long nblocks);

@@ -604,6 +604,14 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
         if (rce) return rce;
         p.partials = ctx->partials;
     }
+    // inside the library's own loops a small launch parks its partial rows for a batched fold (tvdn_common.hpp)
+    double *parked = sums_defer_slot(ctx, grid, a->accumulate != 0);
+    if (parked) {
+        p.partials = parked;
+    } else {
+        const int rcf = sums_defer_flush(ctx, s);  // what is parked lands before a fold that is not
+        if (rcf) return rcf;
+    }
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ctx->timing) {
@@ -621,6 +629,7 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
         ctx->events.emplace_back(ev0, ev1);
     }
     if (rc) return rc;
+    if (parked) return sums_defer_push(ctx, (int)grid, sums_out, s);
     return launch_finalize(ctx, (int)grid, 3, sums_out, s, a->accumulate != 0);
 }
 
@@ -707,6 +716,7 @@ extern "C" int tvdn_iterate_many(tvdn_ctx *ctx, tvdn_many_args *st, int32_t n_fi
     const int nd = st->base.ndim;
     TVDN_REQUIRE(nd == 3 || nd == 4, "ndim must be 3 or 4, got %d", nd);
     tvdn_iter_args it = st->base;
+    tvdn::sums_defer_begin(ctx);  // nobody reads the sums between these iterations: fold them in batches
     for (int i = 0; i < n_fista + n_plain; ++i) {
         const bool use_fista = i < n_fista;
         const double ratio = use_fista ? ratios[i] : 0.0;
@@ -714,10 +724,13 @@ extern "C" int tvdn_iterate_many(tvdn_ctx *ctx, tvdn_many_args *st, int32_t n_fi
         it.sweep_lo = it.sweep_hi = 0;
         it.accumulate = 0;
         const int rc = tvdn_iterate_fused(ctx, &it, sums_out + 3 * (size_t)i, stream);
-        if (rc) return rc;
+        if (rc) {
+            (void)tvdn::sums_defer_end(ctx, (hipStream_t)stream);
+            return rc;
+        }
         tvdn::roles_advance(*st, use_fista, ratio);
     }
-    return TVDN_OK;
+    return tvdn::sums_defer_end(ctx, (hipStream_t)stream);
 }
 
 // The schedule's host side for callers that drive tvdn_iterate_fused themselves (cytvdn_amd/engine.py): the same three

@@ -593,6 +593,9 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
         return TVDN_OK;
     };
 
+    // no stopping rule, one slab: nobody reads the sums before the end, small launches fold them in batches (tvdn_common.hpp)
+    const bool defer_sums = world == 1 && !a->use_stop;
+    if (defer_sums) sums_defer_begin(sl[0].ctx);
     bool recon_home = false;
     if (pipelined) {
         // ---- middle: whole sweeps; end: the last k1 levels as a wavefront, finished rows go home chunk by chunk ----------
@@ -713,6 +716,11 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
         }
     }
 
+    if (defer_sums) {
+        TVDN_HIP(hipSetDevice(sl[0].device));
+        const int rcd = sums_defer_end(sl[0].ctx, sl[0].main);
+        if (rcd) return rcd;
+    }
     if (!pipelined) clk.mark("iterations");
     // ---- results home ---------------------------------------------------------------------------------
     if (n_total > 0) std::memset(a->sums_out, 0, sizeof(double) * 3 * (size_t)n_total);

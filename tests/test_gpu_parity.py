@@ -455,3 +455,33 @@ def test_native_loop_equals_python_loop(tv, monkeypatch, shape, dtype, its, fist
     b = fn(x, mu, its, FISTA=fista, quiet=True)
     for u, v in zip(a, b):
         assert bits_equal(u, v)
+
+
+@pytest.mark.parametrize("shape,dtype,its,fista", [
+    ((6, 5, 8, 12), np.float32, 70, True), ((9, 6, 16), np.float64, [33, 3], True), ((5, 3, 7, 9), np.float32, 32, False),
+    ((12, 4, 8, 16), np.float32, 5, True),
+])
+def test_batched_fold_of_the_sums_changes_no_bit(tv, oracle, monkeypatch, shape, dtype, its, fista):
+    """Inside the library's own loops small launches park their partial sums and one launch folds up to 32 iterations'
+    worth (csrc/tvdn_capi.hip sums_defer_*): the same tree per iteration, so b_norm / delta_recon agree to the last bit with
+    the fold after every sweep -- more iterations than ring slots, the d -> b transition, a pipelined run (whose partial
+    sweeps accumulate and are folded at once, in order with what is parked)."""
+    from cytvdn_amd import synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=53, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    fn = tv.denoise4D if nd == 4 else tv.denoise3D
+    got = {}
+    for defer in ("0", "1"):
+        monkeypatch.setenv("TVDN_DEFER_SUMS", defer)
+        for loop, pipe in (("run", "0"), ("run", "4,2,2"), ("native", "0")):
+            monkeypatch.setenv("TVDN_LOOP", loop)
+            monkeypatch.setenv("TVDN_PIPELINE", pipe)
+            got[defer, loop, pipe] = fn(x, mu, its, FISTA=fista, quiet=True)
+    for key in (("run", "0"), ("run", "4,2,2"), ("native", "0")):
+        for u, v in zip(got[("0",) + key], got[("1",) + key]):
+            assert bits_equal(u, v), key
+    ref = oracle.denoise(x, mu, its, fista)
+    assert bits_equal(got["1", "run", "0"][0], ref["recon"])
+    np.testing.assert_allclose(got["1", "run", "0"][1].astype(np.float64), ref["b_norm64"].astype(dt).astype(np.float64), rtol=1e-5)
