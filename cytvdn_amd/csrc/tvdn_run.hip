@@ -852,7 +852,9 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
         int same = 0;  // slabs sharing the first device share its HBM
         for (int i = 0; i < world; ++i) same += (a->n_devices == 0 || a->devices[i] == a->devices[0]) ? 1 : 0;
         // ONE threshold (tvdn_plan's `fits`): a state beyond 90 % of the free HBM streams when asked to decide, else is refused
-        const bool over = pl.bytes_per_slab * same > (int64_t)(0.9 * (double)pl.free_bytes);
+        // a caller that brings the state's memory (workspace, one slab) has nothing left to fit but the sums
+        const bool brought = a->workspace != nullptr && world == 1;
+        const bool over = !brought && pl.bytes_per_slab * same > (int64_t)(0.9 * (double)pl.free_bytes);
         if (stream_auto && over && world == 1) {
             // asked to decide: one device, state beyond its HBM -> stream it (tvdn_stream.hip; it refuses, before it
             // touches the caller's arrays, what the host cannot hold either)
