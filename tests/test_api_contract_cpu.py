@@ -230,3 +230,23 @@ def test_progress_bars_follow_the_library_reports(monkeypatch):
     assert play(0, 4, [2, 4]) == [("Unaccelerated", 4, 4)]
     assert play(5, 0, [5]) == [("FISTA", 5, 5)]
     assert not driver._ProgressBars(5, 0, True).active
+
+
+def test_integration_md_structs_are_the_real_ones():
+    """The ctypes stubs INTEGRATION.md shows a cyTVDN maintainer (IterArgs, RunArgs) are executed and compared with the
+    tested binding field by field: name, ctypes type, offset."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    for name, real in (("IterArgs", _lib.IterArgs), ("RunArgs", _lib.RunArgs)):
+        m = re.search(r"class %s\(C\.Structure\):.*?\n(\s+_fields_ = \[.*?\)\])" % name, text, re.S)
+        assert m, name
+        ns = {"C": ctypes}
+        exec("class S(C.Structure):\n" + m.group(1), ns)
+        doc = ns["S"]
+        assert ctypes.sizeof(doc) == ctypes.sizeof(real), name
+        assert [f[0] for f in doc._fields_] == [f[0] for f in real._fields_], name
+        for f in doc._fields_:
+            assert getattr(doc, f[0]).offset == getattr(real, f[0]).offset, (name, f[0])
+            assert getattr(doc, f[0]).size == getattr(real, f[0]).size, (name, f[0])
+    assert "tvdn_abi_version() == %d" % _lib.lib().tvdn_abi_version() in text

@@ -205,3 +205,34 @@ def test_tvdn_run_in_the_callers_workspace(oracle, monkeypatch, shape, dtype, n_
     host = np.zeros(need.value + 512, np.uint8)                # host memory is refused, not dereferenced by a kernel
     a.workspace = (host.ctypes.data + 255) // 256 * 256
     assert _lib.lib().tvdn_run(C.byref(a)) == -1 and b"not device memory" in _lib.lib().tvdn_last_error()
+
+
+def test_the_binding_shown_in_integration_md_runs(oracle):
+    """the ctypes stub a cyTVDN maintainer would add around tvdn_run, executed as printed (only the
+    library's path filled in) -- the oracle's reconstruction, a progress bar that ends at its total."""
+    import os
+    import re
+    from cytvdn_amd import _lib, synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    m = re.search(r"```python\n(# cyTVDN/_hip\.py  \(new file upstream\)\nimport ctypes as C\nL = C\.CDLL.*?)```", text, re.S)
+    assert m
+    ns = {"np": np}
+    exec(m.group(1).replace('"libtvdn_hip.so"', repr(_lib.LIB_PATH)), ns)
+    dt = np.dtype(np.float32)
+    x = synth.cube((20, 3, 4, 8), seed=41, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6], dt)
+    lam = mu / dt.type(32.0)
+
+    class Bar:
+        n = 0
+
+        def update(self, k):
+            self.n += k
+
+    bar = Bar()
+    recon, b_norm, delta = ns["denoise4D_hip"](x, 1.0 / lam, (lam / mu).astype(dt), 6, 3, 2, bar)
+    ref = oracle.denoise(x, mu, [6, 3], True)
+    assert bits_equal(recon, ref["recon"]) and bar.n == 9
+    np.testing.assert_allclose(b_norm.astype(np.float64), ref["b_norm64"].astype(dt).astype(np.float64), rtol=1e-6)
+    np.testing.assert_allclose(delta.astype(np.float64), (ref["delta64"].astype(dt) / ref["rnorm64"].astype(dt)).astype(np.float64), rtol=1e-6)
