@@ -196,7 +196,7 @@ class EmulatedNeighbours:
         import torch
         from cytvdn_amd.engine import edge_block
         self.be, self.torch, self.edge_block = be, torch, edge_block
-        self.side = torch.cuda.Stream(device=be.device)
+        self.side = torch.cuda.Stream(device=be.device, priority=-1)   # as engine.SlabRunner: not on the sweeps' hardware queue
 
     def _step(self, tk, slot):
         torch, be = self.torch, self.be
@@ -356,7 +356,10 @@ def init_groups(local_rank):
         return None, "gloo", False
     ok, g, err = 1, None, ""
     try:
-        g = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL's own stream from the high-priority pool: a hardware-queue class the sweeps (default stream) are not in, so the
+        # send/recv kernels neither queue behind the interior sweep nor wait for its workgroups to be dispatched first
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        g = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
         dist.barrier(group=g)   # first collective with every rank taking part (batched P2P must not be the first one)
         torch.cuda.synchronize()
     except Exception as e:

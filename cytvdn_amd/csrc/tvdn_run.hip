@@ -178,8 +178,12 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
         TVDN_HIP(hipSetDevice(s.device));
         int rc = tvdn_ctx_create(&s.ctx, s.device);
         if (rc) return rc;
-        rc = make_stream(&s.main, +1);  // sweeps: a hardware queue no transfer shares (tvdn_common.hpp)
-        if (!rc) rc = make_stream(&s.copy, 0);
+        // Sweeps and transfers in different hardware-queue classes (tvdn_common.hpp make_stream).  One slab: the transfers
+        // are the staging lanes' DMA copies (normal class), the sweeps go high.  Several slabs: the transfers are peer
+        // copies of one row under the interior sweep, possibly done by copy kernels -- those go high, so that their few
+        // workgroups are dispatched ahead of the sweep's many instead of after them, and the sweeps stay normal.
+        rc = make_stream(&s.main, world == 1 ? +1 : 0);
+        if (!rc) rc = make_stream(&s.copy, world == 1 ? 0 : +1);
         if (rc) return rc;
         TVDN_HIP(hipEventCreateWithFlags(&s.edge_done, hipEventDisableTiming));
         TVDN_HIP(hipEventCreateWithFlags(&s.halo_done, hipEventDisableTiming));

@@ -637,7 +637,12 @@ class SlabRunner:
             return
         main = torch.cuda.current_stream(be.device)
         if self._side is None:
-            self._side = torch.cuda.Stream(device=be.device)
+            # HIGH priority = a hardware-queue class the sweeps' stream is not in.  Streams of one priority share a few
+            # hardware queues in turn (profiles/r03_queue_alias_probe.jsonl); a side stream that lands on the main stream's
+            # queue puts its wait for the exchange IN FRONT of the interior sweep, and the overlap is gone -- one time in
+            # four, by the order streams happened to be created in.  (The group's own RCCL stream should be created the
+            # same way: ProcessGroupNCCL.Options(is_high_priority_stream=True), as bench.py does.)
+            self._side = torch.cuda.Stream(device=be.device, priority=-1)
         main.wait_stream(self._side)                     # the previous exchange has filled my halo rows
         e = edge_block(hi - lo)
         be.step(tk_ratio, slot, rows=(lo, lo + e), accumulate=False)
