@@ -40,6 +40,5 @@ python3 tools/clocks_during.py $O/r03_clocks_sustained.txt -- python3 bench.py -
 echo "clocks rc=$?"
 cat $O/r03_b_pmc_bench_summary.txt
 head -8 $O/r03_a_kernel_trace_by_grid.csv
-head -5 $O/r03_clocks_sustained.txt
-tail -3 $O/r03_clocks_sustained.txt
+tail -2 $O/r03_clocks_sustained.txt | cut -c1-200
 cat $O/bench_600.json | head -c 600
