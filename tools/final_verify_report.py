@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/r03_gputest_head.txt from the logs tools/final_verify.sh left under gpurun_out/r3final/."""
-import os, re, subprocess, sys
+import os, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = os.path.join(ROOT, "gpurun_out", "r3final")
 summary = open(os.path.join(O, "summary.txt")).read()

@@ -6,7 +6,6 @@ import json, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cytvdn_amd import _lib
-import ctypes as C
 
 dev = torch.device("cuda", 0)
 L = _lib.lib()

@@ -3,7 +3,7 @@
 onto each of 12 other streams and the host notes when each copy's event completes.  A stream that sits on the same hardware
 queue as the busy one sees its copy complete only when the queued kernels have drained.  Twice: busy stream of normal
 priority, busy stream of high priority (the fix in csrc/tvdn_common.hpp make_stream)."""
-import json, os, sys, time
+import json, time
 import torch
 
 dev = torch.device("cuda", 0)
