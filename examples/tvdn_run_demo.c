@@ -15,6 +15,12 @@
 
 #include "tvdn.h"
 
+/* tvdn_run_args.progress: called on this thread with the number of iteration slots handed to the GPU so far */
+static void on_progress(int32_t slots_done, void *user)
+{
+    fprintf(stderr, "\r%d / %d iterations queued%s", (int)slots_done, *(const int *)user, slots_done == *(const int *)user ? "\n" : "");
+}
+
 int main(int argc, char **argv)
 {
     int64_t shape[4] = {12, 10, 16, 32};
@@ -49,6 +55,8 @@ int main(int argc, char **argv)
     a.data = x; a.recon_out = recon; a.sums_out = sums;
     int32_t ran = 0;
     a.iters_run = &ran;
+    a.progress = on_progress;
+    a.progress_user = &iters;
     int rc = tvdn_run(&a);
     if (rc != TVDN_OK) {
         fprintf(stderr, "tvdn_run failed (%d): %s\n", rc, tvdn_last_error());
