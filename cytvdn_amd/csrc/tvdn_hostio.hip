@@ -273,6 +273,29 @@ __global__ void __launch_bounds__(256) stream_mix_kernel(MixPtrs p, long long n1
         __builtin_nontemporal_store(o, reinterpret_cast<f4 *>(p.out[k]) + i);
     }
 }
+// The same mix over a TILE-INTERLEAVED layout (measurement: DESIGN.md section 8, "what is left for placement"): tile t of array
+// slot s lives at base + (t * (NR + NW) + s) * 4 KiB, so a workgroup's 15 tiles are one contiguous 60 KiB block and the whole
+// launch is one sequential stream instead of NR + NW.  TVDN_MIX_INTERLEAVED=1 makes tvdn_stream_mix run this over in[0].
+template <int NR, int NW>
+__global__ void __launch_bounds__(256) stream_mix_interleaved_kernel(const float4 *base, long long tiles)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const long long t = xcd_remap(blockIdx.x, gridDim.x);
+    if (t >= tiles) return;
+    const f4 *blk = reinterpret_cast<const f4 *>(base) + t * (long long)(NR + NW) * 256 + threadIdx.x;
+    f4 v[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) v[k] = __builtin_nontemporal_load(blk + k * 256);
+    f4 s = v[0];
+#pragma unroll
+    for (int k = 1; k < NR; ++k) s += v[k];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        f4 o = s;
+        o.x += (float)k;
+        __builtin_nontemporal_store(o, const_cast<f4 *>(blk) + (NR + k) * 256);
+    }
+}
 // The same stream in the SWEEP's traversal: a workgroup owns one 4 KiB tile of a row-plane and marches `chunk` rows along
 // axis 0 (stride = one plane), workgroup ids remapped per XCD like the sweep's -- the ceiling of that structure, apart
 // from neighbour re-reads and arithmetic.
@@ -341,6 +364,13 @@ extern "C" int tvdn_stream_mix(int32_t n_read, const void *const *in, int32_t n_
     const long long n16 = bytes_each / 16;
     const long long grid = (n16 + 255) / 256;
     TVDN_REQUIRE(grid < (1LL << 31), "array too long for one launch");
+    if (getenv("TVDN_MIX_INTERLEAVED") && n_read == 10 && n_write == 5) {
+        // measurement knob: in[0] is the base of (n_read + n_write) * bytes_each bytes, read and written tile-interleaved
+        hipLaunchKernelGGL((tvdn::stream_mix_interleaved_kernel<10, 5>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                           (const float4 *)in[0], grid);
+        TVDN_HIP(hipGetLastError());
+        return TVDN_OK;
+    }
 #define TVDN_MIX(NR, NW)                                                                                                           \
     if (n_read == NR && n_write == NW) {                                                                                           \
         hipLaunchKernelGGL((tvdn::stream_mix_kernel<NR, NW>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, n16); \
