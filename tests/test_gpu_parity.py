@@ -485,3 +485,20 @@ def test_batched_fold_of_the_sums_changes_no_bit(tv, oracle, monkeypatch, shape,
     ref = oracle.denoise(x, mu, its, fista)
     assert bits_equal(got["1", "run", "0"][0], ref["recon"])
     np.testing.assert_allclose(got["1", "run", "0"][1].astype(np.float64), ref["b_norm64"].astype(dt).astype(np.float64), rtol=1e-5)
+
+
+@pytest.mark.parametrize("shape,dtype", [((6, 5, 8, 12), np.float32), ((7, 6, 16), np.float64)])
+def test_zero_iterations_return_the_input(tv, shape, dtype):
+    """iterations=0: upstream's loops do not run (cyTVDN.py:148, :196) -- recon is a copy of the input, the traces are empty;
+    the input array is left alone."""
+    from cytvdn_amd import synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=59, dtype=dt) + dt.type(0.25)
+    x0 = x.copy()
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    fn = tv.denoise4D if nd == 4 else tv.denoise3D
+    for its, fista in ((0, True), (0, False), ([0, 0], True)):
+        recon, bn, dl = fn(x, mu, its, FISTA=fista, quiet=True)
+        assert bits_equal(recon, x0) and recon is not x and bits_equal(x, x0)
+        assert bn.shape == (0,) and dl.shape == (0,) and bn.dtype == dt and dl.dtype == dt
