@@ -237,3 +237,38 @@ def test_multi_gpu_slab_shape_on_one_gpu(oracle, plane, own, thin, k):
     del grp, bes, big, be, orig_rows, recon_rows, rows_o, got
     gc.collect()
     torch.cuda.empty_cache()
+
+
+def test_default_path_with_pipelined_transfers_at_full_size(oracle, monkeypatch):
+    """denoise4D as a user calls it on the config-2 cube in host memory: tvdn_run shapes its own pipelined transfers (32-row
+    chunks, 8 iterations under the upload, 8 over the download, the real helper threads and staging lanes) -- the same bits
+    as the plain order, and windows of the result equal the oracle on the enlarged windows of the input."""
+    import torch
+    import cytvdn_amd as tv
+    from cytvdn_amd import _lib, synth
+    its = 18
+    dt = np.dtype(np.float32)
+    mu = np.array([1.0, 1.0, 0.5, 0.5], dt)
+    buf = torch.empty(SHAPE, dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().tvdn_synth_fill(0, 4, _lib.shape_arr(SHAPE), synth.SEED_4D, 0, SHAPE[0], buf.data_ptr(),
+                                          _lib.current_stream(0)))
+    x = buf.cpu().numpy()
+    del buf
+    torch.cuda.empty_cache()
+    monkeypatch.delenv("TVDN_PIPELINE", raising=False)
+    assert _lib.pipeline_plan(SHAPE[0], its, x.nbytes) == (32, 8, 8)
+    got, bn, dl = tv.denoise4D(x, mu, its, quiet=True)
+    monkeypatch.setenv("TVDN_PIPELINE", "0")
+    plain, bn0, dl0 = tv.denoise4D(x, mu, its, quiet=True)
+    assert hashlib.sha1(got.tobytes()).hexdigest() == hashlib.sha1(plain.tobytes()).hexdigest()
+    np.testing.assert_allclose(bn.astype(np.float64), bn0.astype(np.float64), rtol=1e-6)
+    np.testing.assert_allclose(dl.astype(np.float64), dl0.astype(np.float64), rtol=1e-6)
+    del plain
+    halo = 2 * its
+    for start, ext in (((0, 0, 0, 0), (6, 6, 8, 8)), ((250, 250, 120, 120), (6, 6, 8, 8)), ((29, 120, 60, 60), (6, 4, 6, 8))):
+        lo = [max(0, s - halo) for s in start]
+        hi = [min(n, s + e + halo) for s, e, n in zip(start, ext, SHAPE)]
+        sl = tuple(slice(a, b) for a, b in zip(lo, hi))
+        ref = oracle.denoise(np.ascontiguousarray(x[sl]), mu, its, True)["recon"]
+        inner = tuple(slice(s - a, s - a + e) for s, a, e in zip(start, lo, ext))
+        assert bits_equal(got[tuple(slice(s, s + e) for s, e in zip(start, ext))], ref[inner]), start
