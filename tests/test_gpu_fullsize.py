@@ -272,3 +272,31 @@ def test_default_path_with_pipelined_transfers_at_full_size(oracle, monkeypatch)
         ref = oracle.denoise(np.ascontiguousarray(x[sl]), mu, its, True)["recon"]
         inner = tuple(slice(s - a, s - a + e) for s, a, e in zip(start, lo, ext))
         assert bits_equal(got[tuple(slice(s, s + e) for s, e in zip(start, ext))], ref[inner]), start
+
+
+@pytest.mark.parametrize("bc", [2, 0])
+def test_streamed_run_at_a_size_that_page_locks_in_place(monkeypatch, bc):
+    """The C++ streamed loop on a cube large enough (2 GiB arrays) that `data` and `recon_out` are page-locked IN PLACE
+    (csrc/tvdn_stream.hip; the small streamed tests go through staging copies): two passes of four iterations, 16-row
+    chunks, against the resident run of the same call -- same bits, same traces; the input is left alone.  Jia-Zhao and
+    periodic boundaries (the latter keeps old and new host state apart: 19 pinned arrays)."""
+    import torch
+    import cytvdn_amd as tv
+    from cytvdn_amd import _lib, synth
+    shape = (128, 256, 128, 128)
+    dt = np.dtype(np.float32)
+    mu = np.array([1.0, 1.0, 0.5, 0.5], dt)
+    buf = torch.empty(shape, dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().tvdn_synth_fill(0, 4, _lib.shape_arr(shape), synth.SEED_4D, 0, shape[0], buf.data_ptr(),
+                                          _lib.current_stream(0)))
+    x = buf.cpu().numpy()
+    del buf
+    torch.cuda.empty_cache()
+    sha_in = hashlib.sha1(x.tobytes()).hexdigest()
+    resident = tv.denoise4D(x, mu, 8, quiet=True, BC_mode=bc)
+    monkeypatch.setenv("TVDN_WAVEFRONT", "16,4")
+    streamed = tv.denoise4D(x, mu, 8, quiet=True, BC_mode=bc)
+    assert hashlib.sha1(x.tobytes()).hexdigest() == sha_in
+    assert hashlib.sha1(streamed[0].tobytes()).hexdigest() == hashlib.sha1(resident[0].tobytes()).hexdigest()
+    np.testing.assert_allclose(streamed[1].astype(np.float64), resident[1].astype(np.float64), rtol=1e-6)
+    np.testing.assert_allclose(streamed[2].astype(np.float64), resident[2].astype(np.float64), rtol=1e-6)
