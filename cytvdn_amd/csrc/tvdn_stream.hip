@@ -193,12 +193,14 @@ static int64_t stream_planes(int nd, int64_t rows, int64_t k, bool mse, bool wra
     return ((k + 1) + (k + 2) * nd) * (rows + 2) + (rows + k + 3) * (mse ? 2 : 1) + 2 * (3 + 4 * nd) * rows + (wrap ? k + 1 : 0);
 }
 
-// Chunk height and depth: the deepest k (<= 128) whose rings fit 70 % of the free HBM, taller chunks on ties
+// Chunk height and depth: the deepest k (<= 128) whose rings and staging boxes fit 85 % of the free HBM, taller chunks on
+// ties.  Every byte the run allocates on the device is in that count; on PCIe-bound shapes depth IS speed (256 MiB planes:
+// k = 30 / 38 / 44 -> 28.4 / 33.6 / 37.0 Gvoxel-iters/s, profiles/r03_outofcore_depth.jsonl), so the budget is generous.
 // (a streamed pass is PCIe-bound until k ~ 100: cytvdn_amd/planner.py).
 int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_bytes, bool mse, bool wrap, int64_t *rows_out,
                         int64_t *k_out)
 {
-    const int64_t budget = (int64_t)(0.7 * (double)free_bytes / (double)row_bytes);
+    const int64_t budget = (int64_t)(0.85 * (double)free_bytes / (double)row_bytes);
     int64_t best_k = 0, best_r = 0;
     for (int64_t r : {32, 16, 8, 4, 2}) {
         r = std::min<int64_t>(r, std::max<int64_t>(2, n_rows));

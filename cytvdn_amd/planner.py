@@ -24,7 +24,8 @@ import os
 import numpy as np
 
 HEADROOM = 0.9            # fraction of the free HBM an in-core state may take
-STAGING_FRACTION = 0.7    # fraction the level windows of a streamed run may take
+STAGING_FRACTION = 0.85   # fraction of the free HBM the level windows + staging boxes of a streamed run may take (as
+                          # csrc/tvdn_stream.hip choose_stream_shape: on PCIe-bound planes depth is speed)
 MAX_DEPTH = 128           # iterations per pass beyond which the sweeps, not PCIe, set the pace
 
 

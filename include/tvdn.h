@@ -261,7 +261,7 @@ typedef struct tvdn_run_args {
      * memory with the wavefront schedule: chunks of stream_rows rows, stream_k iterations per PCIe round trip, every
      * row of every iteration swept once (row rings, tvdn_iter_args.ring_rows); bit-identical to the resident run.
      * 0 / 0: never (a state beyond the HBM is refused with TVDN_ERR_UNSUPPORTED and the arithmetic in the message);
-     * -1 / -1: decided here -- resident when it fits, else the deepest stream_k whose rings fit 70 % of the free HBM;
+     * -1 / -1: decided here -- resident when it fits, else the deepest stream_k whose rings fit 85 % of the free HBM;
      * both > 0: stream with exactly these.  A cube whose state the host cannot hold page-locked either is refused
      * before any of the caller's arrays is touched.  Both boundary conditions (periodic: the cube is swept between
      * stream_k wrapped rows at either end, and old and new host state are two sets of arrays); with use_stop one iteration per
