@@ -320,6 +320,9 @@ def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, sto
         a.reference, a.mse_out = ref.ctypes.data, mse.ctypes.data
     a.iters_run = C.addressof(ran)
     workspace = None
+    if stream is not None or len(devices) > 1 or reference_data is not None:   # (the reference cube of an MSE trace too)
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()       # the library allocates these runs' device memory itself: hand it what torch's cache holds
     if len(devices) == 1 and stream is None:
         workspace = _state_workspace(a, datacube.shape, dtype, n_fista > 0, n, devices[0], BC_mode)
         a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()

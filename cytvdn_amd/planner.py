@@ -38,7 +38,11 @@ def _parse_bytes(text: str) -> int:
 
 
 def hbm_available(device: int = 0, hbm_bytes: int = None):
-    """Bytes of HBM the planner may count on: explicit > min(TVDN_HBM_LIMIT, free) > free > None (no GPU)."""
+    """Bytes of HBM the planner may count on: explicit > min(TVDN_HBM_LIMIT, free) > free > None (no GPU).  `free` counts
+    what torch's caching allocator holds but does not use: a process that has just denoised one cube keeps that cube's
+    state block cached, and the next call either reuses it (resident runs allocate through torch) or has it released first
+    (driver.py empties the cache before it hands a run to the library's own allocations) -- without this the second large
+    cube of a process would be sent to the streamed engines although it fits."""
     if hbm_bytes is not None:
         return int(hbm_bytes)
     free = None
@@ -46,6 +50,7 @@ def hbm_available(device: int = 0, hbm_bytes: int = None):
         import torch
         if torch.cuda.is_available():
             free = int(torch.cuda.mem_get_info(device)[0])
+            free += max(0, int(torch.cuda.memory_reserved(device)) - int(torch.cuda.memory_allocated(device)))
     except Exception:
         free = None
     cap = os.environ.get("TVDN_HBM_LIMIT")
