@@ -175,3 +175,20 @@ def test_wavefront_host_state_in_place(oracle, shape, dtype, bc, rows, k, n_f, n
     ref = oracle.denoise(x, mu, its, n_f > 0, BC_mode=bc)
     assert bits_equal(got[True][0], ref["recon"]) and bits_equal(got[False][0], ref["recon"])
     np.testing.assert_allclose(got[True][1], got[False][1], rtol=1e-12)
+
+
+def test_planner_counts_what_torchs_cache_holds():
+    """A process that has just denoised a cube keeps its state block in torch's caching allocator: the planner must count
+    that as available (the next resident run reuses it), else the second large cube of a process is streamed for nothing."""
+    import torch
+    from cytvdn_amd import planner
+    torch.cuda.empty_cache()
+    base = planner.hbm_available(0)
+    t = torch.empty(2 << 30, dtype=torch.uint8, device="cuda")
+    held = planner.hbm_available(0)
+    del t                                                       # back to torch's cache, not to the driver
+    free_now = int(torch.cuda.mem_get_info(0)[0])
+    cached = planner.hbm_available(0)
+    assert held <= base - (2 << 30) + (64 << 20)
+    assert cached >= free_now + (2 << 30) - (64 << 20) and abs(cached - base) <= (64 << 20)
+    torch.cuda.empty_cache()
