@@ -284,6 +284,7 @@ int tvdn_ctx_create(tvdn_ctx **out, int device)
         return TVDN_ERR_NO_DEVICE;
     }
     TVDN_REQUIRE(device >= 0 && device < n, "device %d out of range (0..%d)", device, n - 1);
+    DeviceRestore restore;
     TVDN_HIP(hipSetDevice(device));
     tvdn_ctx *c = new tvdn_ctx;
     c->device = device;

@@ -217,6 +217,24 @@ int ensure_partials(tvdn_ctx *ctx, long long nblocks);
 int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_bytes, bool mse, bool wrap, int64_t *rows_out,
                         int64_t *k_out);
 int run_streamed(const tvdn_run_args *a, int64_t rows, int64_t k);
+// Entry points that select a device put the calling thread's current device back before they return: a library that leaves
+// hipSetDevice(3) behind changes where the caller's next allocation (torch's, say) lands.
+struct DeviceRestore {
+    int prev = -1;
+    DeviceRestore()
+    {
+        if (hipGetDevice(&prev) != hipSuccess) {
+            (void)hipGetLastError();
+            prev = -1;
+        }
+    }
+    ~DeviceRestore()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceRestore(const DeviceRestore &) = delete;
+    DeviceRestore &operator=(const DeviceRestore &) = delete;
+};
 void io_cap_lanes(int n);  // tvdn_hostio.hip: at most n staging lanes per transfer (0 = no cap)
 // A non-blocking stream in a hardware-queue class of its own.  The runtime multiplexes streams onto a few hardware queues
 // per PRIORITY level; two streams that share one execute in submission order, so a transfer's completion marker can sit

@@ -134,6 +134,7 @@ static int transfer(bool up, void *dst, const void *src, size_t bytes, int devic
     TVDN_REQUIRE(device >= 0 && device < 16, "device %d out of range", device);
     TVDN_REQUIRE(bytes == 0 || (dst && src), "NULL buffer");
     if (bytes == 0) return TVDN_OK;
+    DeviceRestore restore;
     std::lock_guard<std::mutex> lock(g_io_mutex);
     if (bytes < (size_t(4) << 20)) {  // small: the runtime's own path is as good
         TVDN_HIP(hipSetDevice(device));

@@ -763,6 +763,7 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
 // tallest slab of an n-way split with its halo rows, what the device has free, and the fewest slabs that would fit.
 extern "C" int tvdn_plan(int dtype, int ndim, const int64_t *shape, int fista, int n_slabs, int device, tvdn_plan_out *out)
 {
+    tvdn::DeviceRestore restore;
     TVDN_REQUIRE(out != nullptr && shape != nullptr, "NULL argument");
     TVDN_REQUIRE(dtype == TVDN_F32 || dtype == TVDN_F64, "bad dtype %d", dtype);
     TVDN_REQUIRE(ndim == 3 || ndim == 4, "ndim must be 3 or 4, got %d", ndim);
@@ -817,6 +818,7 @@ extern "C" int tvdn_pipeline_plan(int64_t n0, int32_t n_iters, int64_t cube_byte
 
 extern "C" int tvdn_run(const tvdn_run_args *a)
 {
+    tvdn::DeviceRestore restore;  // declared first: destroyed after every slab, stream and buffer of the run
     TVDN_REQUIRE(a != nullptr, "args is NULL");
     TVDN_REQUIRE(a->dtype == TVDN_F32 || a->dtype == TVDN_F64, "bad dtype %d", a->dtype);
     TVDN_REQUIRE(a->ndim == 3 || a->ndim == 4, "ndim must be 3 or 4, got %d", a->ndim);

@@ -101,3 +101,25 @@ def test_denoise_with_a_device_list(oracle, shape, dtype, its, fista, stop, with
             np.testing.assert_allclose(u, v, rtol=tol)
     ref = oracle.denoise(x, mu, its, fista, stopping_relative_change=stop, reference_data=refd, BC_mode=bc)
     assert bits_equal(one[0], ref["recon"])
+
+
+def test_entry_points_leave_the_current_device_alone(oracle):
+    """tvdn_run / tvdn_copy_* / tvdn_ctx_create select their device internally and put the caller's back (csrc/tvdn_common.hpp
+    DeviceRestore): after a run on another GPU torch's next allocation still lands where it did.  Needs two GPUs to mean
+    anything; on one it checks the call sequence only."""
+    import torch
+    import cytvdn_amd as tv
+    from cytvdn_amd import synth
+    dt = np.dtype(np.float32)
+    x = synth.cube((12, 3, 4, 8), seed=3, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6], dt)
+    other = 1 if torch.cuda.device_count() > 1 else 0
+    torch.cuda.set_device(0)
+    before = torch.cuda.current_device()
+    got = tv.denoise4D(x, mu, 4, quiet=True, device=other)
+    assert torch.cuda.current_device() == before == 0
+    assert torch.empty(1, device="cuda").device.index == 0
+    got2 = tv.denoise4D(x, mu, 4, quiet=True, device=[0, other])
+    assert torch.cuda.current_device() == 0
+    ref = oracle.denoise(x, mu, 4, True)["recon"]
+    assert bits_equal(got[0], ref) and bits_equal(got2[0], ref)
