@@ -174,7 +174,7 @@ def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int =
     if stop:
         # a stopping rule wants a host decision after every iteration: trapezoid engine, k = 1, three staging buffers
         per_row = 3 * (n_arr + 1) * plane
-        rows = int(STAGING_FRACTION * avail / per_row) - 2
+        rows = int(min(STAGING_FRACTION, 0.7) * avail / per_row) - 2     # k = 1 here: block height buys little, keep the slack
         if rows < 1:
             out.update(mode="does-not-fit", bytes_per_gpu=per_row * 3, why="not even a one-row block fits")
             return out
