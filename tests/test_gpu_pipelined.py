@@ -236,3 +236,38 @@ def test_the_binding_shown_in_integration_md_runs(oracle):
     assert bits_equal(recon, ref["recon"]) and bar.n == 9
     np.testing.assert_allclose(b_norm.astype(np.float64), ref["b_norm64"].astype(dt).astype(np.float64), rtol=1e-6)
     np.testing.assert_allclose(delta.astype(np.float64), (ref["delta64"].astype(dt) / ref["rnorm64"].astype(dt)).astype(np.float64), rtol=1e-6)
+
+
+@pytest.mark.parametrize("shape,its", [((24, 6, 16, 32), 9), ((64, 32, 128, 256), 8)])
+def test_concurrent_calls_from_threads(shape, its):
+    """Three Python threads denoise three different cubes at once (the GIL is released inside tvdn_run; every call has its
+    own context, streams and workspace; the staging lanes are shared behind a mutex): each result equals the serial one.
+    The second shape is large enough (256 MiB) for the pipelined transfers with their helper threads."""
+    import hashlib
+    import threading
+    import cytvdn_amd as tv
+    from cytvdn_amd import synth
+    mu = np.array([1.0, 1.0, 0.5, 0.5], np.float32)
+
+    def sha(a):
+        return hashlib.sha1(a.tobytes()).hexdigest()
+
+    xs = [synth.cube(shape, seed=s, dtype=np.float32) + np.float32(0.25) for s in (1, 2, 3)]
+    want = [sha(tv.denoise4D(x, mu, its, quiet=True)[0]) for x in xs]
+    got = [[None] * 3 for _ in xs]
+    errors = []
+
+    def work(i):
+        try:
+            for r in range(3):
+                got[i][r] = sha(tv.denoise4D(xs[i], mu, its, quiet=True)[0])
+        except Exception as e:      # surfaces in the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(xs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert all(g == w for gs, w in zip(got, want) for g in gs)
