@@ -150,3 +150,36 @@ def test_tvdn_run_device_list_random(oracle, rows, plane, f64, bc, n_f, n_p, see
     its = [n_f, n_p] if (n_f and n_p) else (n_f or n_p)
     ref = oracle.denoise(x, mu, its, n_f > 0, BC_mode=bc)
     assert bits_equal(recon, ref["recon"])
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(shape=st.one_of(st.tuples(st.integers(2, 40), st.integers(1, 4), st.integers(1, 5), st.sampled_from([1, 3, 4, 8, 12])),
+                       st.tuples(st.integers(2, 40), st.integers(1, 6), st.sampled_from([2, 4, 7, 8, 16]))),
+       f64=st.booleans(), sched=st.sampled_from(["fista", "plain", "hybrid"]), seed=st.integers(0, 2 ** 31 - 1),
+       rows=st.integers(1, 48), k0=st.integers(0, 9), k1=st.integers(0, 9), n1=st.integers(1, 9), n2=st.integers(1, 6))
+def test_pipelined_transfers_random(oracle, shape, f64, sched, seed, rows, k0, k1, n1, n2):
+    """tvdn_run's pipelined transfers with arbitrary chunk heights and wavefront depths (more levels than rows, chunks
+    taller than the cube, depths beyond the iteration count, a d -> b transition anywhere) against the oracle."""
+    import os
+    import cytvdn_amd as tv
+    dt = np.dtype(np.float64 if f64 else np.float32)
+    nd = len(shape)
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(shape) + rng.poisson(3.0, shape)).astype(dt)
+    mu = np.array([1.0, 0.7, 0.5, 1.3][:nd], dt)
+    its = {"fista": n1, "plain": n1, "hybrid": [n1, n2]}[sched]
+    fista = sched != "plain"
+    fn = tv.denoise4D if nd == 4 else tv.denoise3D
+    old = os.environ.get("TVDN_PIPELINE")
+    os.environ["TVDN_PIPELINE"] = f"{rows},{k0},{k1}"
+    try:
+        got = fn(x, mu, its, FISTA=fista, quiet=True)
+    finally:
+        if old is None:
+            del os.environ["TVDN_PIPELINE"]
+        else:
+            os.environ["TVDN_PIPELINE"] = old
+    ref = oracle.denoise(x, mu, its, fista)
+    assert bits_equal(got[0], ref["recon"])
+    tol = 1e-6 if dt == np.float32 else 1e-12
+    np.testing.assert_allclose(got[1].astype(np.float64), ref["b_norm64"].astype(dt).astype(np.float64), rtol=tol)
