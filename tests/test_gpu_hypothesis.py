@@ -183,3 +183,30 @@ def test_pipelined_transfers_random(oracle, shape, f64, sched, seed, rows, k0, k
     assert bits_equal(got[0], ref["recon"])
     tol = 1e-6 if dt == np.float32 else 1e-12
     np.testing.assert_allclose(got[1].astype(np.float64), ref["b_norm64"].astype(dt).astype(np.float64), rtol=tol)
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(rows=st.integers(2, 30), plane=st.one_of(st.tuples(st.integers(1, 4), st.integers(1, 5), st.sampled_from([1, 3, 4, 8, 12])),
+                                                st.tuples(st.integers(1, 6), st.sampled_from([2, 4, 7, 8, 16]))),
+       f64=st.booleans(), bc=st.sampled_from([0, 2]), n_f=st.integers(0, 7), n_p=st.integers(0, 5), seed=st.integers(0, 2 ** 31 - 1),
+       chunk=st.integers(1, 12), k=st.integers(1, 9), bad_row0=st.booleans())
+def test_streamed_run_random(oracle, rows, plane, f64, bc, n_f, n_p, seed, chunk, k, bad_row0):
+    """The C++ streamed loop (csrc/tvdn_stream.hip) with arbitrary chunk heights and depths, both boundary conditions, any
+    schedule, a non-finite first row now and then: recon against the oracle bit for bit, the sums against its f64 yardsticks."""
+    from test_gpu_run_streamed import _check_traces, _oracle_bc, _run
+    if n_f + n_p == 0:
+        n_f = 1
+    shape = (rows,) + tuple(plane)
+    dt = np.dtype(np.float64 if f64 else np.float32)
+    nd = len(shape)
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(shape) * 2 + rng.poisson(3.0, shape)).astype(dt)
+    if bad_row0 and bc == 2:
+        x[(0,) + tuple(int(rng.integers(s)) for s in shape[1:])] = np.inf
+    mu = np.array([1.0, 0.7, 0.5, 1.3][:nd], dt)
+    ref = _oracle_bc(oracle, x, mu, n_f, n_p, bc)
+    recon, sums, _, ran = _run(x, mu, n_f, n_p, stream=(chunk, k), bc=bc)
+    assert ran == n_f + n_p
+    assert bits_equal(recon, ref["recon"])
+    if np.isfinite(ref["b_norm64"]).all() and np.isfinite(ref["delta64"]).all():
+        _check_traces(sums, ref, n_f + n_p)
