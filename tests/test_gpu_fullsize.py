@@ -286,6 +286,11 @@ def test_streamed_run_at_a_size_that_page_locks_in_place(monkeypatch, bc):
     shape = (128, 256, 128, 128)
     dt = np.dtype(np.float32)
     mu = np.array([1.0, 1.0, 0.5, 0.5], dt)
+    from cytvdn_amd import planner
+    pinned = (19 if bc == 0 else 10) * int(np.prod(shape)) * 4          # what the streamed run page-locks
+    avail = planner.host_available()
+    if avail is not None and pinned + 3 * int(np.prod(shape)) * 4 > 0.8 * avail:
+        pytest.skip(f"host offers {avail >> 30} GiB to pin, the run needs {pinned >> 30} GiB")
     buf = torch.empty(shape, dtype=torch.float32, device="cuda")
     _lib.check(_lib.lib().tvdn_synth_fill(0, 4, _lib.shape_arr(shape), synth.SEED_4D, 0, shape[0], buf.data_ptr(),
                                           _lib.current_stream(0)))
