@@ -270,7 +270,8 @@ def _state_workspace(args, shape, dtype, fista, n_total, device, BC_mode):
     _lib.check(_lib.lib().tvdn_run_workspace_bytes(C.byref(args), C.byref(need)))
     cands = _audition_candidates(n_total)
     if cands > 1:
-        be = HipBackend.best_of(cands, SlabLayout(tuple(shape), 0, 1, int(BC_mode)), dtype, fista, device=device, max_iters=1)
+        be = HipBackend.best_of(cands, SlabLayout(tuple(shape), 0, 1, int(BC_mode)), dtype, fista, device=device, max_iters=1,
+                                release_losers=False)     # kept in torch's cache for the next call (see best_of)
         slab = getattr(be, "_slab", None)
         if slab is not None and slab.numel() * slab.element_size() >= need.value and slab.data_ptr() % 256 == 0:
             return slab

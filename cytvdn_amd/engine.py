@@ -415,7 +415,8 @@ class HipBackend:
         return float(min(each[1:nl.value])) if nl.value > 1 else float(each[0])
 
     @classmethod
-    def best_of(cls, candidates: int, layout, dtype, fista, device: int = 0, hbm_fraction: float = 0.8, **kw):
+    def best_of(cls, candidates: int, layout, dtype, fista, device: int = 0, hbm_fraction: float = 0.8,
+                release_losers: bool = True, **kw):
         """The sweep's speed depends on WHERE in HBM its state landed: with identical clocks, the same 60 GiB state of
         BASELINE config 2 sweeps in 11.2, 12.1 or 12.6 ms depending on the physical pages one hipMalloc happened to get
         (three states held at once in one process, timed in turn, each reproducible: profiles/r03_placement_audition_*.jsonl;
@@ -449,7 +450,11 @@ class HipBackend:
         keep = held[best]
         keep.audition = [round(times[best], 4)] + [round(t, 4) for i, t in enumerate(times) if i != best]
         del held, be
-        torch.cuda.empty_cache()       # hand the losers' HBM back to the driver (torch caches freed blocks otherwise)
+        if release_losers:
+            torch.cuda.empty_cache()   # hand the losers' HBM back to the driver (torch caches freed blocks otherwise)
+        # else the losers stay in torch's cache: the next audition of this process finds them there instead of asking the
+        # driver again -- a hipMalloc of tens of GiB right after a free of that size stalls for seconds some times
+        # (profiles/r03_e2e_pipelined.txt), which a process that denoises cube after cube would pay on every call
         return keep
 
     # -- staging support (cytvdn_amd/outofcore.py): a backend reused for blocks of varying height ----------
