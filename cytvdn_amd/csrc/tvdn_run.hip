@@ -19,18 +19,23 @@
 
 namespace tvdn {
 
-struct DevBuf {
-    void *p = nullptr;
-    int device = 0;
-    bool owned = true;  // false: the caller's workspace
-    ~DevBuf()
-    {
-        if (p && owned) {
-            (void)hipSetDevice(device);
-            (void)hipFree(p);
-        }
-    }
+// The state block of the last resident run of each device is KEPT when the run ends and handed to the next run that it
+// fits: releasing and re-allocating tens of GiB in quick succession costs 0.7 s per hipMalloc plus 1.1 s per hipFree, with
+// single stalls of 4-6 s (profiles/r03_malloc_stall_probe.jsonl), so a program that calls tvdn_run cube after cube would
+// spend more time in the allocator than in the sweeps.  One block per device at most, only while no caller-provided
+// workspace is in use; tvdn_release_cache() hands it back, TVDN_KEEP_STATE=0 never keeps one.
+struct StateCache {
+    std::mutex mu;
+    void *p[TVDN_MAX_DEVICES] = {};
+    size_t bytes[TVDN_MAX_DEVICES] = {};
 };
+static StateCache g_state_cache;
+
+static bool keep_state()
+{
+    const char *e = getenv("TVDN_KEEP_STATE");
+    return !(e && atoi(e) == 0) && getenv("TVDN_MALLOC") == nullptr;
+}
 
 // The state's allocation.  TVDN_MALLOC=contiguous | uncached | finegrained asks the runtime for another kind of device memory
 // (measurement: does a physically contiguous state take the placement lottery out of the sweep's speed?  DESIGN.md section 3).
@@ -42,6 +47,63 @@ static hipError_t state_malloc(void **p, size_t bytes)
     if (e && !strcmp(e, "finegrained")) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
     return hipMalloc(p, bytes);
 }
+
+// the kept block of `device` if it holds `bytes` without being more than a quarter larger, else a fresh allocation
+static hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device)
+{
+    if (keep_state() && device >= 0 && device < TVDN_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lk(g_state_cache.mu);
+        void *&c = g_state_cache.p[device];
+        size_t &cb = g_state_cache.bytes[device];
+        if (c && cb >= bytes && cb - bytes <= bytes / 4) {
+            *p = c;
+            *got_bytes = cb;
+            c = nullptr;
+            cb = 0;
+            return hipSuccess;
+        }
+        if (c) {  // the wrong size: make room before asking for the right one
+            (void)hipFree(c);
+            c = nullptr;
+            cb = 0;
+        }
+    }
+    *got_bytes = bytes;
+    return state_malloc(p, bytes);
+}
+
+static void state_release(void *p, size_t bytes, int device)
+{
+    if (!p) return;
+    if (keep_state() && device >= 0 && device < TVDN_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lk(g_state_cache.mu);
+        void *&c = g_state_cache.p[device];
+        if (!c) {
+            c = p;
+            g_state_cache.bytes[device] = bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    int device = 0;
+    bool owned = true;  // false: the caller's workspace
+    size_t bytes = 0;   // size of the allocation (state blocks only)
+    bool keep = false;  // a state block that goes to the cache instead of back to the driver
+    ~DevBuf()
+    {
+        if (p && owned) {
+            (void)hipSetDevice(device);
+            if (keep && bytes)
+                state_release(p, bytes, device);
+            else
+                (void)hipFree(p);
+        }
+    }
+};
 
 template <typename T>
 static T delta_in_dtype(const double s[3])
@@ -205,7 +267,13 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
             s.state.p = a->workspace;
             s.state.owned = false;
         } else {
-            TVDN_HIP(state_malloc(&s.state.p, stride * (size_t)n_arr));
+            // one slab: the block the last run of this device left behind, if it fits (StateCache above)
+            if (world == 1) {
+                TVDN_HIP(state_acquire(&s.state.p, stride * (size_t)n_arr, &s.state.bytes, s.device));
+                s.state.keep = true;
+            } else {
+                TVDN_HIP(state_malloc(&s.state.p, stride * (size_t)n_arr));
+            }
         }
         TVDN_HIP(hipMemsetAsync(s.state.p, 0, stride * (size_t)(n_arr - 2), s.main));
         std::memset(&s.roles, 0, sizeof s.roles);
@@ -312,6 +380,7 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
                 if ((double)total > 0.8 * (double)free_b) break;
                 std::unique_ptr<DevBuf> b(new DevBuf);
                 b->device = s.device;
+                b->bytes = total;
                 if (state_malloc(&b->p, total) != hipSuccess) {
                     (void)hipGetLastError();
                     break;
@@ -328,9 +397,12 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             if (rc) return rc;
-            if (best != s.state.p)  // keep the winner in s.state (freed with the slab), the former first one among the losers
+            if (best != s.state.p)  // keep the winner in s.state (released with the slab), the former first one among the losers
                 for (auto &b : held)
-                    if (b->p == best) std::swap(b->p, s.state.p);
+                    if (b->p == best) {
+                        std::swap(b->p, s.state.p);
+                        std::swap(b->bytes, s.state.bytes);  // the winner is what the cache keeps afterwards, the losers are freed
+                    }
             held.clear();  // frees every loser
             s.assign((char *)s.state.p, stride, nd, per_axis);
             roles_reset(s.roles, fista);
@@ -764,6 +836,11 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
 extern "C" int tvdn_plan(int dtype, int ndim, const int64_t *shape, int fista, int n_slabs, int device, tvdn_plan_out *out)
 {
     tvdn::DeviceRestore restore;
+    size_t kept = 0;  // the state block the last run of this device left for the next one counts as free
+    if (device >= 0 && device < TVDN_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lk(tvdn::g_state_cache.mu);
+        kept = tvdn::g_state_cache.bytes[device];
+    }
     TVDN_REQUIRE(out != nullptr && shape != nullptr, "NULL argument");
     TVDN_REQUIRE(dtype == TVDN_F32 || dtype == TVDN_F64, "bad dtype %d", dtype);
     TVDN_REQUIRE(ndim == 3 || ndim == 4, "ndim must be 3 or 4, got %d", ndim);
@@ -780,6 +857,7 @@ extern "C" int tvdn_plan(int dtype, int ndim, const int64_t *shape, int fista, i
     size_t free_b = 0, total_b = 0;
     TVDN_HIP(hipSetDevice(device));
     TVDN_HIP(hipMemGetInfo(&free_b, &total_b));
+    free_b += kept;
     out->arrays = arrays;
     out->bytes_per_slab = slab_bytes(n_slabs);
     out->free_bytes = (int64_t)free_b;
@@ -789,6 +867,20 @@ extern "C" int tvdn_plan(int dtype, int ndim, const int64_t *shape, int fista, i
         if (slab_bytes(s) <= (int64_t)(0.9 * (double)free_b)) {
             out->min_slabs = (int32_t)s;
             break;
+        }
+    return TVDN_OK;
+}
+
+extern "C" int tvdn_release_cache(void)
+{
+    tvdn::DeviceRestore restore;
+    std::lock_guard<std::mutex> lk(tvdn::g_state_cache.mu);
+    for (int d = 0; d < TVDN_MAX_DEVICES; ++d)
+        if (tvdn::g_state_cache.p[d]) {
+            (void)hipSetDevice(d);
+            (void)hipFree(tvdn::g_state_cache.p[d]);
+            tvdn::g_state_cache.p[d] = nullptr;
+            tvdn::g_state_cache.bytes[d] = 0;
         }
     return TVDN_OK;
 }
@@ -847,6 +939,7 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
     TVDN_REQUIRE(a->bc_mode == 0 || a->bc_mode == 2, "bc_mode must be 0 or 2, got %d", a->bc_mode);
     if (a->stream_rows > 0) {
         TVDN_REQUIRE(a->n_devices <= 1, "a streamed run uses one device (slabs x streaming: cytvdn_amd.denoise_slabs(staged=...))");
+        (void)tvdn_release_cache();  // a streamed run takes most of the HBM for its rings: nothing is kept beside it
         return tvdn::run_streamed(a, a->stream_rows, a->stream_k);
     }
     {   // say clearly when the slabs cannot fit, instead of failing somewhere inside hipMalloc
@@ -870,6 +963,7 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
             const int rc2 = tvdn::choose_stream_shape(a->ndim, a->shape[0], row_bytes, (size_t)pl.free_bytes,
                                                       a->mse_out && a->reference, true, &rows, &k);
             if (rc2) return rc2;
+            (void)tvdn_release_cache();
             return tvdn::run_streamed(a, rows, k);
         }
         if (over) {
@@ -880,6 +974,7 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
             return TVDN_ERR_UNSUPPORTED;
         }
     }
+    if ((a->n_devices > 1) || a->workspace) (void)tvdn_release_cache();  // several slabs / the caller's own memory: no use for a kept block
     tvdn::RunClock clk;
     const int rc = tvdn::run_impl(a, clk);
     clk.mark("release");

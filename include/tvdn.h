@@ -295,6 +295,14 @@ typedef struct tvdn_run_args {
 
 int tvdn_run(const tvdn_run_args *args);
 
+/* A resident one-device tvdn_run that allocates its own state KEEPS that block when it returns (one per device) and hands
+ * it to the next such run it fits (same size, or up to a quarter larger than needed): releasing and re-allocating tens of
+ * GiB in quick succession costs about 0.7 s per hipMalloc and 1.1 s per hipFree on this platform, with single stalls of
+ * several seconds, i.e. more than a 50-iteration run itself.  tvdn_plan counts the kept block as free; streamed runs,
+ * device lists and runs with a `workspace` release it first.  tvdn_release_cache() hands it back to the driver at any
+ * time (always TVDN_OK); the environment variable TVDN_KEEP_STATE=0 never keeps one. */
+int tvdn_release_cache(void);
+
 /* Bytes of device memory the state of a resident one-device run of these args takes (dtype, ndim, shape, n_fista > 0
  * are read): what tvdn_run allocates itself, or expects behind tvdn_run_args.workspace.  Pure host arithmetic. */
 int tvdn_run_workspace_bytes(const tvdn_run_args *args, int64_t *bytes);

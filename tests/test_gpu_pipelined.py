@@ -271,3 +271,37 @@ def test_concurrent_calls_from_threads(shape, its):
         t.join()
     assert not errors, errors
     assert all(g == w for gs, w in zip(got, want) for g in gs)
+
+
+def test_the_state_block_is_kept_between_runs_without_a_workspace(oracle, monkeypatch):
+    """A C caller that brings no workspace: tvdn_run keeps the state block of its last resident run (one per device) for the
+    next one -- visible as HBM that stays in use after the call and comes back with tvdn_release_cache() --, reuses it for
+    a run that fits, replaces it for one that does not, never keeps one under TVDN_KEEP_STATE=0; the results are the oracle's."""
+    import torch
+    from test_gpu_run_streamed import _oracle, _run
+    from cytvdn_amd import _lib, synth
+    L = _lib.lib()
+    dt = np.dtype(np.float32)
+    mu = np.array([1.0, 0.8, 0.5, 0.6], dt)
+    big = synth.cube((64, 16, 64, 64), seed=5, dtype=dt) + dt.type(0.25)        # 16 MiB arrays: 240 MiB of state
+    small = synth.cube((8, 4, 8, 16), seed=6, dtype=dt) + dt.type(0.25)
+    assert L.tvdn_release_cache() == 0
+    torch.cuda.empty_cache()
+
+    def free():
+        torch.cuda.synchronize()
+        return int(torch.cuda.mem_get_info(0)[0])
+
+    f0 = free()
+    ref_big, ref_small = _oracle(oracle, big, mu, 3, 0), _oracle(oracle, small, mu, 3, 2)
+    assert bits_equal(_run(big, mu, 3, 0)[0], ref_big["recon"])
+    held = f0 - free()
+    assert 200 << 20 <= held <= 320 << 20                                        # the 15 x 16 MiB state is still allocated
+    assert bits_equal(_run(big, mu, 3, 0)[0], ref_big["recon"])                  # ... and serves the next run
+    assert abs((f0 - free()) - held) <= 8 << 20
+    assert bits_equal(_run(small, mu, 3, 2)[0], ref_small["recon"])              # too large for this one: replaced
+    assert f0 - free() <= 64 << 20
+    assert L.tvdn_release_cache() == 0 and f0 - free() <= 8 << 20
+    monkeypatch.setenv("TVDN_KEEP_STATE", "0")
+    assert bits_equal(_run(big, mu, 3, 0)[0], ref_big["recon"])
+    assert f0 - free() <= 8 << 20
