@@ -25,4 +25,4 @@ print("  " + open(os.path.join(O, "cpu_config1.json")).read().strip())
 print("  recon SHA-1 = the reference's (tests/golden/large.npz, d4e27d23...)")
 print("\nearlier in the round, same procedure: first verification of round 2's HEAD + hardening (r3a-r3e): 800 passed, 9 skipped;\n"
       "after the launch heuristics / buffer addressing: 801; with the Python pipelined transfers: 816; with tvdn_run's own pipelining,\n"
-      "progress callback and workspace: 834-854.")
+      "progress callback and workspace: 834-855.")
