@@ -29,7 +29,7 @@ EXPORTS = (
     "tvdn_ctx_timing_enable", "tvdn_ctx_timing_read", "tvdn_ctx_timing_read_each",
     "tvdn_accumulator_update", "tvdn_datacube_update", "tvdn_sum_square_error", "tvdn_iterate_fused",
     "tvdn_synth_fill", "tvdn_run", "tvdn_pipeline_plan", "tvdn_run_workspace_bytes", "tvdn_release_cache", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many", "tvdn_plan", "tvdn_copy_many", "tvdn_stream_mix", "tvdn_stream_mix_march",
-    "tvdn_stream_host_need", "tvdn_fista_ratios", "tvdn_iter_mode", "tvdn_roles_bind", "tvdn_roles_advance",
+    "tvdn_stream_host_need", "tvdn_stream_plan", "tvdn_fista_ratios", "tvdn_iter_mode", "tvdn_roles_bind", "tvdn_roles_advance",
 )
 
 
@@ -68,6 +68,27 @@ class PlanOut(C.Structure):
                 ("fits", C.c_int32), ("min_slabs", C.c_int32)]
 
 
+class RunStats(C.Structure):
+    """struct tvdn_run_stats (include/tvdn.h, ABI 6)."""
+    _fields_ = [
+        ("engine", C.c_int32), ("pipelined", C.c_int32), ("stream_rows", C.c_int32), ("stream_k", C.c_int32),
+        ("resident_rows", C.c_int64), ("n_passes", C.c_int64), ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64),
+        ("setup_s", C.c_double), ("loop_s", C.c_double), ("total_s", C.c_double),
+        ("audition_n", C.c_int32), ("audition_kept", C.c_int32), ("audition_ms", C.c_double * 8),
+    ]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "audition_ms"}
+        d["audition_ms"] = [round(v, 4) for v in self.audition_ms[:max(0, min(8, self.audition_n))]]
+        return d
+
+
+class StreamPlanOut(C.Structure):
+    """struct tvdn_stream_plan_out (include/tvdn.h, ABI 6)."""
+    _fields_ = [("rows", C.c_int64), ("k", C.c_int64), ("resident_rows", C.c_int64), ("hbm_bytes", C.c_int64),
+                ("host_bytes", C.c_int64)]
+
+
 class RunArgs(C.Structure):
     """struct tvdn_run_args (include/tvdn.h)."""
     _fields_ = [
@@ -84,6 +105,8 @@ class RunArgs(C.Structure):
         ("progress_user", C.c_void_p),
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_int64),
+        ("stats", C.c_void_p),
+        ("stream_resident", C.c_int64),
     ]
 
 
@@ -137,6 +160,7 @@ def lib():
                                         C.c_int32, C.c_void_p]
     L.tvdn_synth_fill.argtypes = [C.c_int, C.c_int, i64p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     L.tvdn_stream_host_need.argtypes = [C.POINTER(RunArgs), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.tvdn_stream_plan.argtypes = [C.POINTER(RunArgs), C.c_int64, C.POINTER(StreamPlanOut)]
     L.tvdn_fista_ratios.argtypes = [C.c_int32, C.POINTER(C.c_double)]
     L.tvdn_iter_mode.argtypes = [C.c_int32, C.c_int32]
     L.tvdn_roles_bind.argtypes = [C.POINTER(ManyArgs), C.c_int32, C.c_double, C.POINTER(IterArgs)]
@@ -145,7 +169,7 @@ def lib():
     L.tvdn_pipeline_plan.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.POINTER(C.c_int32)]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header and library out of step
-    if L.tvdn_abi_version() != 5:
+    if L.tvdn_abi_version() != 6:
         raise TvdnError("libtvdn_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -214,9 +214,14 @@ int sums_defer_end(tvdn_ctx *ctx, hipStream_t s);
 // Makes room for `nblocks` partial rows (grows the scratch buffer; a growth synchronises the device once).
 int ensure_partials(tvdn_ctx *ctx, long long nblocks);
 // tvdn_stream.hip: the out-of-core branch of tvdn_run
-int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_bytes, bool mse, bool wrap, int64_t *rows_out,
-                        int64_t *k_out);
-int run_streamed(const tvdn_run_args *a, int64_t rows, int64_t k);
+int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_bytes, bool mse, bool wrap, int n_state, bool may_keep,
+                        int64_t k_cap, int64_t *rows_out, int64_t *k_out, int64_t *res_out);
+int run_streamed(const tvdn_run_args *a, int64_t rows, int64_t k, int64_t resident_rows);
+// tvdn_run.hip: the big device block of a run is KEPT when the run ends (one per device) and handed to the next run it fits
+// (releasing and re-allocating tens of GiB in quick succession costs seconds); tvdn_release_cache() returns it
+hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, bool *reused);
+void state_release(void *p, size_t bytes, int device);
+size_t state_kept_bytes(int device);  // counts as free: the next run takes it over or releases it
 // Entry points that select a device put the calling thread's current device back before they return: a library that leaves
 // hipSetDevice(3) behind changes where the caller's next allocation (torch's, say) lands.
 struct DeviceRestore {
@@ -235,7 +240,7 @@ struct DeviceRestore {
     DeviceRestore(const DeviceRestore &) = delete;
     DeviceRestore &operator=(const DeviceRestore &) = delete;
 };
-void io_cap_lanes(int n);  // tvdn_hostio.hip: at most n staging lanes per transfer (0 = no cap)
+void io_cap_lanes(int n);  // tvdn_hostio.hip: n > 0 holds a cap of n staging lanes per transfer, 0 drops that hold (counted)
 // A non-blocking stream in a hardware-queue class of its own.  The runtime multiplexes streams onto a few hardware queues
 // per PRIORITY level; two streams that share one execute in submission order, so a transfer's completion marker can sit
 // behind every sweep already queued (tvdn_run's last iterations over the download: the first chunk's copy "took" 90 ms,

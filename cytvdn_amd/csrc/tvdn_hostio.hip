@@ -38,11 +38,23 @@ static std::mutex g_io_mutex;       // one transfer at a time per process: the b
 static HostIo g_io[16];
 
 static std::atomic<int> g_lanes_cap{0};
+static std::atomic<int> g_cap_users{0};
 
 // Transfers that run BESIDE a thread launching sweeps (tvdn_run's pipelined start and end) use fewer staging lanes: with
 // eight host threads copying through their pinned buffers the launching thread falls behind and the overlap is lost
 // (config 2, 50 iterations from host memory: 0.72-0.76 s with 8 lanes, 0.62-0.64 s with 4-6; profiles/r03_e2e_pipelined.txt).
-void io_cap_lanes(int n) { g_lanes_cap.store(n); }
+// Reference-counted: concurrent pipelined runs each hold the cap, and it lifts when the LAST of them ends (a plain
+// set/reset pair let the first run to finish lift it for the others mid-flight).  n > 0 takes a hold, n == 0 drops one.
+void io_cap_lanes(int n)
+{
+    if (n > 0) {
+        g_lanes_cap.store(n);
+        g_cap_users.fetch_add(1);
+    } else if (g_cap_users.fetch_sub(1) <= 1) {
+        g_cap_users.store(0);
+        g_lanes_cap.store(0);
+    }
+}
 
 int make_stream(hipStream_t *s, int level)
 {

@@ -49,8 +49,9 @@ static hipError_t state_malloc(void **p, size_t bytes)
 }
 
 // the kept block of `device` if it holds `bytes` without being more than a quarter larger, else a fresh allocation
-static hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device)
+hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, bool *reused)
 {
+    *reused = false;
     if (keep_state() && device >= 0 && device < TVDN_MAX_DEVICES) {
         std::lock_guard<std::mutex> lk(g_state_cache.mu);
         void *&c = g_state_cache.p[device];
@@ -60,6 +61,7 @@ static hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int d
             *got_bytes = cb;
             c = nullptr;
             cb = 0;
+            *reused = true;
             return hipSuccess;
         }
         if (c) {  // the wrong size: make room before asking for the right one
@@ -72,7 +74,14 @@ static hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int d
     return state_malloc(p, bytes);
 }
 
-static void state_release(void *p, size_t bytes, int device)
+size_t state_kept_bytes(int device)
+{
+    if (device < 0 || device >= TVDN_MAX_DEVICES) return 0;
+    std::lock_guard<std::mutex> lk(g_state_cache.mu);
+    return g_state_cache.bytes[device];
+}
+
+void state_release(void *p, size_t bytes, int device)
 {
     if (!p) return;
     if (keep_state() && device >= 0 && device < TVDN_MAX_DEVICES) {
@@ -195,8 +204,10 @@ struct RunClock {
     }
 };
 
-static int run_impl(const tvdn_run_args *a, RunClock &clk)
+static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats)
 {
+    const auto t_entry = std::chrono::steady_clock::now();
+    auto since_entry = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count(); };
     const int nd = a->ndim;
     const size_t item = a->dtype == TVDN_F32 ? 4 : 8;
     size_t plane = 1;
@@ -230,6 +241,7 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
         }
     }
     const bool exact_wrap = world > 1 && row0_bad;
+    bool state_reused = false;  // the block the last run of this device kept: an audition's winner stays the winner
     for (int r = 0; r < world; ++r) {
         Slab &s = sl[r];
         s.device = a->n_devices > 0 ? a->devices[r] : a->device;
@@ -269,7 +281,7 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
         } else {
             // one slab: the block the last run of this device left behind, if it fits (StateCache above)
             if (world == 1) {
-                TVDN_HIP(state_acquire(&s.state.p, stride * (size_t)n_arr, &s.state.bytes, s.device));
+                TVDN_HIP(state_acquire(&s.state.p, stride * (size_t)n_arr, &s.state.bytes, s.device, &state_reused));
                 s.state.keep = true;
             } else {
                 TVDN_HIP(state_malloc(&s.state.p, stride * (size_t)n_arr));
@@ -338,8 +350,10 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
     if (world == 1) {
         Slab &s = sl[0];
         const char *e = getenv("TVDN_AUDITION");
-        // a caller that brings the state's memory has chosen its placement: no audition then
-        const int want = !s.state.owned ? 1 : (e ? atoi(e) : (n_total >= 800 ? 4 : (n_total >= 400 ? 3 : 1)));
+        // a caller that brings the state's memory has chosen its placement: no audition then.  Nor when the block is the one
+        // the last run kept (if that run auditioned, this IS its winner; allocating and freeing three more blocks of tens of
+        // GiB per call is what the kept block exists to avoid) -- unless TVDN_AUDITION insists.
+        const int want = !s.state.owned ? 1 : (e ? atoi(e) : (state_reused ? 1 : (n_total >= 800 ? 4 : (n_total >= 400 ? 3 : 1))));
         const size_t bytes = (size_t)s.rows() * row_bytes;
         const size_t stride = (bytes + 255) / 256 * 256 + 4096;
         const size_t total = stride * (size_t)(3 + nd * per_axis);
@@ -374,6 +388,8 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
             TVDN_HIP(hipEventCreate(&e1));
             int rc = probe(s.state.p, &best_ms);
             if (clk.on) fprintf(stderr, "tvdn_run:   candidate 0 at %p: %.3f ms per sweep\n", s.state.p, best_ms / 2.0);
+            stats.audition_n = 1;
+            stats.audition_ms[0] = best_ms / 2.0;
             for (int c = 1; c < want && !rc; ++c) {
                 size_t free_b = 0, total_b = 0;
                 TVDN_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -388,9 +404,14 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
                 double ms = 0.0;
                 rc = probe(b->p, &ms);
                 if (clk.on) fprintf(stderr, "tvdn_run:   candidate %d at %p: %.3f ms per sweep\n", c, b->p, ms / 2.0);
+                if (!rc && c < 8) {
+                    stats.audition_ms[c] = ms / 2.0;
+                    stats.audition_n = c + 1;
+                }
                 if (!rc && ms < best_ms) {
                     best_ms = ms;
                     best = b->p;
+                    stats.audition_kept = c < 8 ? c : 0;
                 }
                 held.push_back(std::move(b));
             }
@@ -414,6 +435,7 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
     }
 
     clk.mark("placement audition");
+    stats.setup_s = since_entry();
     // ---- pipelined transfers (one device, resident) ------------------------------------------------------------------------
     // The call takes host arrays and returns one (cyTVDN.py:19-31, :244-247): 2 x the cube over PCIe around the iterations --
     // 0.17 s of the 0.75 s a 50-iteration run of BASELINE config 2 takes.  Both transfers hide under iterations that do
@@ -438,6 +460,7 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
         pipe_k1 = pl[2];
     }
     const bool pipelined = pipe_R > 0;
+    stats.pipelined = pipelined ? 1 : 0;
     struct LaneCap {  // fewer staging lanes while transfers run beside the launching thread (tvdn_hostio.hip)
         bool on;
         explicit LaneCap(bool o) : on(o) { if (on) io_cap_lanes(6); }
@@ -826,6 +849,12 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk)
         a->phase_iters[1] = ran_phase[1];
     }
     clk.mark("results home");
+    stats.engine = TVDN_ENGINE_RESIDENT;
+    stats.loop_s = since_entry() - stats.setup_s;  // upload, iterations, download (overlapped or not)
+    for (int r = 0; r < world; ++r) {
+        stats.h2d_bytes += (int64_t)sl[r].rows() * (int64_t)row_bytes * (want_mse ? 2 : 1);
+        stats.d2h_bytes += (int64_t)(sl[r].g1 - sl[r].g0) * (int64_t)row_bytes;
+    }
     return TVDN_OK;
 }
 
@@ -939,8 +968,7 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
     TVDN_REQUIRE(a->bc_mode == 0 || a->bc_mode == 2, "bc_mode must be 0 or 2, got %d", a->bc_mode);
     if (a->stream_rows > 0) {
         TVDN_REQUIRE(a->n_devices <= 1, "a streamed run uses one device (slabs x streaming: cytvdn_amd.denoise_slabs(staged=...))");
-        (void)tvdn_release_cache();  // a streamed run takes most of the HBM for its rings: nothing is kept beside it
-        return tvdn::run_streamed(a, a->stream_rows, a->stream_k);
+        return tvdn::run_streamed(a, a->stream_rows, a->stream_k, a->stream_resident);
     }
     {   // say clearly when the slabs cannot fit, instead of failing somewhere inside hipMalloc
         const int world = a->n_devices > 0 ? a->n_devices : 1;
@@ -959,12 +987,12 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
             // touches the caller's arrays, what the host cannot hold either)
             size_t row_bytes = a->dtype == TVDN_F32 ? 4 : 8;
             for (int i = 1; i < a->ndim; ++i) row_bytes *= (size_t)a->shape[i];
-            int64_t rows = 0, k = 0;
-            const int rc2 = tvdn::choose_stream_shape(a->ndim, a->shape[0], row_bytes, (size_t)pl.free_bytes,
-                                                      a->mse_out && a->reference, true, &rows, &k);
+            int64_t rows = 0, k = 0, res = 0;
+            const bool keep = a->bc_mode == TVDN_BC_JIA_ZHAO && !(a->mse_out && a->reference) && a->stream_resident != 0;
+            const int rc2 = tvdn::choose_stream_shape(a->ndim, a->shape[0], row_bytes, (size_t)pl.free_bytes, a->mse_out && a->reference, true,
+                                                      a->n_fista > 0 ? 2 : 1, keep, a->use_stop ? 1 : a->n_fista + a->n_plain, &rows, &k, &res);
             if (rc2) return rc2;
-            (void)tvdn_release_cache();
-            return tvdn::run_streamed(a, rows, k);
+            return tvdn::run_streamed(a, rows, k, a->stream_resident > 0 ? a->stream_resident : (keep ? res : 0));
         }
         if (over) {
             tvdn::set_error("state of %lld bytes per slab x %d slab(s) on device %d exceeds 90 %% of its %lld free bytes of HBM: use more "
@@ -976,7 +1004,14 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
     }
     if ((a->n_devices > 1) || a->workspace) (void)tvdn_release_cache();  // several slabs / the caller's own memory: no use for a kept block
     tvdn::RunClock clk;
-    const int rc = tvdn::run_impl(a, clk);
+    const auto t0 = std::chrono::steady_clock::now();
+    tvdn_run_stats stats;
+    std::memset(&stats, 0, sizeof stats);
+    const int rc = tvdn::run_impl(a, clk, stats);
     clk.mark("release");
+    if (!rc && a->stats) {
+        stats.total_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        *a->stats = stats;
+    }
     return rc;
 }

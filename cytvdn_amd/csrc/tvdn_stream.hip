@@ -6,11 +6,17 @@
 // tvdn_iterate_fused launches, so the bits are those of the resident engine.  Upstream has no counterpart: its
 // arrays never leave the host (cyTVDN/cyTVDN.py:148-242 is the loop this replaces for cubes beyond HBM).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
+#include <string>
 #include <thread>
 
+#include <sys/mman.h>
 #include <unistd.h>
 
 #include "tvdn_common.hpp"
@@ -39,39 +45,143 @@ void parallel_copy(void *dst, const void *src, size_t bytes)  // src == nullptr:
     for (int i = 0; i < n; ++i) th[i].join();
 }
 
-// A cube-sized host array the GPU can reach: the caller's own memory page-locked in place when the runtime allows
-// it, otherwise a pinned allocation (filled from / copied back to the caller's array by the user of this struct).
+// Touch every page of [p, p + bytes) from `threads` threads (writing back what is read: contents are kept).
+void touch_pages(char *p, size_t bytes, int threads)
+{
+    if (!bytes) return;
+    const size_t piece = ((bytes + threads - 1) / threads + 4095) / 4096 * 4096;
+    std::vector<std::thread> th;
+    for (size_t off = 0; off < bytes; off += piece) {
+        const size_t len = std::min(piece, bytes - off);
+        th.emplace_back([=] {
+            volatile char *q = p + off;
+            for (size_t o = 0; o < len; o += 4096) q[o] = q[o];
+            q[len - 1] = q[len - 1];
+        });
+    }
+    for (auto &t : th) t.join();
+}
+
+int touch_threads()
+{
+    const unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(16u, hc ? hc : 4u));
+}
+
+// Releases of pinned memory run on detached threads (unregistering and unmapping 16 GiB takes 0.8 s; a run that held 144 GiB
+// would spend 7 s returning it): the next streamed run waits for them before it counts the host's memory.
+std::atomic<int> g_releases_pending{0};
+
+void wait_for_releases()
+{
+    while (g_releases_pending.load() > 0) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+}
+
+// Page-locked host memory the library owns.  Large buffers are anonymous memory with huge pages asked for, first touched by
+// many threads, page-locked with ONE registration: 16 GiB in 0.13 s on the MI355X boxes of this pool, where hipHostMalloc of
+// the same size takes 3.0 s and hipHostFree 2.0 s (tools/ubench/pin_probe.hip, profiles/r04_pin_probe.jsonl) -- page-locking
+// used to be most of a streamed run's set-up.  Same PCIe rate either way (57.6 GB/s one way).
+struct PinnedBuf {
+    char *p = nullptr;
+    size_t bytes = 0;
+    bool mapped = false;
+    int alloc(size_t b)
+    {
+        bytes = b;
+        if (b >= (size_t(8) << 20) && !getenv("TVDN_PIN_HIPMALLOC")) {
+            void *m = mmap(nullptr, b, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (m != MAP_FAILED) {
+                (void)madvise(m, b, MADV_HUGEPAGE);
+                touch_pages((char *)m, b, touch_threads());
+                if (hipHostRegister(m, b, hipHostRegisterDefault) == hipSuccess) {
+                    p = (char *)m;
+                    mapped = true;
+                    return TVDN_OK;
+                }
+                (void)hipGetLastError();
+                (void)munmap(m, b);
+            }
+        }
+        TVDN_HIP(hipHostMalloc((void **)&p, b ? b : 1, hipHostMallocDefault));
+        return TVDN_OK;
+    }
+    void release()
+    {
+        if (!p) return;
+        char *q = p;
+        const size_t b = bytes;
+        const bool m = mapped;
+        p = nullptr;
+        auto job = [q, b, m] {
+            if (m) {
+                (void)hipHostUnregister(q);
+                (void)munmap(q, b);
+            } else {
+                (void)hipHostFree(q);
+            }
+        };
+        if (b >= (size_t(1) << 30)) {  // big: in the background
+            g_releases_pending.fetch_add(1);
+            std::thread([job] {
+                job();
+                g_releases_pending.fetch_sub(1);
+            }).detach();
+        } else {
+            job();
+        }
+    }
+    ~PinnedBuf() { release(); }
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+};
+
+// A cube-shaped host array the GPU can reach.  Either the caller's own memory page-locked in place (`cube_rows`: row g of the
+// cube at p + g * row_bytes), or pinned memory of the library's holding ONLY the rows that stay on the host, packed (the h-th
+// host row at p + h * row_bytes), filled from / copied back to the caller's array by the user of this struct.
 struct HostArr {
     char *p = nullptr;
-    bool registered = false, owned = false;
-    int pin_in_place(void *user, size_t bytes)
+    bool registered = false, owned = false, cube_rows = false;
+    PinnedBuf buf;
+    // `fresh`: the array's contents do not matter yet (the result array): its pages are touched first, with huge pages asked
+    // for, so that the registration finds them in place (registering untouched memory faults it in page by page: 1.4 s per
+    // 16 GiB against 0.1 + 0.04 s)
+    int pin_in_place(void *user, size_t bytes, size_t packed_bytes, bool fresh)
     {
         // Only arrays big enough to own their pages: page-locking works on whole pages, and two small arrays of the
         // caller may share one (overlapping registrations).  Small cubes are staged through pinned copies instead.
-        if (bytes < kPinInPlaceMin) return alloc(bytes);
+        if (bytes < kPinInPlaceMin) return alloc(packed_bytes);
+        if (fresh) {
+            const uintptr_t lo = ((uintptr_t)user + (size_t(2) << 20) - 1) & ~((uintptr_t)(size_t(2) << 20) - 1);
+            const uintptr_t hi = ((uintptr_t)user + bytes) & ~((uintptr_t)(size_t(2) << 20) - 1);
+            if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
+            touch_pages((char *)user, bytes, touch_threads());
+        }
         const hipError_t e = hipHostRegister(user, bytes, hipHostRegisterDefault);
         if (e == hipSuccess) {
             p = (char *)user;
-            registered = true;
+            registered = cube_rows = true;
             return TVDN_OK;
         }
         (void)hipGetLastError();
         if (e == hipErrorHostMemoryAlreadyRegistered) {  // already page-locked by the caller
             p = (char *)user;
+            cube_rows = true;
             return TVDN_OK;
         }
-        return alloc(bytes);
+        return alloc(packed_bytes);
     }
-    int alloc(size_t bytes)
+    int alloc(size_t packed_bytes)
     {
-        TVDN_HIP(hipHostMalloc((void **)&p, bytes, hipHostMallocDefault));
+        const int rc = buf.alloc(packed_bytes);
+        if (rc) return rc;
+        p = buf.p;
         owned = true;
         return TVDN_OK;
     }
     ~HostArr()
     {
         if (registered) (void)hipHostUnregister(p);
-        if (owned) (void)hipHostFree(p);
     }
 };
 
@@ -121,6 +231,24 @@ struct DevMem {
     }
 };
 
+// "64G" / "512M" / bytes from the environment; 0 = not set
+size_t env_bytes(const char *name)
+{
+    const char *e = getenv(name);
+    if (!e) return 0;
+    char *end = nullptr;
+    double v = strtod(e, &end);
+    if (end == e || v <= 0) return 0;
+    switch (*end) {
+    case 'K': case 'k': v *= 1024.0; break;
+    case 'M': case 'm': v *= 1024.0 * 1024.0; break;
+    case 'G': case 'g': v *= 1024.0 * 1024.0 * 1024.0; break;
+    case 'T': case 't': v *= 1024.0 * 1024.0 * 1024.0 * 1024.0; break;
+    default: break;
+    }
+    return (size_t)v;
+}
+
 // Host memory a streamed run may count on: what the kernel calls available, never more than the machine has, and
 // never more than the memory limit of the process's control group (the limit itself, not limit minus usage: the
 // usage counts page cache the kernel would give back, and a false refusal helps nobody; the check is there to stop
@@ -153,20 +281,8 @@ size_t host_available_bytes()
     unsigned long long lim = 0;
     if (read_num("/sys/fs/cgroup/memory.max", &lim) || read_num("/sys/fs/cgroup/memory/memory.limit_in_bytes", &lim))
         if (lim > 0 && (size_t)lim < avail) avail = (size_t)lim;
-    if (const char *e = getenv("TVDN_HOST_LIMIT")) {  // a cap from outside, "64G" / "512M" / bytes (the test-suite sets one)
-        char *end = nullptr;
-        double v = strtod(e, &end);
-        if (end != e && v > 0) {
-            switch (*end) {
-            case 'K': case 'k': v *= 1024.0; break;
-            case 'M': case 'm': v *= 1024.0 * 1024.0; break;
-            case 'G': case 'g': v *= 1024.0 * 1024.0 * 1024.0; break;
-            case 'T': case 't': v *= 1024.0 * 1024.0 * 1024.0 * 1024.0; break;
-            default: break;
-            }
-            if (v < (double)avail) avail = (size_t)v;
-        }
-    }
+    const size_t cap = env_bytes("TVDN_HOST_LIMIT");  // a cap from outside, "64G" / "512M" / bytes (the test-suite sets one)
+    if (cap && cap < avail) avail = cap;
     return avail;
 }
 
@@ -187,29 +303,49 @@ int copy_rows(std::vector<void *> &dst, std::vector<void *> &src, size_t row_byt
 
 }  // namespace
 
-// Rows of HBM (planes) the schedule keeps resident: planner.wavefront_windows of the Python side.
+// Rows of HBM (planes) the schedule keeps besides the resident rows: rings of R+2 rows per level and array, the data-term
+// ring(s), the staging boxes, the planes of an exact Jia-Zhao wrap and one plane of zeros (planner.wavefront_windows of the
+// Python side).
 static int64_t stream_planes(int nd, int64_t rows, int64_t k, bool mse, bool wrap)
 {
-    return ((k + 1) + (k + 2) * nd) * (rows + 2) + (rows + k + 3) * (mse ? 2 : 1) + 2 * (3 + 4 * nd) * rows + (wrap ? k + 1 : 0);
+    return ((k + 1) + (k + 2) * nd) * (rows + 2) + (rows + k + 3) * (mse ? 2 : 1) + 2 * (3 + 4 * nd) * rows + (wrap ? k + 1 : 0) + 1;
 }
 
-// Chunk height and depth: the deepest k (<= 128) whose rings and staging boxes fit 85 % of the free HBM, taller chunks on
-// ties.  Every byte the run allocates on the device is in that count; on PCIe-bound shapes depth IS speed (256 MiB planes:
-// k = 30 / 38 / 44 -> 28.4 / 33.6 / 37.0 Gvoxel-iters/s, profiles/r03_outofcore_depth.jsonl), so the budget is generous.
-// (a streamed pass is PCIe-bound until k ~ 100: cytvdn_amd/planner.py).
-int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_bytes, bool mse, bool wrap, int64_t *rows_out,
-                        int64_t *k_out)
+// Chunk height R, depth K and the number of low rows whose state STAYS in HBM between passes (the resident + streamed hybrid).
+// A pass costs max(PCIe time of the streamed rows, sweep time of all rows + the device copies of the resident rows); the
+// choice minimises that per iteration over every (R, K) whose rings fit 85 % of the free HBM, the rows kept being what the
+// rest of that budget holds (2 + nd x n_state arrays per row: data term, recon, accumulator state).  Without kept rows this is
+// "the deepest K": a streamed pass is PCIe-bound until K ~ 100 (256 MiB planes: K = 30 / 38 / 44 -> 28.4 / 33.6 / 37.0
+// Gvoxel-iters/s, profiles/r03_outofcore_depth.jsonl).  With them, depth and kept rows compete for the same HBM and the
+// model decides: rates measured on MI355X -- both PCIe directions together 60 GB/s through the runtime's copies, the sweep
+// on rings at 0.82 x 5.6 TB/s of moved bytes, device copies at 4.8 TB/s.
+int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_bytes, bool mse, bool wrap, int n_state, bool may_keep,
+                        int64_t k_cap, int64_t *rows_out, int64_t *k_out, int64_t *res_out)
 {
     const int64_t budget = (int64_t)(0.85 * (double)free_bytes / (double)row_bytes);
-    int64_t best_k = 0, best_r = 0;
+    const double rb = (double)row_bytes;
+    const int n_in = 2 + nd * n_state, n_out = 1 + nd * n_state, moved = 3 + nd * (n_state + 1);
+    k_cap = std::max<int64_t>(1, std::min<int64_t>({k_cap, 128, std::max<int64_t>(1, n_rows)}));
+    int64_t best_k = 0, best_r = 0, best_res = 0;
+    double best_t = 0.0;
     for (int64_t r : {32, 16, 8, 4, 2}) {
         r = std::min<int64_t>(r, std::max<int64_t>(2, n_rows));
-        const int64_t slope = stream_planes(nd, r, 2, mse, wrap) - stream_planes(nd, r, 1, mse, wrap);
-        int64_t k = (budget - stream_planes(nd, r, 0, mse, wrap)) / slope;
-        k = std::min<int64_t>({k, 128, std::max<int64_t>(1, n_rows)});
-        if (k >= 1 && stream_planes(nd, r, k, mse, wrap) <= budget && k > best_k) {
-            best_k = k;
-            best_r = r;
+        // sweeps on rings, launches of r rows: 0.86 ms per 256 MiB plane and level whether r is 2, 4 or 8 (83 % of the resident
+        // sweep's rate; all rows resident, profiles/r04_stream_rates.jsonl)
+        const double eff = 0.82;
+        for (int64_t k = 1; k <= k_cap; ++k) {
+            const int64_t planes = stream_planes(nd, r, k, mse, wrap);
+            if (planes > budget) break;
+            const int64_t res = may_keep ? std::min<int64_t>(n_rows, (budget - planes) / n_in) : 0;
+            const double t_pcie = (double)(n_rows - res) * (n_in + n_out) * rb / 60e9;
+            const double t_gpu = (double)n_rows * (double)k * moved * rb / (5.6e12 * eff) + (double)res * (n_in + n_out) * 2.0 * rb / 4.8e12;
+            const double t = std::max(t_pcie, t_gpu) / (double)k;
+            if (best_k == 0 || t < best_t * 0.999) {
+                best_t = t;
+                best_k = k;
+                best_r = r;
+                best_res = res;
+            }
         }
     }
     if (best_k < 1) {
@@ -219,17 +355,12 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
     }
     *rows_out = best_r;
     *k_out = best_k;
+    *res_out = best_res;
     return TVDN_OK;
 }
 
-}  // namespace tvdn
-
-// Host side of a streamed run, as arithmetic only (no HIP call, no device needed, nothing of the caller's dereferenced):
-// the page-locked bytes it would hold -- the data term, recon (= recon_out), the reference when an MSE trace is asked
-// for, one or two accumulator-state arrays per axis, and one more cube when `data` overlaps `recon_out` (the data term
-// then needs its own copy) -- against what the host may give (MemAvailable, physical memory, the control group's
-// limit, TVDN_HOST_LIMIT), of which a streamed run takes 80 % at most.
-extern "C" int tvdn_stream_host_need(const tvdn_run_args *a, int64_t *need_bytes, int64_t *avail_bytes)
+// Page-locked host bytes of a streamed run that keeps the state of `res` low rows in HBM, and what the host may give.
+static int stream_host_need(const tvdn_run_args *a, int64_t res, int64_t *need_bytes, int64_t *avail_bytes)
 {
     TVDN_REQUIRE(a != nullptr, "args is NULL");
     TVDN_REQUIRE(a->dtype == TVDN_F32 || a->dtype == TVDN_F64, "bad dtype %d", a->dtype);
@@ -243,28 +374,193 @@ extern "C" int tvdn_stream_host_need(const tvdn_run_args *a, int64_t *need_bytes
     }
     const int n_state = a->n_fista > 0 ? 2 : 1;
     const bool want_mse = a->mse_out != nullptr && a->reference != nullptr;
-    const bool aliased = a->data && a->recon_out && cube < 9.0e18 && tvdn::arrays_overlap(a->data, a->recon_out, cube_b);
+    const bool aliased = a->data && a->recon_out && cube < 9.0e18 && arrays_overlap(a->data, a->recon_out, cube_b);
     // periodic boundaries: the rows at one end are the other end's halo, uploaded late in a pass that has already sent
     // their new values home -- old and new state are then two sets of arrays instead of one updated in place
     const int twice = a->bc_mode == TVDN_BC_PERIODIC ? 2 : 1;
-    const double need = (double)((a->ndim * n_state + 1) * twice + 1 + (want_mse ? 1 : 0) + (aliased ? 1 : 0)) * cube;
-    const size_t avail = tvdn::host_available_bytes();
+    const double share = res <= 0 ? 1.0 : (res >= a->shape[0] ? 0.0 : (double)(a->shape[0] - res) / (double)a->shape[0]);
+    const double need = (double)((a->ndim * n_state + 1) * twice + 1 + (want_mse ? 1 : 0) + (aliased ? 1 : 0)) * cube * share;
+    const size_t avail = host_available_bytes();
     if (need_bytes) *need_bytes = need < 9.0e18 ? (int64_t)need : INT64_MAX;
     if (avail_bytes) *avail_bytes = (int64_t)avail;
-    if (avail == 0 || need > 0.8 * (double)avail) {
-        tvdn::set_error("a streamed run of this cube needs %.0f bytes of page-locked host memory, which exceeds what the host has "
-                        "available (%zu bytes, of which 80 %% are used at most): cut it into slabs over several nodes (cytvdn_amd.plan_run)",
-                        need, avail);
+    if (need > 0.0 && (avail == 0 || need > 0.8 * (double)avail)) {
+        set_error("a streamed run of this cube needs %.0f bytes of page-locked host memory, which exceeds what the host has "
+                  "available (%zu bytes, of which 80 %% are used at most): cut it into slabs over several nodes (cytvdn_amd.plan_run)",
+                  need, avail);
         return TVDN_ERR_UNSUPPORTED;
     }
     return TVDN_OK;
 }
 
+}  // namespace tvdn
+
+// Host side of a streamed run, as arithmetic only (no HIP call, no device needed, nothing of the caller's dereferenced):
+// the page-locked bytes it would hold -- the data term, recon (= recon_out), the reference when an MSE trace is asked
+// for, one or two accumulator-state arrays per axis, and one more cube when `data` overlaps `recon_out` (the data term
+// then needs its own copy) -- against what the host may give (MemAvailable, physical memory, the control group's
+// limit, TVDN_HOST_LIMIT), of which a streamed run takes 80 % at most.  The figure is the one of a run that keeps NO rows
+// resident in HBM (stream_resident = 0): an upper bound for the others.
+extern "C" int tvdn_stream_host_need(const tvdn_run_args *a, int64_t *need_bytes, int64_t *avail_bytes)
+{
+    return tvdn::stream_host_need(a, 0, need_bytes, avail_bytes);
+}
+
+// What a streamed tvdn_run of these args would choose with `hbm_free_bytes` of HBM to work with (<= 0: ask args->device):
+// chunk height, depth, resident rows; the HBM bytes of rings + boxes + resident rows; the page-locked host bytes.  Pure
+// arithmetic when hbm_free_bytes is given (no device needed): cytvdn_amd/planner.py plans with it.
+extern "C" int tvdn_stream_plan(const tvdn_run_args *a, int64_t hbm_free_bytes, tvdn_stream_plan_out *out)
+{
+    using namespace tvdn;
+    TVDN_REQUIRE(a != nullptr && out != nullptr, "NULL argument");
+    TVDN_REQUIRE(a->dtype == TVDN_F32 || a->dtype == TVDN_F64, "bad dtype %d", a->dtype);
+    TVDN_REQUIRE(a->ndim == 3 || a->ndim == 4, "ndim must be 3 or 4, got %d", a->ndim);
+    size_t row_bytes = a->dtype == TVDN_F32 ? 4 : 8;
+    for (int i = 0; i < a->ndim; ++i) {
+        TVDN_REQUIRE(a->shape[i] >= 1, "shape[%d] must be >= 1", i);
+        if (i) row_bytes *= (size_t)a->shape[i];
+    }
+    if (hbm_free_bytes <= 0) {
+        DeviceRestore restore;
+        size_t free_b = 0, total_b = 0;
+        TVDN_HIP(hipSetDevice(a->n_devices > 0 ? a->devices[0] : a->device));
+        TVDN_HIP(hipMemGetInfo(&free_b, &total_b));
+        hbm_free_bytes = (int64_t)free_b;
+    }
+    const bool mse = a->mse_out != nullptr && a->reference != nullptr;
+    const int n_state = a->n_fista > 0 ? 2 : 1;
+    const bool keep = a->bc_mode == TVDN_BC_JIA_ZHAO && !mse && a->stream_resident != 0;
+    int64_t rows = 0, k = 0, res = 0;
+    const int n_total = a->n_fista + a->n_plain;
+    const int rc = choose_stream_shape(a->ndim, a->shape[0], row_bytes, (size_t)hbm_free_bytes, mse, true, n_state, keep,
+                                       a->use_stop ? 1 : (n_total > 0 ? n_total : 128), &rows, &k, &res);
+    if (rc) return rc;
+    if (a->stream_resident > 0) res = std::min<int64_t>(res, a->stream_resident);
+    out->rows = rows;
+    out->k = k;
+    out->resident_rows = res;
+    out->hbm_bytes = (stream_planes(a->ndim, rows, k, mse, true) + res * (2 + a->ndim * n_state)) * (int64_t)row_bytes;
+    int64_t need = 0, avail = 0;
+    (void)stream_host_need(a, res, &need, &avail);
+    out->host_bytes = need;
+    return TVDN_OK;
+}
+
 namespace tvdn {
 
-int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
+namespace {
+
+// Which rows of axis 0 keep their state in HBM between the passes: `res` of the n0 rows, spread EVENLY over the cube
+// (row g is one of them when floor((g+1) res / n0) > floor(g res / n0)), so that every chunk of a pass has the same share of
+// rows that cross PCIe and the transfers of one chunk hide under the sweeps of the one before.  (With the resident rows in
+// one piece at the low end, the rest of a pass is PCIe-bound chunk after chunk while the link idles under the resident ones:
+// 35 Gvoxel-iters/s on config-5 planes where the evenly spread rows give XX; profiles/r04_stream_rates.jsonl.)
+struct RowMap {
+    int64_t n0 = 1, res = 0;
+    int64_t res_below(int64_t g) const { return res >= n0 ? g : g * res / n0; }  // resident rows among [0, g)
+    bool resident(int64_t g) const { return res_below(g + 1) > res_below(g); }
+    int64_t host_below(int64_t g) const { return g - res_below(g); }             // host rows among [0, g)
+    int64_t host_rows() const { return n0 - res; }
+};
+
+// Accumulator-state rows that live on the host, in pinned memory allocated BLOCK BY BLOCK (in row order) by a helper thread
+// while the first pass is already running: the first pass writes these rows long before any pass reads them.  Indexed by
+// HOST SLOT (the h-th row that lives on the host), not by cube row.
+struct StateBlocks {
+    int n_arr = 0;
+    int64_t n_slots = 0, block_rows = 1;
+    size_t row_bytes = 0;
+    std::vector<std::unique_ptr<PinnedBuf>> blocks;  // one pinned allocation per block: n_arr x block_rows rows, array-major
+    std::mutex mu;
+    std::condition_variable cv;
+    int64_t ready = 0;  // blocks [0, ready) exist
+    int failed = 0;
+    std::string fail_msg;
+    int64_t n_blocks() const { return (n_slots + block_rows - 1) / block_rows; }
+    int64_t block_of(int64_t h) const { return h / block_rows; }
+    int64_t block_end(int64_t h) const { return std::min(n_slots, (block_of(h) + 1) * block_rows); }  // first slot of the next block
+    char *row(int arr, int64_t h) const
+    {
+        const int64_t b = block_of(h);
+        return blocks[(size_t)b]->p + ((size_t)arr * (size_t)block_rows + (size_t)(h - b * block_rows)) * row_bytes;
+    }
+    int allocate(int64_t b)  // helper thread
+    {
+        std::unique_ptr<PinnedBuf> pb(new PinnedBuf);
+        const int rc = pb->alloc((size_t)n_arr * (size_t)block_rows * row_bytes);
+        std::lock_guard<std::mutex> lk(mu);
+        if (rc) {
+            failed = rc;
+            fail_msg = std::string("page-locking a block of host state failed: ") + tvdn_last_error();
+        } else {
+            blocks[(size_t)b] = std::move(pb);
+            ready = b + 1;
+        }
+        cv.notify_all();
+        return failed;
+    }
+    int wait_for(int64_t h)  // calling thread: until the block of host slot h exists
+    {
+        const int64_t b = block_of(h);
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return failed || ready > b; });
+        if (failed) {
+            set_error("%s", fail_msg.c_str());
+            return failed;
+        }
+        return TVDN_OK;
+    }
+    void fail(int rc, const std::string &msg)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!failed) {
+            failed = rc;
+            fail_msg = msg;
+        }
+        cv.notify_all();
+    }
+};
+
+// A one-shot flag a helper thread raises (with an error, if any)
+struct Flag {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool up = false;
+    int rc = TVDN_OK;
+    std::string msg;
+    void raise(int rc_ = TVDN_OK, const std::string &m = std::string())
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (up) return;
+        up = true;
+        rc = rc_;
+        msg = m;
+        cv.notify_all();
+    }
+    int wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return up; });
+        if (rc) set_error("%s", msg.c_str());
+        return rc;
+    }
+};
+
+struct Joiner {
+    std::thread &t;
+    ~Joiner()
+    {
+        if (t.joinable()) t.join();
+    }
+};
+
+}  // namespace
+
+// R rows per chunk, K iteration levels per pass; `res_req` rows keep their state in HBM between passes (-1: as many as fit
+// beside the rings in 85 % of the free HBM, 0: none).
+int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
 {
     const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     const int nd = a->ndim;
     const size_t item = a->dtype == TVDN_F32 ? 4 : 8;
     size_t plane = 1;
@@ -280,6 +576,27 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
     const bool periodic = a->bc_mode == TVDN_BC_PERIODIC;
     TVDN_REQUIRE(periodic || a->bc_mode == TVDN_BC_JIA_ZHAO, "the streamed tvdn_run handles bc_mode 0 and 2");
     TVDN_REQUIRE(R >= 1 && K >= 1, "stream_rows and stream_k must be >= 1");
+    TVDN_REQUIRE(res_req >= -1, "stream_resident must be -1 (as many rows as fit), 0 (none) or a row count");
+    const bool aliased = arrays_overlap(a->data, a->recon_out, cube_bytes);
+    if (n_total == 0) {  // nothing to iterate: recon = datacube.copy() (cyTVDN.py:145)
+        if (a->recon_out != a->data) std::memmove(a->recon_out, a->data, cube_bytes);
+        if (want_mse) {  // MSE[0] on the host in f64 (a corner nobody times)
+            double t = 0.0;
+            for (size_t i = 0; i < (size_t)N0 * plane; ++i) {
+                const double d = a->dtype == TVDN_F32 ? (double)((const float *)a->data)[i] - (double)((const float *)a->reference)[i]
+                                                      : ((const double *)a->data)[i] - ((const double *)a->reference)[i];
+                t += d * d;
+            }
+            a->mse_out[0] = t;
+        }
+        if (a->iters_run) *a->iters_run = 0;
+        if (a->phase_iters) a->phase_iters[0] = a->phase_iters[1] = 0;
+        if (a->stats) {
+            std::memset(a->stats, 0, sizeof *a->stats);
+            a->stats->engine = TVDN_ENGINE_STREAMED;
+        }
+        return TVDN_OK;
+    }
     if (a->use_stop) K = 1;  // the stopping rule needs a decision after every iteration: one level per pass
     K = std::min<int64_t>(K, std::max<int64_t>(1, n_total));
     // Periodic boundaries along axis 0: the sweeps see a virtual cube of N0 + 2 K rows -- the cube between K wrapped rows
@@ -287,31 +604,48 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
     // the two artificial faces; the wrap itself is never swept (cytvdn_amd/wavefront.py does the same).
     if (periodic) K = std::min<int64_t>(K, N0);
     const int64_t KX = periodic ? K : 0, NV = N0 + 2 * KX, G0 = KX, G1 = KX + N0;
-    // BEFORE anything of the caller's is touched: can the host hold the state at all?  (page-locked: it cannot swap)
-    {
-        int64_t need = 0, avail = 0;
-        const int rc0 = tvdn_stream_host_need(a, &need, &avail);
-        if (rc0) return rc0;
-    }
     TVDN_HIP(hipSetDevice(device));
-    // ... and do the rings fit the device?  Also before anything is page-locked or copied (the wrap planes are counted
-    // whether or not they will be needed: deciding that reads the caller's first row).
+    wait_for_releases();  // pinned memory a previous run of this process is still handing back
+
+    // ---- what fits where: rings and boxes first, then as many resident rows as asked for / as fit ---------------------------
     const int64_t cap = R + 2, ocap = R + K + 3;
-    const int n_in = 2 + nd * n_state + (want_mse ? 1 : 0), n_out = 1 + nd * n_state;
+    const int n_in = 2 + nd * n_state + (want_mse ? 1 : 0), n_out = 1 + nd * n_state, n_store = 2 + nd * n_state;
     auto aligned = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t ring_b = aligned((size_t)cap * row_bytes), oring_b = aligned((size_t)ocap * row_bytes);
     const size_t box_b = aligned((size_t)R * row_bytes), plane_b = aligned(row_bytes);
     const size_t n_rings = (size_t)(K + 1) + (size_t)(K + 2) * nd;
     const size_t dev_bytes_max = n_rings * ring_b + oring_b * (want_mse ? 2 : 1) + 2 * (size_t)(n_in + n_out) * box_b +
-                                 (size_t)(K + 1) * plane_b;
+                                 (size_t)(K + 1) * plane_b + plane_b;
+    size_t free_b = 0, total_b = 0;
+    TVDN_HIP(hipMemGetInfo(&free_b, &total_b));
+    free_b += state_kept_bytes(device);  // the block the last run kept is this run's to take over or to release
+    if (const size_t cap_b = env_bytes("TVDN_HBM_LIMIT"))  // what the planner of the Python side counts on (tests: "48G")
+        free_b = std::min(free_b, cap_b);
+    if (dev_bytes_max > free_b) {
+        set_error("streamed run with %lld-row chunks and k = %lld needs %zu bytes of HBM, device %d has %zu free", (long long)R,
+                  (long long)K, dev_bytes_max, device, free_b);
+        return TVDN_ERR_UNSUPPORTED;
+    }
+    // RES of the N0 rows keep their state (data term, recon, accumulators: n_store arrays) in HBM between passes: they enter
+    // the rings and leave them by device copies instead of crossing PCIe.  Jia-Zhao runs without an MSE trace (the periodic
+    // schedule walks a wrapped virtual cube whose ends are both streamed; the reference cube of an MSE trace stays on the host).
+    RowMap rm;
+    rm.n0 = N0;
+    if (!periodic && !want_mse && res_req != 0) {
+        auto fits = [&](double share) -> int64_t {
+            const size_t lim = (size_t)(share * (double)free_b);
+            return lim > dev_bytes_max ? (int64_t)((lim - dev_bytes_max) / ((size_t)n_store * plane_b)) : 0;
+        };
+        rm.res = std::min<int64_t>(N0, res_req < 0 ? fits(0.85) : std::min<int64_t>(res_req, fits(0.92)));
+        if (const char *e = getenv("TVDN_STREAM_RESIDENT")) rm.res = std::max<int64_t>(0, std::min<int64_t>({(int64_t)atoll(e), N0, fits(0.92)}));
+    }
+    const int64_t RES = rm.res, HR = N0 - RES;  // rows in HBM / rows on the host
+    auto resident = [&](int64_t g) { return RES > 0 && rm.resident(g); };
+    // BEFORE anything of the caller's is touched: can the host hold what stays there?  (page-locked: it cannot swap)
     {
-        size_t free_b = 0, total_b = 0;
-        TVDN_HIP(hipMemGetInfo(&free_b, &total_b));
-        if (dev_bytes_max > free_b) {
-            set_error("streamed run with %lld-row chunks and k = %lld needs %zu bytes of HBM, device %d has %zu free",
-                      (long long)R, (long long)K, dev_bytes_max, device, free_b);
-            return TVDN_ERR_UNSUPPORTED;
-        }
+        int64_t need = 0, avail = 0;
+        const int rc0 = stream_host_need(a, RES, &need, &avail);
+        if (rc0) return rc0;
     }
 
     // Jia-Zhao wrap at the top face: exact (TVDN_EDGE_WRAP, row 0 of every level kept aside) when row 0 is not finite
@@ -326,62 +660,37 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
         for (size_t i = 0; i < plane && !exact_wrap; ++i) exact_wrap = !std::isfinite(p0[i]);
     }
 
-    // ---- host state: orig and recon are the caller's arrays page-locked in place where possible ----------------------
-    HostArr orig_h, recon_h, ref_h;
-    std::unique_ptr<HostArr[]> state_h(new HostArr[(size_t)nd * 2]);
-    // `data` may be the very array the result goes to (the resident run allows it too): the passes then write recon rows
-    // over the rows the next pass would upload as `orig`, so the data term gets its own pinned copy first.
-    const bool aliased = arrays_overlap(a->data, a->recon_out, cube_bytes);
-    int rc = aliased ? orig_h.alloc(cube_bytes) : orig_h.pin_in_place(const_cast<void *>(a->data), cube_bytes);
-    if (rc) return rc;
-    if (orig_h.owned) parallel_copy(orig_h.p, a->data, cube_bytes);
-    if (a->recon_out != a->data) {  // recon = datacube.copy() (cyTVDN.py:145)
-        if (aliased)
-            std::memmove(a->recon_out, a->data, cube_bytes);
-        else
-            parallel_copy(a->recon_out, a->data, cube_bytes);
-    }
-    rc = recon_h.pin_in_place(a->recon_out, cube_bytes);
-    if (rc) return rc;
-    if (recon_h.owned) parallel_copy(recon_h.p, a->data, cube_bytes);
-    if (want_mse) {
-        rc = ref_h.pin_in_place(const_cast<void *>(a->reference), cube_bytes);
-        if (rc) return rc;
-        if (ref_h.owned) parallel_copy(ref_h.p, a->reference, cube_bytes);
-    }
-    for (int q = 0; q < nd; ++q)
-        for (int s = 0; s < n_state; ++s) {
-            rc = state_h[(size_t)q * 2 + s].alloc(cube_bytes);
-            if (rc) return rc;
-            parallel_copy(state_h[(size_t)q * 2 + s].p, nullptr, cube_bytes);
-        }
-    // periodic: a second set (new state of a pass); Jia-Zhao runs update the one set in place
-    HostArr recon2_h;
-    std::unique_ptr<HostArr[]> state2_h(new HostArr[(size_t)nd * 2]);
-    if (periodic) {
-        if ((rc = recon2_h.alloc(cube_bytes))) return rc;
-        for (int q = 0; q < nd; ++q)
-            for (int s = 0; s < n_state; ++s)
-                if ((rc = state2_h[(size_t)q * 2 + s].alloc(cube_bytes))) return rc;
-    }
-    int h_old = 0;  // which set holds the current state (periodic); 0 = recon_h / state_h
-    auto recon_of = [&](int set) -> char * { return (periodic && set) ? recon2_h.p : recon_h.p; };
-    auto state_of = [&](int set, int q, int s) -> char * {
-        return (periodic && set) ? state2_h[(size_t)q * 2 + s].p : state_h[(size_t)q * 2 + s].p;
-    };
-
-    // ---- device: rings, staging boxes, sums ----------------------------------------------------------------------------
+    // ---- device: rings, staging boxes, resident rows, sums ---------------------------------------------------------------
     CtxHolder ctx;
-    rc = tvdn_ctx_create(&ctx.c, device);
+    int rc = tvdn_ctx_create(&ctx.c, device);
     if (rc) return rc;
     Streams st;
     if ((rc = make_stream(&st.main, +1))) return rc;  // three queue classes: no false ordering between sweeps, uploads and
     if ((rc = make_stream(&st.up, 0))) return rc;     // downloads whatever other streams the process holds (tvdn_common.hpp)
     if ((rc = make_stream(&st.down, -1))) return rc;
-    const size_t dev_bytes = dev_bytes_max - (exact_wrap ? 0 : (size_t)(K + 1) * plane_b);
-    DevMem mem, sums_d, mse_d;
-    TVDN_HIP(hipMalloc(&mem.p, dev_bytes));
-    TVDN_HIP(hipMemsetAsync(mem.p, 0, dev_bytes, st.main));
+    const size_t ring_bytes = dev_bytes_max - (exact_wrap ? 0 : (size_t)(K + 1) * plane_b);
+    const size_t store_b = aligned((size_t)std::max<int64_t>(RES, 1) * row_bytes);
+    const size_t dev_bytes = ring_bytes + (RES > 0 ? (size_t)n_store * store_b : 0);
+    // the one big device block: the block the last run of this device kept, if it fits (tvdn_run.hip state_acquire; a kept
+    // block of another size is released first, so a streamed run still has the whole HBM to itself)
+    struct KeptBlock {
+        void *p = nullptr;
+        size_t bytes = 0;
+        int device = 0;
+        void release()
+        {
+            if (p) state_release(p, bytes, device);
+            p = nullptr;
+        }
+        ~KeptBlock() { release(); }
+    } mem;
+    DevMem sums_d, mse_d;
+    mem.device = device;
+    {
+        bool reused = false;
+        TVDN_HIP(state_acquire(&mem.p, dev_bytes, &mem.bytes, device, &reused));
+    }
+    TVDN_HIP(hipMemsetAsync(mem.p, 0, ring_bytes, st.main));
     char *cursor = (char *)mem.p;
     auto take = [&](size_t b) { char *p = cursor; cursor += b; return p; };
     std::vector<Ring> Rw((size_t)K + 1);
@@ -395,9 +704,15 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
         for (int i = 0; i < n_in; ++i) inbox[h][i] = take(box_b);
         for (int i = 0; i < n_out; ++i) outbox[h][i] = take(box_b);
     }
-    std::vector<char *> row0;  // row 0 of every level, kept for the top face
+    char *zero_plane = take(plane_b);  // the accumulator state a run starts from (cyTVDN.py:131-145): the first pass uploads none
+    std::vector<char *> row0;          // row 0 of every level, kept for the top face
     if (exact_wrap)
         for (int64_t j = 0; j <= K; ++j) row0.push_back(take(plane_b));
+    // resident rows: array i of the store holds them packed (slot = resident rows below): 0 data term, 1 recon, 2 + q * n_state + s state
+    std::vector<char *> store((size_t)n_store, nullptr);
+    if (RES > 0)
+        for (int i = 0; i < n_store; ++i) store[(size_t)i] = take(store_b);
+    auto store_row = [&](int i, int64_t g) -> char * { return store[(size_t)i] + (size_t)rm.res_below(g) * row_bytes; };
     auto A = [&](int64_t level, int q) -> Ring & { return Aw[(size_t)(level + 1) * nd + q]; };
 
     // one slot per iteration, and a last one that takes the sums of halo rows (periodic: the wrapped rows are swept too)
@@ -417,6 +732,134 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
             (rc = evs.make(&out_free[h])))
             return rc;
     }
+
+    // ---- host state, made available by helper threads while the first pass runs ----------------------------------------------
+    // The HR rows that live on the host, of: the data term (the caller's `data` page-locked in place where possible), recon
+    // (`recon_out`, idem), the reference of an MSE trace, and the accumulator state in blocks of rows (StateBlocks).  The
+    // first pass needs the data term only (recon starts as a copy of it and the accumulators as zeros, cyTVDN.py:131-145:
+    // both are formed on the device), so it starts as soon as that is reachable; recon and the state blocks are needed when
+    // the first rows come back down, K rows later.  Periodic runs keep old and new state in two sets (second recon: recon2_h).
+    // `data` may be the very array the result goes to (the resident run allows it too): the passes then write recon rows
+    // over the rows a later pass would upload as the data term, which therefore gets a pinned copy of its own.
+    HostArr orig_h, recon_h, ref_h, recon2_h;
+    StateBlocks sb[2];
+    const int n_sets = periodic ? 2 : 1;
+    for (int s = 0; s < n_sets; ++s) {
+        sb[s].n_arr = nd * n_state;
+        sb[s].n_slots = HR;
+        sb[s].row_bytes = row_bytes;
+        // blocks of ~4 GiB (all arrays together), never shorter than a chunk: short enough for the first one to exist when the
+        // first rows come down, long enough for the per-allocation costs not to matter
+        const int64_t per_row = (int64_t)sb[s].n_arr * (int64_t)row_bytes;
+        sb[s].block_rows = std::max<int64_t>({R, 1, (int64_t)((int64_t(4) << 30) / std::max<int64_t>(per_row, 1))});
+        sb[s].block_rows = std::min<int64_t>(sb[s].block_rows, std::max<int64_t>(HR, 1));
+        sb[s].blocks.resize((size_t)sb[s].n_blocks());
+    }
+    Flag orig_ready, recon_ready, recon2_ready, staged_done;
+    std::atomic<int64_t> staged_upto{0};  // resident rows g < staged_upto have their data term in the store
+    const size_t host_bytes = (size_t)HR * row_bytes;
+    // data partly overlapping recon_out (not the same array): a download into recon_out may hit rows of `data` that have
+    // not been read yet, so every input is taken out of `data` before the first pass starts
+    const bool eager = (aliased && a->recon_out != a->data) || getenv("TVDN_STREAM_EAGER") != nullptr;
+    auto host_row = [&](const HostArr &h, int64_t g) -> char * {
+        return h.cube_rows ? h.p + (size_t)g * row_bytes : h.p + (size_t)rm.host_below(g) * row_bytes;
+    };
+    // host rows of a cube-shaped user array <-> a packed buffer, run of consecutive host rows by run
+    auto pack_host_rows = [&](char *packed, char *cube, bool to_packed) {
+        for (int64_t g = 0; g < N0;) {
+            if (resident(g)) {
+                ++g;
+                continue;
+            }
+            int64_t e = g + 1;
+            while (e < N0 && !resident(e)) ++e;
+            char *pk = packed + (size_t)rm.host_below(g) * row_bytes, *cb = cube + (size_t)g * row_bytes;
+            parallel_copy(to_packed ? pk : cb, to_packed ? cb : pk, (size_t)(e - g) * row_bytes);
+            g = e;
+        }
+    };
+
+    std::thread stager([&] {  // resident rows of the data term: pageable `data` -> store, through the library's pinned lanes
+        const int64_t piece = std::max<int64_t>(1, (int64_t)((size_t(1) << 30) / row_bytes));
+        for (int64_t g = 0; g < N0 && RES > 0;) {
+            if (!resident(g)) {
+                ++g;
+                continue;
+            }
+            int64_t e = g + 1;
+            while (e < N0 && e - g < piece && resident(e)) ++e;
+            const int rcs = tvdn_copy_to_device(store_row(0, g), (const char *)a->data + (size_t)g * row_bytes, (size_t)(e - g) * row_bytes, device);
+            if (rcs) {
+                staged_upto.store(-1);
+                staged_done.raise(rcs, tvdn_last_error());
+                return;
+            }
+            g = e;
+            staged_upto.store(g);
+        }
+        staged_upto.store(N0);
+        staged_done.raise();
+    });
+    Joiner join_stager{stager};
+    std::thread pinner([&] {
+        (void)hipSetDevice(device);
+        if (HR <= 0) {
+            orig_ready.raise();
+            recon_ready.raise();
+            recon2_ready.raise();
+            return;
+        }
+        // 1. the data term (and the reference): inputs of the first pass
+        int rcp = aliased ? orig_h.alloc(host_bytes) : orig_h.pin_in_place(const_cast<void *>(a->data), cube_bytes, host_bytes, false);
+        if (!rcp && orig_h.owned) pack_host_rows(orig_h.p, (char *)const_cast<void *>(a->data), true);
+        if (!rcp && want_mse) {
+            rcp = ref_h.pin_in_place(const_cast<void *>(a->reference), cube_bytes, host_bytes, false);
+            if (!rcp && ref_h.owned) pack_host_rows(ref_h.p, (char *)const_cast<void *>(a->reference), true);
+        }
+        const std::string m1 = rcp ? tvdn_last_error() : "";
+        orig_ready.raise(rcp, m1);
+        // 2. where the first pass's rows come down: recon (periodic: the SECOND set) and the state blocks in slot order
+        if (!rcp) {
+            if (periodic) {
+                rcp = recon2_h.alloc(host_bytes);
+                recon2_ready.raise(rcp, rcp ? tvdn_last_error() : "");
+            } else {
+                // (a result array that is also the input holds data: not `fresh`)
+                rcp = recon_h.pin_in_place(a->recon_out, cube_bytes, host_bytes, !aliased);
+                recon_ready.raise(rcp, rcp ? tvdn_last_error() : "");
+                recon2_ready.raise();
+            }
+        }
+        const int first_set = periodic ? 1 : 0;
+        for (int64_t b = 0; b < sb[first_set].n_blocks() && !rcp; ++b) rcp = sb[first_set].allocate(b);
+        if (periodic && !rcp) {  // 3. the first set: the second pass's target
+            rcp = recon_h.pin_in_place(a->recon_out, cube_bytes, host_bytes, !aliased);
+            recon_ready.raise(rcp, rcp ? tvdn_last_error() : "");
+            for (int64_t b = 0; b < sb[0].n_blocks() && !rcp; ++b) rcp = sb[0].allocate(b);
+        }
+        if (rcp) {  // nobody waits for ever
+            const std::string m = m1.empty() ? std::string(tvdn_last_error()) : m1;
+            recon_ready.raise(rcp, m);
+            recon2_ready.raise(rcp, m);
+            for (int s = 0; s < n_sets; ++s) sb[s].fail(rcp, m);
+        }
+    });
+    Joiner join_pinner{pinner};
+    if (eager) {
+        if ((rc = staged_done.wait()) || (rc = orig_ready.wait())) return rc;
+    }
+    auto wait_staged = [&](int64_t upto) -> int {  // the resident rows below `upto` have their data term in the store
+        while (true) {
+            const int64_t v = staged_upto.load();
+            if (v < 0) return staged_done.wait();
+            if (v >= upto) return TVDN_OK;
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    };
+
+    int h_old = 0;  // which set holds the current state (periodic); 0 = recon_h / sb[0]
+    auto recon_row = [&](int set, int64_t g) -> char * { return host_row((periodic && set) ? recon2_h : recon_h, g); };
+    auto wait_recon = [&](int set) -> int { return ((periodic && set) ? recon2_ready : recon_ready).wait(); };
 
     tvdn_iter_args it;
     std::memset(&it, 0, sizeof it);
@@ -446,10 +889,10 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
     };
 
     // ---- one pass: `kk` iteration levels over the whole cube ------------------------------------------------------------
-    const int down_blocks = getenv("TVDN_STREAM_DOWN_BLOCKS") ? atoi(getenv("TVDN_STREAM_DOWN_BLOCKS")) : 0;
     bool d_form = fista;
     double tk_prev = 0.0;
     int done = 0;
+    int64_t bytes_up = 0, bytes_down = 0, n_passes = 0;  // across PCIe (tvdn_run_stats)
     std::vector<void *> cdst, csrc;
     auto pass = [&](const double *ratios /* kk entries, NAN = unaccelerated */, int kk) -> int {
         std::vector<int> modes((size_t)kk);
@@ -466,36 +909,69 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
             if (acc) prev = ratios[j];
         }
         const int n_in_state = forms[0] ? 2 : 1, n_out_state = forms[kk] ? 2 : 1;
+        // The first pass of a run starts from recon = data term and all-zero accumulators (cyTVDN.py:131-145): neither is
+        // uploaded -- the level-0 rows of recon are device copies of the data-term rows, those of the state copies of a plane
+        // of zeros -- so the host arrays they will come down into need not exist yet.
+        const bool first = n_passes == 0;
         // rows of the (virtual) cube this pass works on, and what each level can reach at an artificial face
         const int64_t E0 = periodic ? KX - kk : 0, E1 = periodic ? G1 + kk : N0;
         auto lo_bound = [&](int64_t level) { return periodic ? E0 + level : (int64_t)0; };
         auto hi_bound = [&](int64_t level) { return periodic ? E1 - level : N0; };
         const int64_t n_chunks = (E1 - E0 + kk + R - 1) / R;
         const int h_new = periodic ? h_old ^ 1 : h_old;
+        auto cube_row = [&](int64_t v) { return ((v - KX) % N0 + N0) % N0; };  // virtual row -> row of the cube
 
-        // virtual rows [v0, v1) of a host array -> box: host row = (v - KX) mod N0, i.e. up to three contiguous pieces
-        auto up_rows = [&](char *box, const char *host, int64_t v0, int64_t v1) -> int {
+        // The host rows among the virtual rows [v0, v1) -> consecutive rows of a box, run by run: a run ends where the next
+        // row is resident, where the cube wraps and where `contiguous(g, g + 1)` says the host memory is not in one piece.
+        auto up_rows = [&](char *box, int64_t v0, int64_t v1, const std::function<char *(int64_t)> &src_row,
+                           const std::function<bool(int64_t)> &joins_next) -> int {
+            int64_t slot = 0;
             for (int64_t v = v0; v < v1;) {
-                const int64_t hrow = ((v - KX) % N0 + N0) % N0;
-                const int64_t n = std::min(v1 - v, N0 - hrow);
-                TVDN_HIP(hipMemcpyAsync(box + (size_t)(v - v0) * row_bytes, host + (size_t)hrow * row_bytes, (size_t)n * row_bytes,
-                                        hipMemcpyHostToDevice, st.up));
+                const int64_t g = cube_row(v);
+                if (resident(g)) {
+                    ++v;
+                    continue;
+                }
+                int64_t n = 1;
+                while (v + n < v1 && g + n < N0 && !resident(g + n) && joins_next(g + n - 1)) ++n;
+                TVDN_HIP(hipMemcpyAsync(box + (size_t)slot * row_bytes, src_row(g), (size_t)n * row_bytes, hipMemcpyHostToDevice, st.up));
+                bytes_up += n * (int64_t)row_bytes;
+                slot += n;
                 v += n;
             }
             return TVDN_OK;
         };
+        auto host_rows_in = [&](int64_t v0, int64_t v1) {
+            int64_t n = 0;
+            for (int64_t v = v0; v < v1; ++v) n += resident(cube_row(v)) ? 0 : 1;
+            return n;
+        };
         auto upload = [&](int64_t c) -> int {
             const int64_t u0 = E0 + c * R, u1 = std::min(E0 + (c + 1) * R, E1);
-            if (u0 >= u1) return TVDN_OK;
+            if (u0 >= u1 || host_rows_in(u0, u1) == 0) return TVDN_OK;
+            int rcu = orig_ready.wait();
+            if (rcu) return rcu;
             const int h = (int)(c % 2);
             if (in_free_set[h]) TVDN_HIP(hipStreamWaitEvent(st.up, in_free[h], 0));
-            int i = 0, rcu;
-            if ((rcu = up_rows(inbox[h][i++], orig_h.p, u0, u1))) return rcu;
-            if ((rcu = up_rows(inbox[h][i++], recon_of(h_old), u0, u1))) return rcu;
-            for (int q = 0; q < nd; ++q)
-                for (int s = 0; s < n_in_state; ++s)
-                    if ((rcu = up_rows(inbox[h][i++], state_of(h_old, q, s), u0, u1))) return rcu;
-            if (want_mse && (rcu = up_rows(inbox[h][i++], ref_h.p, u0, u1))) return rcu;
+            auto joins = [&](const HostArr &ha) {  // in place: cube rows g and g+1 are adjacent; packed: host slots are
+                return std::function<bool(int64_t)>([&ha](int64_t) { (void)ha; return true; });
+            };
+            int i = 0;
+            if ((rcu = up_rows(inbox[h][i++], u0, u1, [&](int64_t g) { return host_row(orig_h, g); }, joins(orig_h)))) return rcu;
+            if (!first) {
+                if ((rcu = wait_recon(h_old))) return rcu;
+                if ((rcu = up_rows(inbox[h][i++], u0, u1, [&](int64_t g) { return recon_row(h_old, g); }, joins(recon_h)))) return rcu;
+                for (int q = 0; q < nd; ++q)
+                    for (int s = 0; s < n_in_state; ++s) {
+                        const int arr = q * n_state + s;
+                        if ((rcu = up_rows(inbox[h][i++], u0, u1, [&](int64_t g) { return sb[h_old].row(arr, rm.host_below(g)); },
+                                           [&](int64_t g) { return sb[h_old].block_of(rm.host_below(g)) == sb[h_old].block_of(rm.host_below(g + 1)); })))
+                            return rcu;
+                    }
+            } else {
+                i += 1 + nd * n_in_state;
+            }
+            if (want_mse && (rcu = up_rows(inbox[h][i++], u0, u1, [&](int64_t g) { return host_row(ref_h, g); }, joins(ref_h)))) return rcu;
             TVDN_HIP(hipEventRecord(in_ready[h], st.up));
             return TVDN_OK;
         };
@@ -507,23 +983,38 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
             const int h = (int)(c % 2);
             const int64_t u0 = E0 + c * R, u1 = std::min(E0 + (c + 1) * R, E1);
             if (u0 < u1) {
-                TVDN_HIP(hipStreamWaitEvent(st.main, in_ready[h], 0));
+                const bool from_host = host_rows_in(u0, u1) > 0;
+                if (from_host) TVDN_HIP(hipStreamWaitEvent(st.main, in_ready[h], 0));
+                if (first && RES > 0 && (rc2 = wait_staged(u1))) return rc2;
                 cdst.clear();
                 csrc.clear();
-                auto scatter = [&](const Ring &rg, const char *box) {
-                    for (int64_t g = u0; g < u1; ++g) {
-                        cdst.push_back(rg.row(g));
-                        csrc.push_back((void *)(box + (size_t)(g - u0) * row_bytes));
+                // row v of ring `rg` <- array `i_store` of the store (resident rows), box `i_box` (host rows, in their order),
+                // or, in the first pass, the data-term row (recon) / the plane of zeros (state)
+                auto scatter = [&](const Ring &rg, int i_store, int i_box, bool from_first, bool zeros) {
+                    int64_t slot = 0;
+                    for (int64_t v = u0; v < u1; ++v) {
+                        const int64_t g = cube_row(v);
+                        const bool res_row = resident(g);
+                        const char *src;
+                        if (from_first && zeros)
+                            src = zero_plane;
+                        else if (from_first)  // recon <- data term
+                            src = res_row ? store_row(0, g) : inbox[h][0] + (size_t)slot * row_bytes;
+                        else
+                            src = res_row ? store_row(i_store, g) : inbox[h][i_box] + (size_t)slot * row_bytes;
+                        if (!res_row) ++slot;
+                        cdst.push_back(rg.row(v));
+                        csrc.push_back((void *)src);
                     }
                 };
                 int i = 0;
-                scatter(Ow, inbox[h][i++]);
-                scatter(Rw[0], inbox[h][i++]);
+                scatter(Ow, 0, i++, false, false);
+                scatter(Rw[0], 1, i++, first, false);
                 for (int q = 0; q < nd; ++q) {
-                    scatter(A(0, q), inbox[h][i++]);                        // level 0: d_k (or b)
-                    if (n_in_state == 2) scatter(A(-1, q), inbox[h][i++]);  // level -1: d_k-1
+                    scatter(A(0, q), 2 + q * n_state, i++, first, true);                            // level 0: d_k (or b)
+                    if (n_in_state == 2) scatter(A(-1, q), 2 + q * n_state + 1, i++, first, true);  // level -1: d_k-1
                 }
-                if (want_mse) scatter(Fw, inbox[h][i++]);
+                if (want_mse) scatter(Fw, -1, i++, false, false);
                 rc2 = copy_rows(cdst, csrc, row_bytes, st.main);
                 if (rc2) return rc2;
                 if (exact_wrap && u0 == 0)
@@ -531,8 +1022,10 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
                 if (want_mse && done == 0)  // MSE[0]: the input against the reference (cyTVDN.py:124-125), own rows
                     for (int64_t g = std::max(u0, G0); g < std::min(u1, G1); ++g)
                         if ((rc2 = sse_row(Rw[0].row(g), Fw.row(g), 0, g - KX))) return rc2;
-                TVDN_HIP(hipEventRecord(in_free[h], st.main));
-                in_free_set[h] = true;
+                if (from_host) {
+                    TVDN_HIP(hipEventRecord(in_free[h], st.main));
+                    in_free_set[h] = true;
+                }
             }
             // the wavefront: level j+1 trails level j by one row
             for (int j = 0; j < kk; ++j) {
@@ -559,64 +1052,76 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
                 // the sums count the cube's own rows once: wrapped rows (periodic) go to the discard slot
                 const int64_t parts[3][2] = {{lo, std::min(hi, G0)}, {std::max(lo, G0), std::min(hi, G1)}, {std::max(lo, G1), hi}};
                 for (int part = 0; part < 3; ++part) {
-                    const int64_t x0 = parts[part][0], x1 = parts[part][1];
-                    if (x0 >= x1) continue;
-                    it.sweep_lo = x0;
-                    it.sweep_hi = x1;
+                    const int64_t p0 = parts[part][0], p1 = parts[part][1];
+                    if (p0 >= p1) continue;
+                    it.sweep_lo = p0;
+                    it.sweep_hi = p1;
                     const int slot = part == 1 ? done + j : discard;
                     rc2 = tvdn_iterate_fused(ctx.c, &it, (double *)sums_d.p + 3 * (size_t)slot, st.main);
                     if (rc2) return rc2;
                     if (want_mse && part == 1)
-                        for (int64_t g = x0; g < x1; ++g)
+                        for (int64_t g = p0; g < p1; ++g)
                             if ((rc2 = sse_row(Fw.row(g), Rw[j + 1].row(g), done + j + 1, g - KX))) return rc2;
                 }
                 if (exact_wrap && lo == 0)
                     TVDN_HIP(hipMemcpyAsync(row0[j + 1], Rw[j + 1].row(0), row_bytes, hipMemcpyDeviceToDevice, st.main));
             }
-            // rows that have reached the last level go home
+            // rows that have reached the last level go home: resident rows into the store (device copies, in the same launch
+            // as the gather of the others into the out box), the others across PCIe.  [lo, hi) are rows of the cube proper.
             const int64_t lo = std::max(G0, E0 + c * R - kk), hi = std::min(G1, E0 + (c + 1) * R - kk);
             if (lo < hi) {
-                if (out_free_set[h]) TVDN_HIP(hipStreamWaitEvent(st.main, out_free[h], 0));
+                const bool to_host = host_rows_in(lo, hi) > 0;
+                if (to_host && out_free_set[h]) TVDN_HIP(hipStreamWaitEvent(st.main, out_free[h], 0));
                 cdst.clear();
                 csrc.clear();
-                auto gather = [&](char *box, const Ring &rg) {
-                    for (int64_t g = lo; g < hi; ++g) {
-                        cdst.push_back(box + (size_t)(g - lo) * row_bytes);
-                        csrc.push_back(rg.row(g));
+                auto gather = [&](int i_store, int i_box, const Ring &rg) {
+                    int64_t slot = 0;
+                    for (int64_t v = lo; v < hi; ++v) {
+                        const int64_t g = v - KX;
+                        const bool res_row = resident(g);
+                        cdst.push_back(res_row ? store_row(i_store, g) : outbox[h][i_box] + (size_t)slot * row_bytes);
+                        csrc.push_back(rg.row(v));
+                        if (!res_row) ++slot;
                     }
                 };
                 int i = 0;
-                gather(outbox[h][i++], Rw[kk]);
+                gather(1, i++, Rw[kk]);
                 for (int q = 0; q < nd; ++q) {
-                    gather(outbox[h][i++], A(kk, q));
-                    if (n_out_state == 2) gather(outbox[h][i++], A(kk - 1, q));
+                    gather(2 + q * n_state, i++, A(kk, q));
+                    if (n_out_state == 2) gather(2 + q * n_state + 1, i++, A(kk - 1, q));
                 }
                 rc2 = copy_rows(cdst, csrc, row_bytes, st.main);
                 if (rc2) return rc2;
-                TVDN_HIP(hipEventRecord(out_ready[h], st.main));
-                TVDN_HIP(hipStreamWaitEvent(st.down, out_ready[h], 0));
-                const size_t off = (size_t)(lo - KX) * row_bytes, len = (size_t)(hi - lo) * row_bytes;
-                i = 0;
-                if (down_blocks > 0 && len % 16 == 0) {  // measurement knob: one capped copy launch writing pinned memory
-                    cdst.clear();
-                    csrc.clear();
-                    cdst.push_back(recon_of(h_new) + off);
-                    csrc.push_back(outbox[h][i++]);
-                    for (int q = 0; q < nd; ++q)
-                        for (int s = 0; s < n_out_state; ++s) {
-                            cdst.push_back(state_of(h_new, q, s) + off);
-                            csrc.push_back(outbox[h][i++]);
+                if (to_host) {
+                    TVDN_HIP(hipEventRecord(out_ready[h], st.main));
+                    TVDN_HIP(hipStreamWaitEvent(st.down, out_ready[h], 0));
+                    if ((rc2 = wait_recon(h_new))) return rc2;  // the host arrays these rows land in exist (first pass: the helper may still be at it)
+                    const HostArr &rh = (periodic && h_new) ? recon2_h : recon_h;
+                    // runs of host rows: consecutive cube rows (an array page-locked in place) or consecutive host slots inside
+                    // one block of host state -- a run must be one piece in every destination
+                    int64_t slot = 0;
+                    for (int64_t g = lo - KX; g < hi - KX;) {
+                        if (resident(g)) {
+                            ++g;
+                            continue;
                         }
-                    rc2 = tvdn_copy_many((int32_t)cdst.size(), cdst.data(), csrc.data(), (int64_t)len, down_blocks, st.down);
-                    if (rc2) return rc2;
-                } else {
-                    TVDN_HIP(hipMemcpyAsync(recon_of(h_new) + off, outbox[h][i++], len, hipMemcpyDeviceToHost, st.down));
-                    for (int q = 0; q < nd; ++q)
-                        for (int s = 0; s < n_out_state; ++s)
-                            TVDN_HIP(hipMemcpyAsync(state_of(h_new, q, s) + off, outbox[h][i++], len, hipMemcpyDeviceToHost, st.down));
+                        const int64_t hs = rm.host_below(g);
+                        if ((rc2 = sb[h_new].wait_for(hs))) return rc2;
+                        int64_t n = 1;
+                        while (g + n < hi - KX && !resident(g + n) && sb[h_new].block_of(hs + n) == sb[h_new].block_of(hs)) ++n;
+                        const size_t boff = (size_t)slot * row_bytes, len = (size_t)n * row_bytes;
+                        i = 0;
+                        TVDN_HIP(hipMemcpyAsync(host_row(rh, g), outbox[h][i++] + boff, len, hipMemcpyDeviceToHost, st.down));
+                        for (int q = 0; q < nd; ++q)
+                            for (int s = 0; s < n_out_state; ++s)
+                                TVDN_HIP(hipMemcpyAsync(sb[h_new].row(q * n_state + s, hs), outbox[h][i++] + boff, len, hipMemcpyDeviceToHost, st.down));
+                        bytes_down += (int64_t)len * (1 + (int64_t)n_out_state * nd);
+                        slot += n;
+                        g += n;
+                    }
+                    TVDN_HIP(hipEventRecord(out_free[h], st.down));
+                    out_free_set[h] = true;
                 }
-                TVDN_HIP(hipEventRecord(out_free[h], st.down));
-                out_free_set[h] = true;
             }
         }
         TVDN_HIP(hipStreamSynchronize(st.down));
@@ -626,6 +1131,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
         tk_prev = prev;
         done += kk;
         h_old = h_new;
+        ++n_passes;
         return TVDN_OK;
     };
 
@@ -643,10 +1149,12 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
     };
     TVDN_HIP(hipStreamSynchronize(st.main));
     const auto t_passes = std::chrono::steady_clock::now();
+    double first_pass_s = 0.0;
     if (!a->use_stop) {
         for (int i = 0; i < n_total;) {  // a pass may hold the last FISTA iterations and the first unaccelerated ones
             const int kk = (int)std::min<int64_t>(K, n_total - i);
             if ((rc = pass(ratios.data() + i, kk))) return rc;
+            if (i == 0) first_pass_s = since(t_passes);
             ran += kk;
             i += kk;
             if (a->progress) a->progress((int32_t)i, a->progress_user);
@@ -669,18 +1177,37 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
             }
         }
     }
+    const auto t_end_passes = std::chrono::steady_clock::now();
 
-    if (getenv("TVDN_STREAM_TIMING")) {  // measurement aid: set-up (page-locking, first touch, rings) apart from the passes
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "tvdn_run streamed: rows %lld k %lld, set-up %.3f s, passes %.3f s\n", (long long)R, (long long)K,
-                std::chrono::duration<double>(t_passes - t_start).count(), std::chrono::duration<double>(now - t_passes).count());
-    }
     // ---- results home -------------------------------------------------------------------------------------------------------
-    if (periodic && h_old == 1)
-        parallel_copy(a->recon_out, recon2_h.p, cube_bytes);  // the last pass wrote the second set
-    else if (recon_h.owned)
-        parallel_copy(a->recon_out, recon_h.p, cube_bytes);
-    if (n_total > 0) TVDN_HIP(hipMemcpy(a->sums_out, sums_d.p, sizeof(double) * 3 * (size_t)n_total, hipMemcpyDeviceToHost));
+    if (stager.joinable()) stager.join();
+    if (pinner.joinable()) pinner.join();
+    for (int64_t g = 0; g < N0 && RES > 0;) {  // resident rows: store -> the caller's array, through the library's pinned lanes
+        if (!resident(g)) {
+            ++g;
+            continue;
+        }
+        int64_t e = g + 1;
+        while (e < N0 && resident(e)) ++e;
+        rc = tvdn_copy_to_host((char *)a->recon_out + (size_t)g * row_bytes, store_row(1, g), (size_t)(e - g) * row_bytes, device);
+        if (rc) return rc;
+        g = e;
+    }
+    if (HR > 0) {
+        const HostArr &last = (periodic && h_old == 1) ? recon2_h : recon_h;  // periodic: the set the last pass wrote
+        if (last.owned) pack_host_rows(last.p, (char *)a->recon_out, false);
+        else if (last.p != (char *)a->recon_out) parallel_copy(a->recon_out, last.p, cube_bytes);
+    }
+    const double home_s = since(t_end_passes);
+    // the device block goes back (to the cache) BEFORE the host state starts to be unpinned in the background: a hipFree issued
+    // behind dozens of hipHostUnregister calls waits for them
+    const auto t_free = std::chrono::steady_clock::now();
+    mem.release();
+    if (getenv("TVDN_STREAM_TIMING"))  // measurement aid: set-up apart from the passes
+        fprintf(stderr, "tvdn_run streamed: rows %lld k %lld resident rows %lld of %lld, set-up %.3f s, passes %.3f s (first %.3f s), results home %.3f s, device block released in %.3f s\n",
+                (long long)R, (long long)K, (long long)RES, (long long)N0, std::chrono::duration<double>(t_passes - t_start).count(),
+                std::chrono::duration<double>(t_end_passes - t_passes).count(), first_pass_s, home_s, since(t_free));
+    TVDN_HIP(hipMemcpy(a->sums_out, sums_d.p, sizeof(double) * 3 * (size_t)n_total, hipMemcpyDeviceToHost));
     if (want_mse) {
         std::vector<double> per_row((size_t)(n_total + 1) * (size_t)N0);
         TVDN_HIP(hipMemcpy(per_row.data(), mse_d.p, sizeof(double) * per_row.size(), hipMemcpyDeviceToHost));
@@ -694,6 +1221,20 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K)
     if (a->phase_iters) {
         a->phase_iters[0] = ran_phase[0];
         a->phase_iters[1] = ran_phase[1];
+    }
+    if (a->stats) {
+        tvdn_run_stats &s = *a->stats;
+        std::memset(&s, 0, sizeof s);
+        s.engine = TVDN_ENGINE_STREAMED;
+        s.stream_rows = (int32_t)R;
+        s.stream_k = (int32_t)K;
+        s.resident_rows = RES;
+        s.n_passes = n_passes;
+        s.h2d_bytes = bytes_up + RES * (int64_t)row_bytes;
+        s.d2h_bytes = bytes_down + RES * (int64_t)row_bytes;
+        s.setup_s = std::chrono::duration<double>(t_passes - t_start).count();
+        s.loop_s = std::chrono::duration<double>(t_end_passes - t_passes).count();
+        s.total_s = since(t_start);
     }
     return TVDN_OK;
 }

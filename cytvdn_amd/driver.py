@@ -19,6 +19,7 @@ Differences, all deliberate:
 from __future__ import annotations
 
 import os
+import threading
 from typing import Optional, Tuple
 
 import numpy as np
@@ -259,6 +260,17 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
     return recon, b_norm, delta_recon
 
 
+_audition_locks: dict = {}
+_audition_locks_guard = threading.Lock()
+
+
+def _audition_lock(device: int) -> threading.Lock:
+    """One placement audition at a time per device: the probes time sweeps with HIP events and hold several states of tens
+    of GiB side by side -- two threads doing that at once would share the HBM budget and disturb each other's timings."""
+    with _audition_locks_guard:
+        return _audition_locks.setdefault(int(device), threading.Lock())
+
+
 def _state_workspace(args, shape, dtype, fista, n_total, device, BC_mode):
     """Device memory for the state of a resident tvdn_run, from torch's caching allocator: `hipMalloc` of tens of GiB
     takes 11 ms most times and 3-5 s some times, and a process that denoises cube after cube should pay that once
@@ -270,8 +282,14 @@ def _state_workspace(args, shape, dtype, fista, n_total, device, BC_mode):
     _lib.check(_lib.lib().tvdn_run_workspace_bytes(C.byref(args), C.byref(need)))
     cands = _audition_candidates(n_total)
     if cands > 1:
-        be = HipBackend.best_of(cands, SlabLayout(tuple(shape), 0, 1, int(BC_mode)), dtype, fista, device=device, max_iters=1,
-                                release_losers=False)     # kept in torch's cache for the next call (see best_of)
+        # ctypes releases the GIL inside the library, so denoise3D/4D may run on several threads: the audition is serialised
+        # per device and its backends time their sweeps on a reduction context of their OWN (the process-wide context of
+        # _lib.ctx keeps one event list and one scratch buffer, which two auditions at once would race on)
+        with _audition_lock(device):
+            be = HipBackend.best_of(cands, SlabLayout(tuple(shape), 0, 1, int(BC_mode)), dtype, fista, device=device,
+                                    max_iters=1, release_losers=False,    # kept in torch's cache for the next call (see best_of)
+                                    private_ctx=True)
+            torch.cuda.current_stream(int(device)).synchronize()
         slab = getattr(be, "_slab", None)
         if slab is not None and slab.numel() * slab.element_size() >= need.value and slab.data_ptr() % 256 == 0:
             return slab
@@ -299,6 +317,7 @@ def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, sto
                      n_devices=len(devices) if stream is None else 0)
     if stream is not None:
         a.stream_rows, a.stream_k = int(stream[0]), int(stream[1])
+        a.stream_resident = -1       # the low rows whose state fits beside the rings stay in HBM between the passes
     if len(devices) > len(a.devices):
         raise ValueError(f"at most {len(a.devices)} devices")
     for i, d in enumerate(devices):

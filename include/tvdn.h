@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TVDN_ABI_VERSION 5
+#define TVDN_ABI_VERSION 6
 
 typedef enum tvdn_dtype { TVDN_F32 = 0, TVDN_F64 = 1 } tvdn_dtype;
 
@@ -237,6 +237,29 @@ int tvdn_iterate_many(tvdn_ctx *ctx, tvdn_many_args *state, int32_t n_fista, con
  * ---------------------------------------------------------------------------------------- */
 #define TVDN_MAX_DEVICES 16
 
+/* ABI 6.  Where a tvdn_run call's time and bytes went; filled on success when tvdn_run_args.stats points at one.
+ * Measurement and planning aid (bench.py reports the PCIe rates of a streamed run from it); the
+ * reference has no counterpart (its loop prints nothing but progress bars, cyTVDN/cyTVDN.py:148-242). */
+#define TVDN_ENGINE_RESIDENT 0
+#define TVDN_ENGINE_STREAMED 1
+
+typedef struct tvdn_run_stats {
+    int32_t engine;        /* TVDN_ENGINE_*                                                                        */
+    int32_t pipelined;     /* resident: 1 when the transfers ran under the first / over the last iterations        */
+    int32_t stream_rows;   /* streamed: rows per chunk                                                              */
+    int32_t stream_k;      /* streamed: iteration levels per PCIe round trip                                        */
+    int64_t resident_rows; /* streamed: low rows of axis 0 whose state stayed in HBM between passes (0 = none)      */
+    int64_t n_passes;      /* streamed: passes over the cube                                                        */
+    int64_t h2d_bytes;     /* bytes that crossed PCIe towards the device during the call                            */
+    int64_t d2h_bytes;     /* ... and back                                                                          */
+    double setup_s;        /* entry -> first iteration queued: allocations, page-locking, placement audition        */
+    double loop_s;         /* the iterations, with the transfers that run under them (a streamed run: its passes)   */
+    double total_s;        /* entry -> return                                                                       */
+    int32_t audition_n;    /* resident: placements of the state tried (0 / 1: the first allocation was taken)       */
+    int32_t audition_kept; /* index of the one kept                                                                 */
+    double audition_ms[8]; /* probe time per sweep of each candidate, in the order tried                            */
+} tvdn_run_stats;
+
 typedef struct tvdn_run_args {
     int32_t dtype;
     int32_t ndim;
@@ -291,16 +314,27 @@ typedef struct tvdn_run_args {
      * the library's own placement audition is off. */
     void *workspace;
     int64_t workspace_bytes;
+    /* ABI 6.  Optional, host: filled on success (struct above). */
+    tvdn_run_stats *stats;
+    /* ABI 6.  Streamed runs: the low rows of axis 0 whose state (data term, recon, accumulators) STAYS in HBM between the
+     * passes instead of crossing PCIe twice per pass -- the resident + streamed hybrid.  0: none (every row streams, as
+     * before ABI 6); -1: as many as fit beside the rings in 85 % of the free HBM (with stream_rows / stream_k = -1 / -1 the
+     * library weighs depth against kept rows itself); n > 0: that many (at most what fits).  Jia-Zhao runs without an MSE
+     * trace; ignored otherwise.  Bit-identical to the resident run whatever the split. */
+    int64_t stream_resident;
 } tvdn_run_args;
 
 int tvdn_run(const tvdn_run_args *args);
 
-/* A resident one-device tvdn_run that allocates its own state KEEPS that block when it returns (one per device) and hands
- * it to the next such run it fits (same size, or up to a quarter larger than needed): releasing and re-allocating tens of
- * GiB in quick succession costs about 0.7 s per hipMalloc and 1.1 s per hipFree on this platform, with single stalls of
- * several seconds, i.e. more than a 50-iteration run itself.  tvdn_plan counts the kept block as free; streamed runs,
- * device lists and runs with a `workspace` release it first.  tvdn_release_cache() hands it back to the driver at any
- * time (always TVDN_OK); the environment variable TVDN_KEEP_STATE=0 never keeps one. */
+/* A one-device tvdn_run that allocates its own device memory -- the state of a resident run, or the rings, boxes and
+ * resident rows of a streamed one -- KEEPS that block when it returns (one per device) and hands it to the next run it fits
+ * (same size, or up to a quarter larger than needed; a kept block of another size is released before the new one is
+ * allocated): releasing and re-allocating tens of GiB in quick succession costs about 0.7 s per hipMalloc and 1.1 s per
+ * hipFree on this platform, with single stalls of several seconds, i.e. more than a 50-iteration run itself.  NOTE that the
+ * block (up to most of the HBM) therefore stays allocated after tvdn_run returns: a caller that needs the device memory for
+ * something else calls tvdn_release_cache() (always TVDN_OK), or sets the environment variable TVDN_KEEP_STATE=0, which
+ * never keeps one.  tvdn_plan and tvdn_stream_plan count the kept block as free; device lists and runs with a `workspace`
+ * release it first. */
 int tvdn_release_cache(void);
 
 /* Bytes of device memory the state of a resident one-device run of these args takes (dtype, ndim, shape, n_fista > 0
@@ -312,7 +346,8 @@ int tvdn_run_workspace_bytes(const tvdn_run_args *args, int64_t *bytes);
  * chunk by chunk, out[2] = iterations that run over the download; all 0 = plain order (upload, iterate, download).  Pure
  * host arithmetic, the very function tvdn_run asks: cubes from 256 MiB and 32 rows on, runs from 4 iterations on, eight
  * chunks, at most 8 iterations at either end.  tvdn_run applies it to Jia-Zhao runs without stopping rule or MSE trace
- * whose first row is finite; the result is bit-identical to the plain order either way.  Environment: TVDN_PIPELINE=0
+ * whose first row is finite; recon is bit-identical to the plain order either way, the sums agree with it to rounding (1e-6
+ * relative: the rows' partial sums are added in another order).  Environment: TVDN_PIPELINE=0
  * (never), "rows,k_start,k_end" (forced). */
 int tvdn_pipeline_plan(int64_t n0, int32_t n_iters, int64_t cube_bytes, int32_t *out);
 
@@ -325,6 +360,21 @@ int tvdn_pipeline_plan(int64_t n0, int32_t n_iters, int64_t cube_bytes, int32_t 
  * call before it touches anything (the reference's counterpart is check_memory, cyTVDN/cyTVDN.py:438-467, which only
  * prints). */
 int tvdn_stream_host_need(const tvdn_run_args *args, int64_t *need_bytes, int64_t *avail_bytes);
+
+/* ABI 6.  What a streamed tvdn_run of these args (dtype, ndim, shape, n_fista / n_plain, use_stop, bc_mode, reference /
+ * mse_out, stream_resident are read) chooses when it may use `hbm_free_bytes` of HBM (<= 0: what args->device has free now):
+ * rows per chunk, iterations per pass, resident rows, and what that costs in HBM and in page-locked host memory.  The very
+ * function tvdn_run asks with stream_rows / stream_k = -1 / -1; pure host arithmetic when hbm_free_bytes is given
+ * (cytvdn_amd/planner.py plans with it; the reference's counterpart is check_memory, cyTVDN/cyTVDN.py:438-467). */
+typedef struct tvdn_stream_plan_out {
+    int64_t rows;
+    int64_t k;
+    int64_t resident_rows;
+    int64_t hbm_bytes;
+    int64_t host_bytes;
+} tvdn_stream_plan_out;
+
+int tvdn_stream_plan(const tvdn_run_args *args, int64_t hbm_free_bytes, tvdn_stream_plan_out *out);
 
 /* The host side of the schedule, for callers that drive tvdn_iterate_fused themselves (cytvdn_amd/engine.py does): the
  * very functions tvdn_iterate_many and tvdn_run use, so that the parity-critical logic exists once.  Pure host code.

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/tvdn.h but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert _lib.lib().tvdn_abi_version() == 5
+    assert _lib.lib().tvdn_abi_version() == 6
 
 
 def test_iter_args_struct_matches_header_layout():
@@ -166,14 +166,16 @@ def test_struct_layouts_match_the_c_header(tmp_path):
                    '  P(tvdn_iter_args, orig_ring_rows); P(tvdn_iter_args, accumulate);\n'
                    '  printf("tvdn_many_args %zu\\n", sizeof(tvdn_many_args)); P(tvdn_many_args, recon); P(tvdn_many_args, S); P(tvdn_many_args, tk_prev);\n'
                    '  printf("tvdn_run_args %zu\\n", sizeof(tvdn_run_args)); P(tvdn_run_args, stop); P(tvdn_run_args, data); P(tvdn_run_args, devices);\n'
-                   '  P(tvdn_run_args, stream_rows); P(tvdn_run_args, stream_k); P(tvdn_run_args, phase_iters); P(tvdn_run_args, progress_user); P(tvdn_run_args, workspace_bytes); P(tvdn_run_args, n_devices);\n'
+                   '  P(tvdn_run_args, stream_rows); P(tvdn_run_args, stream_k); P(tvdn_run_args, phase_iters); P(tvdn_run_args, progress_user); P(tvdn_run_args, workspace_bytes); P(tvdn_run_args, n_devices); P(tvdn_run_args, stats); P(tvdn_run_args, stream_resident);\n'
+                   '  printf("tvdn_run_stats %zu\\n", sizeof(tvdn_run_stats)); P(tvdn_run_stats, resident_rows); P(tvdn_run_stats, d2h_bytes); P(tvdn_run_stats, total_s);\n'
+                   '  P(tvdn_run_stats, audition_kept); P(tvdn_run_stats, audition_ms);\n'
                    '  printf("tvdn_plan_out %zu\\n", sizeof(tvdn_plan_out)); P(tvdn_plan_out, fits); P(tvdn_plan_out, min_slabs);\n'
                    '  return 0; }\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
     got = dict(line.rsplit(" ", 1) for line in subprocess.check_output([str(exe)], text=True).splitlines())
     mirrors = {"tvdn_iter_args": _lib.IterArgs, "tvdn_many_args": _lib.ManyArgs, "tvdn_run_args": _lib.RunArgs,
-               "tvdn_plan_out": _lib.PlanOut}
+               "tvdn_plan_out": _lib.PlanOut, "tvdn_run_stats": _lib.RunStats}
     for key, val in got.items():
         name, _, field = key.partition(".")
         want = getattr(mirrors[name], field).offset if field else ctypes.sizeof(mirrors[name])

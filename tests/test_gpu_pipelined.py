@@ -273,6 +273,70 @@ def test_concurrent_calls_from_threads(shape, its):
     assert all(g == w for gs, w in zip(got, want) for g in gs)
 
 
+def test_concurrent_calls_that_audition(monkeypatch):
+    """The same with runs that audition their placement (TVDN_AUDITION=3; by default from 400 iterations on): the probes of
+    several threads time sweeps with HIP events on a reduction context -- each audition has its own and they take turns per
+    device (driver._audition_lock), so nothing races on the process-wide context's event list or scratch."""
+    import hashlib
+    import threading
+    import cytvdn_amd as tv
+    from cytvdn_amd import synth
+    monkeypatch.setenv("TVDN_AUDITION", "3")
+    mu = np.array([1.0, 1.0, 0.5, 0.5], np.float32)
+    xs = [synth.cube((24, 6, 16, 32), seed=s, dtype=np.float32) + np.float32(0.25) for s in (4, 5, 6)]
+    want = [hashlib.sha1(tv.denoise4D(x, mu, 7, quiet=True)[0].tobytes()).hexdigest() for x in xs]
+    got = [[None] * 3 for _ in xs]
+    errors = []
+
+    def work(i):
+        try:
+            for r in range(3):
+                got[i][r] = hashlib.sha1(tv.denoise4D(xs[i], mu, 7, quiet=True)[0].tobytes()).hexdigest()
+        except Exception as e:
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(xs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert all(g == w for gs, w in zip(got, want) for g in gs)
+
+
+def test_run_stats_say_where_the_time_and_bytes_went(oracle, monkeypatch):
+    """tvdn_run_args.stats (ABI 6): engine, set-up / loop / total seconds, bytes across PCIe, the audition's probe times."""
+    import ctypes as C
+    from cytvdn_amd import _lib, synth
+    monkeypatch.setenv("TVDN_AUDITION", "3")
+    monkeypatch.setenv("TVDN_KEEP_STATE", "0")
+    x = synth.cube((24, 6, 16, 32), seed=11, dtype=np.float32) + np.float32(0.25)
+    mu = np.array([1.0, 1.0, 0.5, 0.5], np.float32)
+    lam = mu / np.float32(32.0)
+    recon, sums = np.empty_like(x), np.zeros((5, 3))
+    st = _lib.RunStats()
+    a = _lib.RunArgs(dtype=0, ndim=4, bc_mode=2, device=0, n_fista=5, n_plain=0)
+    for i, v in enumerate(x.shape):
+        a.shape[i] = v
+    for q in range(4):
+        a.clip[q], a.lambda_mu[q] = float((1.0 / lam)[q]), float((lam / mu).astype(np.float32)[q])
+    a.data, a.recon_out, a.sums_out, a.stats = x.ctypes.data, recon.ctypes.data, sums.ctypes.data, C.addressof(st)
+    _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+    assert bits_equal(recon, oracle.denoise(x, mu, 5, True)["recon"])
+    d = st.as_dict()
+    assert d["engine"] == 0 and d["h2d_bytes"] == x.nbytes and d["d2h_bytes"] == x.nbytes
+    assert d["audition_n"] == 3 and len(d["audition_ms"]) == 3 and 0 <= d["audition_kept"] < 3 and min(d["audition_ms"]) > 0
+    assert 0 < d["setup_s"] and 0 < d["loop_s"] and d["setup_s"] + d["loop_s"] <= d["total_s"] * 1.001
+    # streamed: the passes' bytes; 5 iterations at k = 2 are three passes of 10 arrays up (the first with both d arrays) and 9 down
+    a.stream_rows, a.stream_k = 4, 2
+    _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+    assert bits_equal(recon, oracle.denoise(x, mu, 5, True)["recon"])
+    d = st.as_dict()
+    assert d["engine"] == 1 and d["stream_rows"] == 4 and d["stream_k"] == 2 and d["n_passes"] == 3
+    assert 0 < d["h2d_bytes"] <= 3 * 10 * x.nbytes and 0 < d["d2h_bytes"] <= 3 * 9 * x.nbytes
+    assert d["loop_s"] > 0 and d["total_s"] >= d["loop_s"]
+
+
 def test_the_state_block_is_kept_between_runs_without_a_workspace(oracle, monkeypatch):
     """A C caller that brings no workspace: tvdn_run keeps the state block of its last resident run (one per device) for the
     next one -- visible as HBM that stays in use after the call and comes back with tvdn_release_cache() --, reuses it for

@@ -33,7 +33,7 @@ def _check_traces(sums, ref, n):
     np.testing.assert_allclose(sums[:n, 2], ref["rnorm64"][:n], rtol=1e-9)
 
 
-def _run(x, mu, n_f, n_p, stop=None, ref=None, stream=None, device=0, bc=2):
+def _run(x, mu, n_f, n_p, stop=None, ref=None, stream=None, device=0, bc=2, resident=0, stats=None):
     from cytvdn_amd import _lib
     dt = x.dtype
     nd = x.ndim
@@ -43,6 +43,9 @@ def _run(x, mu, n_f, n_p, stop=None, ref=None, stream=None, device=0, bc=2):
                      use_stop=int(stop is not None), stop=float(stop or 0.0))
     if stream:
         a.stream_rows, a.stream_k = stream
+        a.stream_resident = resident
+    if stats is not None:
+        a.stats = C.addressof(stats)
     for i, s in enumerate(x.shape):
         a.shape[i] = s
     for q in range(nd):
@@ -92,6 +95,96 @@ def test_streamed_run_equals_resident_run(oracle, shape, dtype, n_f, n_p, rows, 
     ref = _oracle(oracle, x, mu, n_f, n_p)                    # ... and the oracle itself, not only the resident HIP run
     assert bits_equal(got[0], ref["recon"])
     _check_traces(got[1], ref, n_f + n_p)
+
+
+@pytest.mark.parametrize("shape,dtype,n_f,n_p,rows,k,resident", [
+    ((23, 3, 4, 8), np.float32, 9, 0, 5, 3, 7),           # the boundary inside the second chunk; three passes
+    ((23, 3, 4, 8), np.float32, 9, 0, 5, 3, 5),           # ... exactly at a chunk boundary
+    ((23, 3, 4, 8), np.float32, 9, 0, 5, 3, 1),           # one resident row
+    ((23, 3, 4, 8), np.float32, 9, 0, 5, 3, 22),          # one streamed row
+    ((23, 3, 4, 8), np.float32, 9, 0, 5, 3, 23),          # every row resident: nothing crosses PCIe between the passes
+    ((23, 3, 4, 8), np.float32, 9, 0, 5, 3, -1),          # as many as fit (all of this cube)
+    ((23, 3, 4, 8), np.float32, 5, 4, 3, 9, 11),          # hybrid, d -> b inside the one pass
+    ((40, 4, 8, 16), np.float32, 7, 6, 3, 4, 17),         # hybrid over four passes: the kept state changes form in the store
+    ((17, 6, 16), np.float64, 0, 7, 3, 5, 8),             # unaccelerated, 3-D, f64
+    ((17, 6, 16), np.float64, 7, 0, 17, 2, 9),            # one chunk per pass
+    ((9, 2, 5, 7), np.float32, 6, 0, 2, 8, 4),            # scalar packs; more levels than rows
+    ((19, 3, 4, 8), np.float32, 6, 3, 1, 7, 10),          # one-row chunks
+    ((33, 3, 4, 8), np.float32, 10, 0, 1, 5, 32),
+])
+def test_streamed_run_with_resident_rows(oracle, shape, dtype, n_f, n_p, rows, k, resident):
+    """The resident + streamed hybrid (tvdn_run_args.stream_resident): the low rows keep their state in HBM between the
+    passes and enter / leave the rings by device copies, the others cross PCIe; wherever the boundary falls the result is
+    the resident run's and the oracle's, bit for bit, traces included."""
+    from cytvdn_amd import _lib, synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=23, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    want = _run(x, mu, n_f, n_p)
+    st = _lib.RunStats()
+    got = _run(x, mu, n_f, n_p, stream=(rows, k), resident=resident, stats=st)
+    n = n_f + n_p
+    assert got[3] == want[3] == n
+    assert bits_equal(got[0], want[0])
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-12)
+    ref = _oracle(oracle, x, mu, n_f, n_p)
+    assert bits_equal(got[0], ref["recon"])
+    _check_traces(got[1], ref, n)
+    want_res = shape[0] if resident < 0 else min(resident, shape[0])
+    assert st.engine == 1 and st.resident_rows == want_res
+    # what crossed PCIe: the cube once each way plus, per pass, the streamed rows only (none of them in the first pass's state upload)
+    hr = shape[0] - want_res
+    per_row = x.nbytes // shape[0]
+    n_state = 2 if n_f else 1
+    assert st.h2d_bytes <= per_row * (want_res + st.n_passes * hr * (2 + nd * n_state))
+    assert st.d2h_bytes <= per_row * (want_res + st.n_passes * hr * (1 + nd * n_state))
+    if hr == 0:
+        assert st.h2d_bytes == x.nbytes and st.d2h_bytes == x.nbytes
+
+
+def test_streamed_hybrid_with_stopping_rule_in_place_and_nonfinite_row(oracle):
+    from cytvdn_amd import _lib, synth
+    dt = np.dtype(np.float32)
+    # stopping rule: one level per pass, kept rows or not
+    shape = (12, 5, 8, 12)
+    x = synth.cube(shape, seed=31, dtype=dt)
+    mu = np.array([1.0, 1.0, 0.5, 0.5], dt)
+    want = _run(x, mu, 0, 40, stop=0.02)
+    for resident in (5, 12):
+        got = _run(x, mu, 0, 40, stop=0.02, stream=(4, 6), resident=resident)
+        assert 0 < got[3] == want[3] < 40 and bits_equal(got[0], want[0])
+        np.testing.assert_allclose(got[1], want[1], rtol=1e-12)
+    # exact Jia-Zhao wrap (non-finite first row) with the first rows resident
+    shape = (14, 3, 6, 8)
+    x = synth.cube(shape, seed=7, dtype=dt) + dt.type(0.5)
+    mu = np.array([1.0, 0.8, 0.5, 0.6], dt)
+    x[0, 1, 2, 3] = np.inf
+    ref = _oracle(oracle, x, mu, 7, 0)
+    for resident in (1, 6, 14):
+        got = _run(x, mu, 7, 0, stream=(2, 2), resident=resident)
+        assert np.isnan(ref["recon"][-1]).any() and bits_equal(got[0], ref["recon"]), resident
+    # in place (data is recon_out), and recon_out overlapping data partly
+    shape = (21, 3, 4, 8)
+    x = synth.cube(shape, seed=13, dtype=dt) + dt.type(0.25)
+    ref = _oracle(oracle, x, mu, 7, 0)
+    lam = mu / dt.type(32.0)
+    for resident, shift in ((8, 0), (0, 0), (8, 3), (0, 3), (21, 3), (5, -2)):
+        plane = x[0].size
+        buf = np.zeros(x.size + 8 * plane, dt)
+        src = buf[4 * plane:4 * plane + x.size].reshape(shape)
+        src[...] = x
+        dst = buf[(4 + shift) * plane:(4 + shift) * plane + x.size].reshape(shape)
+        a = _lib.RunArgs(dtype=0, ndim=4, bc_mode=2, device=0, n_fista=7, n_plain=0, stream_rows=3, stream_k=2, stream_resident=resident)
+        for i, s_ in enumerate(shape):
+            a.shape[i] = s_
+            a.clip[i] = float((1.0 / lam)[i])
+            a.lambda_mu[i] = float((lam / mu).astype(dt)[i])
+        sums = np.zeros((7, 3))
+        a.data, a.recon_out, a.sums_out = src.ctypes.data, dst.ctypes.data, sums.ctypes.data
+        _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+        assert bits_equal(dst, ref["recon"]), (resident, shift)
+        _check_traces(sums, ref, 7)
 
 
 @pytest.mark.parametrize("shape,dtype,n_f,n_p,stop,rows,k", [

@@ -1,0 +1,158 @@
+// What the PCIe link of an MI355X box gives in each direction, alone and both at once, by mechanism: the runtime's
+// hipMemcpyAsync (SDMA engines / blit kernels) against a copy KERNEL that reads or writes page-locked host memory directly,
+// with and without an HBM-bound kernel running beside them (the sweeps of a streamed tvdn_run, csrc/tvdn_stream.hip).
+//   hipcc -O2 --offload-arch=gfx950 tools/ubench/pcie_duplex.hip -o tools/ubench/pcie_duplex -lpthread
+// One JSON object per experiment.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <sys/mman.h>
+
+#define CK(x)                                                                  \
+    do {                                                                       \
+        hipError_t e_ = (x);                                                   \
+        if (e_ != hipSuccess) {                                                \
+            printf("{\"error\": \"%s: %s\"}\n", #x, hipGetErrorString(e_));    \
+            exit(1);                                                           \
+        }                                                                      \
+    } while (0)
+
+static double now()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+typedef float vec_t __attribute__((ext_vector_type(4)));
+
+// grid-stride copy of n 16-byte elements
+__global__ void __launch_bounds__(256) copy_kernel(vec_t *__restrict__ d, const vec_t *__restrict__ s, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x; i < n; i += stride) {
+        vec_t a0 = __builtin_nontemporal_load(s + i), a1, a2, a3;
+        const bool b1 = i + 256 < n, b2 = i + 512 < n, b3 = i + 768 < n;
+        if (b1) a1 = __builtin_nontemporal_load(s + i + 256);
+        if (b2) a2 = __builtin_nontemporal_load(s + i + 512);
+        if (b3) a3 = __builtin_nontemporal_load(s + i + 768);
+        __builtin_nontemporal_store(a0, d + i);
+        if (b1) __builtin_nontemporal_store(a1, d + i + 256);
+        if (b2) __builtin_nontemporal_store(a2, d + i + 512);
+        if (b3) __builtin_nontemporal_store(a3, d + i + 768);
+    }
+}
+
+// HBM-bound background work: x = x * 1.0001 over a big buffer
+__global__ void __launch_bounds__(256) scale_kernel(vec_t *x, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = x[i] * 1.0001f;
+}
+
+static char *pinned(size_t bytes)
+{
+    char *p = (char *)mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    madvise(p, bytes, MADV_HUGEPAGE);
+    std::vector<std::thread> th;
+    for (int t = 0; t < 16; ++t)
+        th.emplace_back([=] {
+            for (size_t o = bytes / 16 * t; o < bytes / 16 * (t + 1); o += 4096) p[o] = 1;
+        });
+    for (auto &t : th) t.join();
+    CK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return p;
+}
+
+int main(int argc, char **argv)
+{
+    const size_t piece = size_t(512) << 20;  // one transfer
+    const int n_piece = argc > 1 ? atoi(argv[1]) : 12;
+    CK(hipSetDevice(0));
+    char *h_up = pinned(piece * 2), *h_dn = pinned(piece * 2);
+    char *d_up, *d_dn;
+    vec_t *big;
+    const size_t big_n = (size_t(4) << 30) / 16;
+    CK(hipMalloc(&d_up, piece * 2));
+    CK(hipMalloc(&d_dn, piece * 2));
+    CK(hipMalloc(&big, big_n * 16));
+    CK(hipMemset(d_dn, 1, piece * 2));
+    CK(hipMemset(big, 0, big_n * 16));
+    hipStream_t s_up, s_dn, s_bg;
+    int least, greatest;
+    CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    CK(hipStreamCreateWithPriority(&s_up, hipStreamNonBlocking, 0));
+    CK(hipStreamCreateWithPriority(&s_dn, hipStreamNonBlocking, least));
+    CK(hipStreamCreateWithPriority(&s_bg, hipStreamNonBlocking, greatest));
+
+    // mode: 0 none, 1 hipMemcpyAsync, >1 copy kernel with that many workgroups
+    auto issue = [&](bool up, int mode, int i) {
+        const size_t off = (size_t)(i & 1) * piece;
+        if (mode == 0) return;
+        if (up) {
+            if (mode == 1)
+                CK(hipMemcpyAsync(d_up + off, h_up + off, piece, hipMemcpyHostToDevice, s_up));
+            else
+                hipLaunchKernelGGL(copy_kernel, dim3(mode), dim3(256), 0, s_up, (vec_t *)(d_up + off), (const vec_t *)(h_up + off), piece / 16);
+        } else {
+            if (mode == 1)
+                CK(hipMemcpyAsync(h_dn + off, d_dn + off, piece, hipMemcpyDeviceToHost, s_dn));
+            else
+                hipLaunchKernelGGL(copy_kernel, dim3(mode), dim3(256), 0, s_dn, (vec_t *)(h_dn + off), (const vec_t *)(d_dn + off), piece / 16);
+        }
+    };
+    auto experiment = [&](const char *what, int up_mode, int dn_mode, bool background) {
+        CK(hipDeviceSynchronize());
+        hipEvent_t u0, u1, d0, d1, b0, b1;
+        for (hipEvent_t *e : {&u0, &u1, &d0, &d1, &b0, &b1}) CK(hipEventCreate(e));
+        int n_bg = 0;
+        CK(hipEventRecord(u0, s_up));
+        CK(hipEventRecord(d0, s_dn));
+        CK(hipEventRecord(b0, s_bg));
+        const double t0 = now();
+        for (int i = 0; i < n_piece; ++i) {
+            issue(true, up_mode, i);
+            issue(false, dn_mode, i);
+            if (background)
+                for (int j = 0; j < 6; ++j, ++n_bg) hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((big_n + 255) / 256)), dim3(256), 0, s_bg, big, big_n);
+        }
+        CK(hipEventRecord(u1, s_up));
+        CK(hipEventRecord(d1, s_dn));
+        CK(hipEventRecord(b1, s_bg));
+        CK(hipDeviceSynchronize());
+        const double wall = now() - t0;
+        float tu = 0, td = 0, tb = 0;
+        CK(hipEventElapsedTime(&tu, u0, u1));
+        CK(hipEventElapsedTime(&td, d0, d1));
+        CK(hipEventElapsedTime(&tb, b0, b1));
+        const double gb = (double)piece * n_piece / 1e9;
+        printf("{\"what\": \"%s\", \"up\": %d, \"down\": %d, \"background\": %s, \"h2d_GBps\": %.1f, \"d2h_GBps\": %.1f, \"wall_s\": %.3f", what, up_mode,
+               dn_mode, background ? "true" : "false", up_mode ? gb / (tu * 1e-3) : 0.0, dn_mode ? gb / (td * 1e-3) : 0.0, wall);
+        if (background) printf(", \"background_TBps\": %.2f", (double)n_bg * big_n * 32 / (tb * 1e-3) / 1e12);
+        printf("}\n");
+        fflush(stdout);
+        for (hipEvent_t e : {u0, u1, d0, d1, b0, b1}) CK(hipEventDestroy(e));
+    };
+    for (int bg = 0; bg < 2; ++bg) {
+        experiment("background alone", 0, 0, bg);
+        experiment("memcpy up alone", 1, 0, bg);
+        experiment("memcpy down alone", 0, 1, bg);
+        experiment("memcpy both", 1, 1, bg);
+        for (int g : {4, 8, 16, 32, 64, 128}) {
+            experiment("kernel down alone", 0, g, bg);
+            experiment("kernel up alone", g, 0, bg);
+        }
+        for (int g : {8, 16, 32, 64}) {
+            experiment("memcpy up + kernel down", 1, g, bg);
+            experiment("kernel up + memcpy down", g, 1, bg);
+            experiment("kernel both", g, g, bg);
+        }
+    }
+    return 0;
+}
