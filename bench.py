@@ -81,6 +81,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of each timed CPU leg")
     ap.add_argument("--no-preflight", action="store_true", help="N > 1: skip the bit-exactness check of the exchange")
+    ap.add_argument("--cpu-child", type=str, default=None, metavar="NPY",
+                    help="internal: run ONLY the CPU baseline on the cube saved at NPY ('' = the 1/16 sample) and print its JSON")
     return ap.parse_args()
 
 
@@ -166,6 +168,29 @@ def cpu_baseline(target_s, x_host=None):
                       f"{dt:.1f} s, OMP_NUM_THREADS={cores}; oracle/libtvdn_oracle_timed.so = the reference's five "
                       f"passes, visiting order, dtype-width sums and serial boundary hyperslab")
     return out
+
+
+def cpu_baseline_in_child(target_s, x_host):
+    """The CPU leg in a process of its own (thread binding: see main): the cube travels through /dev/shm when it fits there."""
+    import numpy as np
+    path = ""
+    try:
+        if x_host is not None:
+            st = os.statvfs("/dev/shm")
+            if st.f_bavail * st.f_frsize > x_host.nbytes + (1 << 30):
+                path = f"/dev/shm/tvdn_bench_cube_{os.getpid()}.npy"
+                np.save(path, x_host)
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", path, "--cpu-seconds", str(target_s)]
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        for line in reversed(out.stdout.splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"error": f"CPU child rc {out.returncode}: {out.stderr[-400:]}"}
+    except Exception as e:
+        return {"error": repr(e)}
+    finally:
+        if path and os.path.exists(path):
+            os.remove(path)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -384,7 +409,7 @@ def api_denoise4d(x, iters_list, device=0):
     return out
 
 
-def api_streamed(shape, rows, k, iters, what, x=None, device=0, force_stream=False):
+def api_streamed(shape, rows, k, iters, what, x=None, device=0, force_stream=False, resident=-1):
     """tvdn_run (the C entry, csrc/tvdn_stream.hip) on a cube whose state stays in page-locked HOST memory: `rows`-row
     chunks, `k` iterations per PCIe round trip (-1 / -1: the library's own choice).  Reports the rate of the passes, the
     PCIe rates beside it (tvdn_run_stats), set-up and whole-call time.  Skips, visibly, when the host cannot hold the state."""
@@ -394,7 +419,7 @@ def api_streamed(shape, rows, k, iters, what, x=None, device=0, force_stream=Fal
     nd = len(shape)
     entry = {"config": {"workload": what, "global_shape": list(shape), "engine": "tvdn_run streamed (csrc/tvdn_stream.hip)"}}
     a = _lib.RunArgs(dtype=0, ndim=nd, bc_mode=2, device=device, n_fista=iters, n_plain=0, stream_rows=rows, stream_k=k,
-                     stream_resident=-1)
+                     stream_resident=resident)
     for i, v in enumerate(shape):
         a.shape[i] = int(v)
     if force_stream and rows < 0:
@@ -403,6 +428,9 @@ def api_streamed(shape, rows, k, iters, what, x=None, device=0, force_stream=Fal
         po = _lib.StreamPlanOut()
         _lib.check(_lib.lib().tvdn_stream_plan(C.byref(a), 0, C.byref(po)))
         a.stream_rows, a.stream_k, a.stream_resident = int(po.rows), int(po.k), int(po.resident_rows)
+        if iters < 0:                        # -n: n passes of the planned depth (whole PCIe round trips)
+            iters = -iters * int(po.k)
+            a.n_fista = iters
     mu = np.array([1.0, 1.0, 0.5, 0.5], np.float32)
     lam = mu / np.float32(32.0)
     for q in range(nd):
@@ -497,10 +525,18 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # libgomp reads these when it is first loaded (numpy/torch pull it in): set them before any import
+    # libgomp reads these when it is first loaded (numpy/torch pull it in): set them before any import.  The thread BINDING
+    # SURVEY 8d asks of the CPU leg (OMP_PROC_BIND=spread, OMP_PLACES=cores) is set in a child process that runs nothing but
+    # that leg: with it in this process libgomp pins the MAIN thread to one core, every host thread the library starts
+    # (staging lanes, page-touching, copies) inherits that mask, and the API-level entries measure one core's memcpy.
     os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))
-    os.environ.setdefault("OMP_PROC_BIND", "spread")
-    os.environ.setdefault("OMP_PLACES", "cores")
+    if a.cpu_child is not None:
+        os.environ.setdefault("OMP_PROC_BIND", "spread")
+        os.environ.setdefault("OMP_PLACES", "cores")
+        import numpy as np
+        x = np.load(a.cpu_child, mmap_mode="r") if a.cpu_child else None
+        print(json.dumps(cpu_baseline(a.cpu_seconds, None if x is None else np.ascontiguousarray(x))), flush=True)
+        return
 
     import numpy as np
     import torch
@@ -595,23 +631,36 @@ def main():
     api = None
     if headline and rank == 0 and not a.no_api:
         api = []
-        x2 = None
+        x2 = x_half = None
         try:
             x2 = synth_host(shape, local_rank)
             api.extend(api_denoise4d(x2, (50, 200), local_rank))                               # NumPy -> NumPy, PCIe included
         except Exception as e:
             api.append({"config": {"workload": "cytvdn_amd.denoise4D NumPy -> NumPy"}, "error": repr(e)})
-        for shp, rows, k, iters, what, xin in (
-                (shape, 16, 128, 256, "BASELINE config 2 cube advanced from HOST-resident state (streamed tvdn_run, 16-row "
-                                      "chunks, 128 iterations per PCIe round trip)", x2),
-                ((64, 1024, 256, 256), -1, -1, 80, "BASELINE config 5 planes on one GPU: HALF a rank slab (64x1024x256x256 of the "
-                                                   "128 rows a rank of 8 holds), out-of-core, the library's own (rows, k)", None)):
+        half = (64, 1024, 256, 256)
+        for shp, rows, k, iters, what, xin, resident in (
+                # (the tallest device block first: the library keeps it, and the later runs carve theirs out of it instead of
+                #  releasing and re-allocating a quarter of a TB, which stalls for seconds while the driver clears the memory)
+                (half, -1, -1, 80, "BASELINE config 5 planes on one GPU, OUT OF CORE: HALF a rank slab (64x1024x256x256 of the 128 rows a "
+                                   "rank of 8 holds; a whole one needs 320 GiB of page-locked host memory, this box's control group allows "
+                                   "300), forced through the streamed tvdn_run with the library's own plan (rows, k, rows resident in HBM)",
+                 None, -1),
+                (half, -1, -1, -2, "the same half rank slab with EVERY row streamed (stream_resident = 0, the library's deepest k, two "
+                                   "passes of it): the PCIe-bound regime a whole rank slab of config 5 is in", None, 0),
+                (shape, 16, 128, 256, "BASELINE config 2 cube advanced from HOST-resident state (streamed tvdn_run, 16-row chunks, 128 "
+                                      "iterations per PCIe round trip, no rows resident)", "config2", 0)):
             try:
-                if xin is None:
-                    x2 = None                                       # drop the 4 GiB cube before the 16 GiB one
-                api.append(api_streamed(shp, rows, k, iters, what, xin, local_rank))
+                if xin == "config2":
+                    x_half = None
+                    xin = x2
+                else:
+                    if x_half is None:
+                        x_half = synth_host(shp, local_rank)
+                    xin = x_half
+                api.append(api_streamed(shp, rows, k, iters, what, xin, local_rank, force_stream=True, resident=resident))
             except Exception as e:
                 api.append({"config": {"workload": what}, "error": repr(e)})
+        x_half = None
         x2 = None
 
     cpu = None
@@ -625,7 +674,8 @@ def main():
             x_host = buf.cpu().numpy()
             del buf
             torch.cuda.empty_cache()
-        cpu = cpu_baseline(a.cpu_seconds, x_host)
+        cpu = cpu_baseline_in_child(a.cpu_seconds, x_host)
+        del x_host
 
     if rank == 0:
         out = {"metric": "Gvoxel-iters/s (4D aniso FISTA)", "value": main_res["value"], "unit": "Gvoxel-iters/s",

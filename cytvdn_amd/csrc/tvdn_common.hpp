@@ -219,7 +219,7 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
 int run_streamed(const tvdn_run_args *a, int64_t rows, int64_t k, int64_t resident_rows);
 // tvdn_run.hip: the big device block of a run is KEPT when the run ends (one per device) and handed to the next run it fits
 // (releasing and re-allocating tens of GiB in quick succession costs seconds); tvdn_release_cache() returns it
-hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, bool *reused);
+hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, bool *reused, bool any_larger);
 void state_release(void *p, size_t bytes, int device);
 size_t state_kept_bytes(int device);  // counts as free: the next run takes it over or releases it
 // Entry points that select a device put the calling thread's current device back before they return: a library that leaves

@@ -288,8 +288,15 @@ __device__ __forceinline__ long long row_slot(long long m, unsigned ring)
     return RING ? (long long)((unsigned)m % ring) : m;
 }
 
+// TVDN_WAVES_PER_EU (measurement builds only, tools/build_variants.sh waves): pin the occupancy the register allocator aims for
+#ifdef TVDN_WAVES_PER_EU
+#define TVDN_OCCUPANCY __attribute__((amdgpu_waves_per_eu(TVDN_WAVES_PER_EU, TVDN_WAVES_PER_EU)))
+#else
+#define TVDN_OCCUPANCY
+#endif
+
 template <typename T, int VEC, int NAX, int MODE, bool RING, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) fused_iter_kernel(FusedParams<T> p)
+__global__ void __launch_bounds__(BLOCK) TVDN_OCCUPANCY fused_iter_kernel(FusedParams<T> p)
 {
     using P = Pack<T, VEC>;
     using MT = ModeTraits<MODE>;

@@ -48,15 +48,16 @@ static hipError_t state_malloc(void **p, size_t bytes)
     return hipMalloc(p, bytes);
 }
 
-// the kept block of `device` if it holds `bytes` without being more than a quarter larger, else a fresh allocation
-hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, bool *reused)
+// the kept block of `device` if it holds `bytes` without being more than a quarter larger (`any_larger`: however much larger -- a
+// streamed run carves rings out of it and is indifferent to where they lie), else a fresh allocation
+hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, bool *reused, bool any_larger)
 {
     *reused = false;
     if (keep_state() && device >= 0 && device < TVDN_MAX_DEVICES) {
         std::lock_guard<std::mutex> lk(g_state_cache.mu);
         void *&c = g_state_cache.p[device];
         size_t &cb = g_state_cache.bytes[device];
-        if (c && cb >= bytes && cb - bytes <= bytes / 4) {
+        if (c && cb >= bytes && (any_larger || cb - bytes <= bytes / 4)) {
             *p = c;
             *got_bytes = cb;
             c = nullptr;
@@ -281,7 +282,7 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
         } else {
             // one slab: the block the last run of this device left behind, if it fits (StateCache above)
             if (world == 1) {
-                TVDN_HIP(state_acquire(&s.state.p, stride * (size_t)n_arr, &s.state.bytes, s.device, &state_reused));
+                TVDN_HIP(state_acquire(&s.state.p, stride * (size_t)n_arr, &s.state.bytes, s.device, &state_reused, false));
                 s.state.keep = true;
             } else {
                 TVDN_HIP(state_malloc(&s.state.p, stride * (size_t)n_arr));
@@ -968,7 +969,11 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
     TVDN_REQUIRE(a->bc_mode == 0 || a->bc_mode == 2, "bc_mode must be 0 or 2, got %d", a->bc_mode);
     if (a->stream_rows > 0) {
         TVDN_REQUIRE(a->n_devices <= 1, "a streamed run uses one device (slabs x streaming: cytvdn_amd.denoise_slabs(staged=...))");
-        return tvdn::run_streamed(a, a->stream_rows, a->stream_k, a->stream_resident);
+        const auto ts = std::chrono::steady_clock::now();
+        const int rcs = tvdn::run_streamed(a, a->stream_rows, a->stream_k, a->stream_resident);
+        if (getenv("TVDN_STREAM_TIMING"))
+            fprintf(stderr, "tvdn_run streamed: whole call %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count());
+        return rcs;
     }
     {   // say clearly when the slabs cannot fit, instead of failing somewhere inside hipMalloc
         const int world = a->n_devices > 0 ? a->n_devices : 1;

@@ -179,10 +179,13 @@ struct HostArr {
         owned = true;
         return TVDN_OK;
     }
-    ~HostArr()
+    void release()
     {
         if (registered) (void)hipHostUnregister(p);
+        registered = false;
+        buf.release();
     }
+    ~HostArr() { release(); }
 };
 
 struct Ring {  // `cap` row-planes; global row g lives at slot g % cap
@@ -208,27 +211,35 @@ struct Events {
 
 struct Streams {
     hipStream_t main = nullptr, up = nullptr, down = nullptr;
-    ~Streams()
+    void release()
     {
-        for (hipStream_t s : {main, up, down})
-            if (s) (void)hipStreamDestroy(s);
+        for (hipStream_t *s : {&main, &up, &down})
+            if (*s) {
+                (void)hipStreamDestroy(*s);
+                *s = nullptr;
+            }
     }
+    ~Streams() { release(); }
 };
 
 struct CtxHolder {
     tvdn_ctx *c = nullptr;
-    ~CtxHolder()
+    void release()
     {
         if (c) (void)tvdn_ctx_destroy(c);
+        c = nullptr;
     }
+    ~CtxHolder() { release(); }
 };
 
 struct DevMem {
     void *p = nullptr;
-    ~DevMem()
+    void release()
     {
         if (p) (void)hipFree(p);
+        p = nullptr;
     }
+    ~DevMem() { release(); }
 };
 
 // "64G" / "512M" / bytes from the environment; 0 = not set
@@ -424,7 +435,8 @@ extern "C" int tvdn_stream_plan(const tvdn_run_args *a, int64_t hbm_free_bytes, 
         size_t free_b = 0, total_b = 0;
         TVDN_HIP(hipSetDevice(a->n_devices > 0 ? a->devices[0] : a->device));
         TVDN_HIP(hipMemGetInfo(&free_b, &total_b));
-        hbm_free_bytes = (int64_t)free_b;
+        // (the block the last run of this device kept is the next run's to take over: it counts as free)
+        hbm_free_bytes = (int64_t)(free_b + state_kept_bytes(a->n_devices > 0 ? a->devices[0] : a->device));
     }
     const bool mse = a->mse_out != nullptr && a->reference != nullptr;
     const int n_state = a->n_fista > 0 ? 2 : 1;
@@ -599,6 +611,9 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
     }
     if (a->use_stop) K = 1;  // the stopping rule needs a decision after every iteration: one level per pass
     K = std::min<int64_t>(K, std::max<int64_t>(1, n_total));
+    // as many passes as this depth needs, of equal depth: 80 iterations at k = 38 are three PCIe round trips whether they hold
+    // 38 + 38 + 4 levels or 27 + 27 + 26, and the shallower rings leave HBM for resident rows
+    if (!a->use_stop) K = (n_total + (n_total + K - 1) / K - 1) / ((n_total + K - 1) / K);
     // Periodic boundaries along axis 0: the sweeps see a virtual cube of N0 + 2 K rows -- the cube between K wrapped rows
     // at either end, which are each other's halo -- and, as at the face between two slabs, give up one row per level at
     // the two artificial faces; the wrap itself is never swept (cytvdn_amd/wavefront.py does the same).
@@ -688,7 +703,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
     mem.device = device;
     {
         bool reused = false;
-        TVDN_HIP(state_acquire(&mem.p, dev_bytes, &mem.bytes, device, &reused));
+        TVDN_HIP(state_acquire(&mem.p, dev_bytes, &mem.bytes, device, &reused, true));
     }
     TVDN_HIP(hipMemsetAsync(mem.p, 0, ring_bytes, st.main));
     char *cursor = (char *)mem.p;
@@ -1198,15 +1213,6 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
         if (last.owned) pack_host_rows(last.p, (char *)a->recon_out, false);
         else if (last.p != (char *)a->recon_out) parallel_copy(a->recon_out, last.p, cube_bytes);
     }
-    const double home_s = since(t_end_passes);
-    // the device block goes back (to the cache) BEFORE the host state starts to be unpinned in the background: a hipFree issued
-    // behind dozens of hipHostUnregister calls waits for them
-    const auto t_free = std::chrono::steady_clock::now();
-    mem.release();
-    if (getenv("TVDN_STREAM_TIMING"))  // measurement aid: set-up apart from the passes
-        fprintf(stderr, "tvdn_run streamed: rows %lld k %lld resident rows %lld of %lld, set-up %.3f s, passes %.3f s (first %.3f s), results home %.3f s, device block released in %.3f s\n",
-                (long long)R, (long long)K, (long long)RES, (long long)N0, std::chrono::duration<double>(t_passes - t_start).count(),
-                std::chrono::duration<double>(t_end_passes - t_passes).count(), first_pass_s, home_s, since(t_free));
     TVDN_HIP(hipMemcpy(a->sums_out, sums_d.p, sizeof(double) * 3 * (size_t)n_total, hipMemcpyDeviceToHost));
     if (want_mse) {
         std::vector<double> per_row((size_t)(n_total + 1) * (size_t)N0);
@@ -1222,6 +1228,34 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
         a->phase_iters[0] = ran_phase[0];
         a->phase_iters[1] = ran_phase[1];
     }
+    const double home_s = since(t_end_passes);
+    // the device block goes back (to the cache) BEFORE the host state starts to be unpinned in the background: a hipFree issued
+    // behind dozens of hipHostUnregister calls waits for them
+    auto t_mark = std::chrono::steady_clock::now();
+    double td[5];
+    auto lap = [&](int i) {
+        td[i] = since(t_mark);
+        t_mark = std::chrono::steady_clock::now();
+    };
+    mem.release();
+    lap(0);
+    sums_d.release();
+    mse_d.release();
+    st.release();
+    ctx.release();
+    lap(1);
+    orig_h.release();
+    recon_h.release();
+    ref_h.release();
+    recon2_h.release();
+    lap(2);
+    for (int s = 0; s < n_sets; ++s) sb[s].blocks.clear();
+    lap(3);
+    if (getenv("TVDN_STREAM_TIMING"))  // measurement aid: set-up apart from the passes
+        fprintf(stderr, "tvdn_run streamed: rows %lld k %lld resident rows %lld of %lld, set-up %.3f s, passes %.3f s (first %.3f s), results home %.3f s; "
+                "released: device block %.3f s, sums/streams/context %.3f s, caller's arrays unpinned %.3f s, host state handed to the background %.3f s\n",
+                (long long)R, (long long)K, (long long)RES, (long long)N0, std::chrono::duration<double>(t_passes - t_start).count(),
+                std::chrono::duration<double>(t_end_passes - t_passes).count(), first_pass_s, home_s, td[0], td[1], td[2], td[3]);
     if (a->stats) {
         tvdn_run_stats &s = *a->stats;
         std::memset(&s, 0, sizeof s);

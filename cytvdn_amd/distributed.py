@@ -234,7 +234,25 @@ def selfcheck_exchange(group=None, device=None, iterations: int = 6, dtype=np.fl
         torch.cuda.synchronize(device)
         return be.recon_tensor()[lay.row_lo:lay.row_hi].clone(), r.transport
 
-    res = {"overlap": False, "blocking": False, "transport": None, "error": None}
+    res = {"overlap": False, "blocking": False, "transport": None, "error": None, "world": world, "ranks_seen": None,
+           "distinct_gpus": None}
+    # who is really there: every rank adds 1 through the data-plane group itself, and names its GPU (PCI bus id) through
+    # whatever group exists -- eight ranks that all landed on one GPU would pass every bit test and measure nothing
+    try:
+        one = torch.ones(1, dtype=torch.int32)
+        if dist.get_backend(group) == "nccl":
+            one = one.to(torch.device("cuda", device))
+        dist.all_reduce(one, group=group)
+        res["ranks_seen"] = int(one.item())
+        try:
+            bus = str(torch.cuda.get_device_properties(device).pci_bus_id) + ":" + str(torch.cuda.get_device_properties(device).pci_device_id)
+        except Exception:
+            bus = f"index{device}"
+        names = [None] * world
+        dist.all_gather_object(names, f"{os.uname().nodename}/{bus}/{device}", group=group if dist.get_backend(group) != "nccl" else None)
+        res["distinct_gpus"] = len(set(n for n in names if n))
+    except Exception as e:
+        res["error"] = f"census: {e!r}"
     lay = SlabLayout(shape, rank, world, 2)
     want, _ = run(SlabLayout(shape, 0, 1, 2), False, None)
     want = want[lay.g0:lay.g1]

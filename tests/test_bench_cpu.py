@@ -51,3 +51,13 @@ def test_world_size_must_match(monkeypatch):
 
 def test_host_probes():
     assert bench.host_cores() >= 1 and bench.mem_available_gib() > 0
+
+
+def test_traffic_json_is_what_the_script_makes_of_the_committed_csvs(tmp_path):
+    """profiles/traffic.json (what bench.py copies into roofline.traffic) is generated, not edited: tools/make_traffic_json.py
+    rebuilds it byte for byte from the committed per-workload PMC CSVs."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_traffic_json
+    out = tmp_path / "traffic.json"
+    make_traffic_json.write_traffic("r04", str(out))
+    assert out.read_bytes() == open(os.path.join(ROOT, "profiles", "traffic.json"), "rb").read()

@@ -41,7 +41,8 @@ def worker(rank, world, port, a, q):
     from cytvdn_amd.distributed import slab_rows
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    dev = rank % torch.cuda.device_count() if a.gpu_per_rank else 0
+    torch.cuda.set_device(dev)
     shape = tuple(int(v) for v in a.shape.split("x"))
     nd = len(shape)
     dt = np.dtype(np.float32)
@@ -52,7 +53,7 @@ def worker(rank, world, port, a, q):
     for r in range(g0, g1, step):
         n = min(step, g1 - r)
         _lib.check(_lib.lib().tvdn_synth_fill(0, nd, _lib.shape_arr(shape), synth.SEED_4D if nd == 4 else synth.SEED_3D,
-                                              r, n, buf.data_ptr(), _lib.current_stream(0)))
+                                              r, n, buf.data_ptr(), _lib.current_stream(dev)))
         own[r - g0:r - g0 + n] = buf[:n].cpu().numpy()
     del buf
     mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
@@ -60,7 +61,7 @@ def worker(rank, world, port, a, q):
     from cytvdn_amd.wavefront import WavefrontRunner
     t0 = time.perf_counter()
     # what distributed.denoise_slabs(..., staged=(rows, k)) builds (cytvdn_amd/distributed.py), timed in two parts
-    wr = WavefrontRunner(own, True, 1.0 / lam, (lam / mu).astype(dt), device=0, chunk_rows=a.rows, k=min(a.k, g1 - g0),
+    wr = WavefrontRunner(own, True, 1.0 / lam, (lam / mu).astype(dt), device=dev, chunk_rows=a.rows, k=min(a.k, g1 - g0),
                          max_iters=a.iters, global_rows=shape[0], row0=g0, world=world, rank=rank)
     t_pin = time.perf_counter() - t0
     dist.barrier()
@@ -83,6 +84,7 @@ def main():
     ap.add_argument("--rows", type=int, default=16)
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--iters", type=int, default=64)
+    ap.add_argument("--gpu-per-rank", action="store_true", help="rank r on GPU r (a multi-GPU node) instead of all ranks on GPU 0")
     a = ap.parse_args()
     import numpy as np
     import torch.multiprocessing as mp
@@ -98,7 +100,7 @@ def main():
         p.join()
     shape = tuple(int(v) for v in a.shape.split("x"))
     vox = float(np.prod(shape))
-    res.update({"metric": "Gvoxel-iters/s (4D aniso FISTA, staged slabs, %d ranks on ONE GPU over gloo)" % a.ranks,
+    res.update({"metric": "Gvoxel-iters/s (4D aniso FISTA, staged slabs, %d ranks %s over gloo)" % (a.ranks, "one GPU each" if a.gpu_per_rank else "on ONE GPU"),
                 "value": round(vox * a.iters / res["seconds"] / 1e9, 2), "unit": "Gvoxel-iters/s", "shape": list(shape),
                 "ranks": a.ranks, "chunk_rows": a.rows, "k": a.k, "iters": a.iters,
                 "state_GiB_compact": round(15 * vox * 4 / 2 ** 30, 1), "wall_s": round(time.perf_counter() - t0, 1)})

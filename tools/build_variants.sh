@@ -13,6 +13,10 @@ if [ "$1" = "blocks" ]; then   # workgroup sizes of the fused sweep, for tools/a
   build ntm4 "-DTVDN_NTMASK=4" &
   wait; ls -la tools/ubench/*blk*.so; exit 0
 fi
+if [ "$1" = "waves" ]; then   # round 4: occupancy targets of the fused sweep (amdgpu_waves_per_eu)
+  for w in 3 4 5 6 7 8; do build wav$w "-DTVDN_WAVES_PER_EU=$w" & done
+  wait; ls -la tools/ubench/*wav*.so; exit 0
+fi
 if [ "$1" = "ntmask" ]; then   # round 3: which accumulator-state loads stream past the L2 (csrc/tvdn_fused.hip, kNtMask)
   for m in 1 2 3 7 11 27 31 4 16; do build ntm$m "-DTVDN_NTMASK=$m" & done
   wait; ls -la tools/ubench/*ntm*.so; exit 0

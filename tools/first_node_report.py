@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""One page from the logs of tools/first_node_run.sh: which steps ran, the JSON line of every bench.py run (value, transport,
+pre-flight verdicts, ranks seen / distinct GPUs) and the weak-scaling efficiency against the 1-GPU line."""
+import json
+import os
+import sys
+
+
+def last_json(path):
+    try:
+        for line in reversed(open(path).read().splitlines()):
+            line = line.strip()
+            if line.startswith("{") and line.endswith("}"):
+                return json.loads(line)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def main():
+    o = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/first_node"
+    print(open(os.path.join(o, "summary.txt")).read().rstrip())
+    base = None
+    for name in sorted((f for f in os.listdir(o) if f.startswith("bench_gpus_") and f.endswith(".out")),
+                       key=lambda f: int(f[len("bench_gpus_"):-4])):
+        d = last_json(os.path.join(o, name))
+        n = int(name[len("bench_gpus_"):-4])
+        if d is None:
+            print(f"--gpus {n}: no JSON line (see {name[:-4]}.err)")
+            continue
+        pf = d.get("preflight") or {}
+        per_gpu = d["value"] / max(1, d["n_gpus"])
+        if n == 1:
+            base = d["value"]
+        eff = f", {d['value'] / base:.2f}x the 1-GPU line" if base else ""
+        ok = (pf.get("ranks_seen") in (None, d["n_gpus"])) and (pf.get("distinct_gpus") in (None, d["n_gpus"]))
+        print(f"--gpus {n}: {d['value']} {d['unit']} ({per_gpu:.1f} per GPU{eff}), {d['ms_per_step']} ms per step, "
+              f"transport {d['config'].get('transport')}, overlap {d['config'].get('overlap')}, fallback {d.get('transport_fallback')}, "
+              f"preflight overlap/blocking {pf.get('overlap')}/{pf.get('blocking')}, ranks seen {pf.get('ranks_seen')} of {pf.get('world')}, "
+              f"distinct GPUs {pf.get('distinct_gpus')}{'' if ok else '  <-- NOT one GPU per rank'}, roofline frac {d['roofline']['frac']}")
+    d = last_json(os.path.join(o, "staged_slabs.out"))
+    if d:
+        print(f"staged slabs: {d.get('value')} {d.get('unit')} on {d.get('ranks')} ranks, shape {d.get('shape')}, chunk rows {d.get('chunk_rows')}, "
+              f"k {d.get('k')}, PCIe rank 0 {d.get('h2d_GBps_rank0')} + {d.get('d2h_GBps_rank0')} GB/s")
+
+
+if __name__ == "__main__":
+    main()

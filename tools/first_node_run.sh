@@ -1,0 +1,47 @@
+#!/usr/bin/env bash
+# One-shot kit for the FIRST run on a multi-GPU MI355X node (no round so far had one: RCCL has never executed, SURVEY 8e /
+# BASELINE configs[3] and [4] have no hardware number).  Every step runs in its own process under its own timeout with its log
+# kept, a failing step does not stop the later ones, and nothing here starts more ranks than the node has GPUs:
+#   1. tests/test_gpu_rccl.py            the RCCL data path against the oracle (2 and 3 ranks, chain / ring, overlapped / blocking)
+#   2. bench.py --gpus 2, 4, 8           weak scaling of BASELINE configs[3] (one 64-row slab of 512x256x256 planes per GPU),
+#                                        each with its pre-flight (bit-exact exchange, ranks seen == world, one GPU per rank)
+#   3. tools/bench_staged_slabs.py       BASELINE configs[4] in structure: every rank streams its slab from page-locked host
+#                                        memory (needs 40 GiB of host memory per rank at the default shape)
+#   4. tools/first_node_report.py        one page: what ran, what it gave, scaling efficiency against the 1-GPU line
+# Usage (on the node, from the repo root):   bash tools/first_node_run.sh [OUTDIR]
+# Rehearsal on a one-GPU box (several ranks share the GPU, halo rows staged through host memory over gloo; at most 6 processes
+# may use a GPU at once on the pool's boxes, launcher included: 4 ranks is the most that rehearses safely):   TVDN_DIST_BACKEND=gloo REHEARSE_RANKS="2 4" REHEARSE_SHAPE=1 bash tools/first_node_run.sh
+set -u -o pipefail
+O=${1:-gpurun_out/first_node}
+mkdir -p "$O"
+: > "$O/summary.txt"
+NGPU=$(python3 -c "import torch; print(torch.cuda.device_count())" 2>/dev/null || echo 0)
+echo "GPUs visible: $NGPU" | tee -a "$O/summary.txt"
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+step() {  # name, timeout seconds, command...
+  local name=$1 t=$2; shift 2
+  local t0=$SECONDS
+  timeout -k 10 "$t" "$@" > "$O/$name.out" 2> "$O/$name.err"
+  local rc=$?
+  echo "$name rc=$rc $((SECONDS - t0)) s" | tee -a "$O/summary.txt"
+}
+RANKS=${REHEARSE_RANKS:-"2 4 8"}
+step rccl_tests 900 python3 -m pytest tests/test_gpu_rccl.py -q -p no:cacheprovider
+step bench_gpus_1 900 python3 bench.py --gpus 1 --steps 10 --warmup 3 --no-also --no-sustained --no-api --audition-extra 0 --no-cpu-baseline
+for n in $RANKS; do
+  if [ -n "${REHEARSE_SHAPE:-}" ]; then
+    # rehearsal: a slab of 2 rows of small planes per rank, the ranks share the GPU(s) that exist
+    step bench_gpus_$n 300 python3 bench.py --gpus "$n" --steps 6 --warmup 2 --shape $((2 * n))x64x64x64
+  elif [ "$n" -le "$NGPU" ]; then
+    step bench_gpus_$n 900 python3 bench.py --gpus "$n" --steps 10 --warmup 3
+  else
+    echo "bench_gpus_$n skipped: $NGPU GPUs" | tee -a "$O/summary.txt"
+  fi
+done
+if [ -n "${REHEARSE_SHAPE:-}" ]; then
+  step staged_slabs 300 python3 tools/bench_staged_slabs.py --shape 32x64x64x64 --ranks 2 --rows 4 --k 4 --iters 8
+elif [ "$NGPU" -ge 2 ]; then
+  # config 5 in structure at a size every node can pin: the config-2 planes, 32 rows per rank, one GPU per rank
+  step staged_slabs 1200 python3 tools/bench_staged_slabs.py --shape $((32 * NGPU))x256x128x128 --ranks "$NGPU" --gpu-per-rank --rows 8 --k 24 --iters 48
+fi
+python3 tools/first_node_report.py "$O" | tee "$O/report.txt"
