@@ -19,24 +19,26 @@ sweep kernel, from HIP events recorded around that kernel on its own stream duri
 The compact state of this engine moves fewer bytes than that yardstick (15 passes = 60 B per voxel); what the
 kernel really streams is reported next to it as roofline.moved_GBps / roofline.moved_frac.
 
+The headline runs on the FIRST allocation of the state: the sweep's speed depends on which physical pages that allocation got
+(same clocks, same virtual address, 11.0 ... 12.6 ms for config 2: profiles/r03_placement_audition_*.jsonl), denoise3D/4D take
+the first one below 400 iterations and audition 3-4 from there on, so a single draw is what a typical call gets.
+
 At N = 1 the line also carries
-  also          the other single-GPU configurations on the same clock: BASELINE configs[2] (float64,
-                unaccelerated), the configs[0] shape on the GPU (3-D FISTA 128x128x512), and ONE slab of
-                configs[3] (66x512x256x256 local block, halo edges, edge rows first, halo rows refreshed by
-                device copies of the same size as the RCCL messages) = the per-GPU term of the weak-scaling curve
-  cpu_baseline  the reference-structured CPU restatement (oracle/libtvdn_oracle_timed.so, kind "port": the
-                reference's five passes per iteration, its visiting order, dtype-width sums and serial
-                boundary hyperslab) on the host cores of the same box, on config 2 itself when the host has
-                the memory for it.  Nothing built from the reference's sources runs (or travels) here: how the port
-                compares with the reference's own compiled kernels is measured in the build container by
-                tools/port_vs_reference.py (profiles/r03_port_vs_reference.json).
-  sustained     config 2 again for >= 300 steps (several seconds of sweeps) with the same fields: what a user's
-                200-iteration denoise4D sees once the device has settled, next to the short headline run.
-  placement     the sweep's speed depends on which physical pages the state's allocation got (same clocks, same virtual
-                address, 11.2 / 12.1 / 12.6 ms for config 2: profiles/r03_placement_audition_*.jsonl), so the engine tries
-                --audition N placements (default 4, as many as fit the HBM) and keeps the fastest -- as denoise3D/4D do
-                for runs of >= 400 iterations; config.placement_audition_ms lists the candidates' probe times (kept one
-                first), so the spread of the box is in the line.  Untimed set-up, like the allocation itself.
+  best_placement  the headline workload once more on the fastest of --audition-extra (4) placements, candidates' probe times
+                  listed (kept one first): the spread of the box is in the line
+  sustained     config 2 again for >= 400 steps under the product's own audition rule (3 candidates): what a long run sees
+  also          the other single-GPU configurations on the same clock: BASELINE configs[2] (float64, unaccelerated), the
+                configs[0] shape on the GPU (3-D FISTA 128x128x512), ONE slab of configs[3] (66x512x256x256 local block, halo
+                edges, edge rows first, halo rows refreshed by device copies of the size of the RCCL messages) = the per-GPU term
+                of the weak-scaling curve; and the API level, PCIe included (never `value`): cytvdn_amd.denoise4D NumPy -> NumPy
+                at 50 and 200 iterations, and tvdn_run streamed from page-locked host memory (tvdn_run_stats: passes-only rate,
+                h2d / d2h GB/s, set-up and whole-call seconds) -- half a rank slab of BASELINE configs[4] with the library's
+                plan (rows resident in HBM) and with every row streamed, and the config-2 cube from host-resident state
+  cpu_baseline  the reference-structured CPU restatement (oracle/libtvdn_oracle_timed.so, kind "port": the reference's five
+                passes per iteration, its visiting order, dtype-width sums and serial boundary hyperslab) on the host cores of
+                the same box, on config 2 itself when the host has the memory for it, in a CHILD process (the thread binding
+                SURVEY 8d asks of it must not leak into the library's host threads).  Nothing built from the reference's
+                sources runs (or travels) here: port / reference = 0.94, profiles/r03_port_vs_reference.json.
 Every roofline object carries the per-step sweep-kernel time as mean, minimum, median and maximum (HIP events per launch).
 """
 import argparse

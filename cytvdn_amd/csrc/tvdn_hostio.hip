@@ -395,7 +395,8 @@ extern "C" int tvdn_stream_mix(int32_t n_read, const void *const *in, int32_t n_
     TVDN_MIX(8, 4)   // 3-D FISTA, compact state
     TVDN_MIX(5, 4)   // 3-D unaccelerated
     TVDN_MIX(1, 1)   // plain copy
+    TVDN_MIX(9, 4)   // 4-D FISTA without a stored recon (rebuilt from orig and the d pairs): orig, 4 x (d_k, d_k-1) in; 4 x d_k+1 out
 #undef TVDN_MIX
-    tvdn::set_error("stream mix %d in / %d out is not instantiated (10/5, 6/5, 8/4, 5/4, 1/1)", n_read, n_write);
+    tvdn::set_error("stream mix %d in / %d out is not instantiated (10/5, 6/5, 8/4, 5/4, 1/1, 9/4)", n_read, n_write);
     return TVDN_ERR_UNSUPPORTED;
 }

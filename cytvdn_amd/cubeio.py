@@ -2,9 +2,9 @@
 
 The reference's MPI driver memory-maps its input (ncempy / py4DSTEM / h5py, cyTVDN/mpi.py:95-124), loads each
 rank's tile as float32 (:217-239) and writes the result into a hand-built EMD v0.7 HDF5 file (:446-498).  The
-counterpart here feeds the in-core and the out-of-core engines straight from a memory-mapped file, row block by row
-block (the dtype conversion of :217-239 happens per block, never on the whole cube), and writes the result row
-block by row block into the output file:
+counterpart here hands the engines the memory-mapped file itself when it holds the compute dtype (the library reads it in
+place: staged through its pinned lanes, or page-locked), converts any other dtype block by block (:217-239 does it per tile),
+and lets the result land in the output file's own memory map (.npy / raw) or writes it block by block (HDF5 / EMD):
 
     b_norm, delta_recon = denoise_file("scan.npy", "scan_denoised.npy", mu=[1, 1, .5, .5], iterations=50)
 
@@ -171,10 +171,25 @@ def denoise_file(input_path, output_path, mu, iterations=10, FISTA=True, stoppin
         if nd == 3:
             lam_mu = (lam / mu).astype(dt)
             assert np.all(lam_mu <= (1.0 / 16.0)) & np.all(lam_mu > 0), "Parameters must satisfy 0 < λ/μ <= 1/16"
+        # The engines see arrays: a stored cube of the compute dtype IS one (its memory map, read in place), any other is
+        # converted block by block (mpi.py:217-239 converts per tile); the result lands in the output file's own memory map
+        # where the format has one (.npy / raw), else it is written block by block (HDF5 / EMD).
+        if isinstance(src.src, np.ndarray) and src.src.dtype == dt and src.src.flags["C_CONTIGUOUS"]:
+            x = src.src
+        else:
+            x = np.empty(src.shape, dt)
+            step = src.block_rows()
+            for a0 in range(0, src.shape[0], step):
+                x[a0:a0 + step] = src.read_rows(a0, min(a0 + step, src.shape[0]))
         out = CubeWriter(output_path, src.shape, dt)
         try:
-            res = driver._run(nd, src, mu, lam, iterations, FISTA, stopping_relative_change, None, BC_mode, quiet,
-                              device, out=out)
+            target = out.arr if isinstance(out.arr, np.ndarray) and out.arr.dtype == dt else None
+            res = driver._run(nd, x, mu, lam, iterations, FISTA, stopping_relative_change, None, BC_mode, quiet, device,
+                              out=target)
+            if target is None:
+                step = src.block_rows()
+                for a0 in range(0, src.shape[0], step):
+                    out.write_rows(a0, res[0][a0:a0 + step])
         finally:
             out.close()
     finally:

@@ -109,8 +109,8 @@ class _ProgressBars:
 
 def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, reference_data, BC_mode, quiet,
          device, out=None):
-    """`datacube`: NumPy array, or a cubeio.LazyCube (a cube on disk, streamed in row blocks).  `out`: None (return the
-    reconstruction as a fresh array) or a cubeio.CubeWriter (write it there block by block; recon is then None)."""
+    """`datacube`: NumPy array (a memory-mapped file is one: cubeio.denoise_file).  `out`: None (return the reconstruction as
+    a fresh array) or a writable array of the cube's shape and dtype that receives it (a memory-mapped output file)."""
     dtype = datacube.dtype
     lambdaInv = 1.0 / lam                      # cyTVDN.py:77 / :303
     lam_mu = (lam / mu).astype(dtype)          # cyTVDN.py:78 / :304
@@ -134,10 +134,8 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
 
     if isinstance(device, (list, tuple)):
         if len(device) > 1:
-            if hasattr(datacube, "read_rows") or out is not None:
-                raise NotImplementedError("file-to-file runs use one device")
             return _run_device_list([int(d) for d in device], datacube, lambdaInv, lam_mu, n_fista, n_plain,
-                                    stopping_relative_change, reference_data, BC_mode, quiet)
+                                    stopping_relative_change, reference_data, BC_mode, quiet, out=out)
         device = int(device[0]) if len(device) else None
     if device is None:
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
@@ -147,38 +145,49 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
     stop = stopping_relative_change
     wf, st = os.environ.get("TVDN_WAVEFRONT"), os.environ.get("TVDN_STAGED")
     # streamed engines, Jia-Zhao: exact wrap at the cube's top face when the FIRST row is not finite (engine.py)
-    first = datacube.read_rows(0, 1) if hasattr(datacube, "read_rows") else datacube[:1]
-    exact_wrap = bool(BC_mode == 2 and not np.isfinite(first).all())
+    exact_wrap = bool(BC_mode == 2 and not np.isfinite(datacube[:1]).all())
     plan = plan_run(datacube.shape, dtype, FISTA, 1, stop=stop is not None, device=device)
     if plan["mode"] == "does-not-fit" and not (wf or st):
         raise MemoryError(f"cube of shape {datacube.shape} cannot be streamed through {_fmt_bytes(plan['hbm_bytes'])} "
                           f"of HBM: {plan['why']}")
-    if wf or st or plan["mode"] in ("wavefront", "trapezoid"):
+    native = os.environ.get("TVDN_STREAM_ENGINE", "native") == "native"
+    if (wf or st or plan["mode"] in ("wavefront", "trapezoid")) and not native:
         # the streamed engines keep the whole state page-locked on the host: refuse what the host cannot hold BEFORE
-        # anything is allocated (a host driven out of memory takes every process on it down)
+        # anything is allocated (a host driven out of memory takes every process on it down).  (The library's own streamed
+        # loop makes this check itself, with the rows it keeps resident in HBM taken off: tvdn_stream_host_need.)
         forced = dict(plan)
         if plan.get("host_bytes_per_rank") is None:     # engine forced by TVDN_WAVEFRONT / TVDN_STAGED on a cube that fits
             forced.update(mode="streamed (forced)", k=None,
                           host_bytes_per_rank=(3 + 2 * nd * (2 if FISTA else 1)) * int(np.prod(datacube.shape)) * dtype.itemsize)
         check_host_fits(forced)
-    if stop is None and (wf or (plan["mode"] == "wavefront" and not st)):
-        rows_k = tuple(int(v) for v in wf.split(",")) if wf else (plan["chunk_rows"], plan["k"])
-        if not quiet:
-            print(f"State exceeds HBM: streaming the cube from pinned host memory, {rows_k[1]} iterations per pass "
-                  f"(wavefront schedule, {rows_k[0]}-row chunks)", flush=True)
-        return _run_wavefront(rows_k, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device,
-                              BC_mode, reference_data, out, exact_wrap)
-    if st or plan["mode"] in ("trapezoid", "wavefront"):
-        if st:
+    if wf or st or plan["mode"] in ("wavefront", "trapezoid"):
+        # Streamed: ONE engine, the library's own (tvdn_run, csrc/tvdn_stream.hip) -- wavefront schedule, rows resident in HBM
+        # where they fit, chained passes; with a stopping rule one iteration per pass.  TVDN_STREAM_ENGINE=python keeps the
+        # Python-driven schedules (wavefront.py / outofcore.py), which exist for slabs x staging across ranks
+        # (distributed.denoise_slabs(staged=...)) and are tested through this switch.
+        if wf:
+            rows, k = (int(v) for v in wf.split(","))
+        elif st:
             rows, k = (int(v) for v in st.split(","))
+        elif native:
+            # the library's own plan for this much HBM: chunk height, depth, rows resident (csrc/tvdn_stream.hip choose_stream_shape)
+            rows, k = _library_stream_plan(datacube, n_fista if FISTA else 0, n_plain if unaccelerated else 0, stop is not None,
+                                           reference_data is not None, BC_mode, device, plan["hbm_bytes"])
         else:
             rows, k = plan["chunk_rows"], plan["k"]
-        if stop is not None:
-            k = 1      # the stopping test is per iteration (cyTVDN.py:189-194): no temporal blocking then
-        return _run_staged((max(1, rows), max(1, k)), datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista,
+        rows, k = max(1, rows), max(1, k)
+        if not quiet:
+            print(f"State exceeds HBM: streaming the cube from pinned host memory, {1 if stop is not None else k} iterations per pass "
+                  f"(wavefront schedule, {rows}-row chunks)", flush=True)
+        if native:
+            return _run_device_list([device], datacube, lambdaInv, lam_mu, n_fista if FISTA else 0, n_plain if unaccelerated else 0,
+                                    stop, reference_data, BC_mode, True, stream=(rows, k), out=out)
+        if stop is None and not st:
+            return _run_wavefront((rows, k), datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device,
+                                  BC_mode, reference_data, out, exact_wrap)
+        return _run_staged((rows, 1 if stop is not None else k), datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista,
                            n_plain, stop, reference_data, BC_mode, quiet, device, out, exact_wrap)
-    if isinstance(datacube, np.ndarray) and out is None and DEFAULT_STATE == "compact" \
-            and os.environ.get("TVDN_LOOP", "run") == "run":
+    if DEFAULT_STATE == "compact" and os.environ.get("TVDN_LOOP", "run") == "run":
         # A NumPy cube that fits: the whole call behind the library's entry point (tvdn_run, csrc/tvdn_run.hip) -- state
         # allocation and placement audition, the loop, stopping rule and MSE trace, and for long-enough Jia-Zhao runs
         # the first iterations under the upload and the last ones over the download.  The progress bars are fed from
@@ -186,7 +195,7 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
         bars = _ProgressBars(n_fista, n_plain, quiet, may_stop=stop is not None)
         try:
             return _run_device_list([int(device)], datacube, lambdaInv, lam_mu, n_fista, n_plain, stop, reference_data,
-                                    BC_mode, quiet, progress=bars.update if bars.active else None, announce=False)
+                                    BC_mode, quiet, progress=bars.update if bars.active else None, announce=False, out=out)
         finally:
             bars.close()
     layout = SlabLayout(tuple(datacube.shape), 0, 1, int(BC_mode))
@@ -250,7 +259,10 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
     num, den = sums[:, 1].astype(dtype), sums[:, 2].astype(dtype)
     with np.errstate(divide="ignore", invalid="ignore"):
         delta_recon = np.where(ran, num / den, dtype.type(0)).astype(dtype)   # divided in the data dtype (utils.pyx:125)
-    recon = be.recon_to_host(out)
+    recon = be.recon_to_host()
+    if out is not None:
+        out[...] = recon
+        recon = out
 
     if stopping_relative_change is not None and not quiet and unaccelerated and n_plain and not ran[-1]:
         print(f"Stopping condition reached after {int(np.nonzero(ran)[0][-1])} iterations, stopping.")
@@ -269,6 +281,23 @@ def _audition_lock(device: int) -> threading.Lock:
     of GiB side by side -- two threads doing that at once would share the HBM budget and disturb each other's timings."""
     with _audition_locks_guard:
         return _audition_locks.setdefault(int(device), threading.Lock())
+
+
+def _library_stream_plan(datacube, n_fista, n_plain, use_stop, mse, BC_mode, device, hbm_bytes):
+    """(rows per chunk, iterations per pass) the library would choose for a streamed run of this cube in `hbm_bytes` of HBM
+    (tvdn_stream_plan: depth weighed against rows kept resident); the rows it keeps resident follow from what is left."""
+    import ctypes as C
+    from . import _lib
+    a = _lib.RunArgs(dtype=_lib.dtype_code(datacube.dtype), ndim=datacube.ndim, bc_mode=int(BC_mode), device=int(device),
+                     n_fista=int(n_fista), n_plain=int(n_plain), use_stop=int(bool(use_stop)), stream_rows=-1, stream_k=-1,
+                     stream_resident=-1)
+    for i, v in enumerate(datacube.shape):
+        a.shape[i] = int(v)
+    if mse:                                   # only their being non-NULL is read: an MSE trace keeps every row on the host
+        a.reference, a.mse_out = 1, 1
+    po = _lib.StreamPlanOut()
+    _lib.check(_lib.lib().tvdn_stream_plan(C.byref(a), int(hbm_bytes or 0), C.byref(po)))
+    return int(po.rows), int(po.k)
 
 
 def _state_workspace(args, shape, dtype, fista, n_total, device, BC_mode):
@@ -298,7 +327,7 @@ def _state_workspace(args, shape, dtype, fista, n_total, device, BC_mode):
 
 
 def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, stop, reference_data, BC_mode, quiet,
-                     stream=None, progress=None, announce=True):
+                     stream=None, progress=None, announce=True, out=None):
     """`device=[0, 1, ...]`: one slab of axis 0 per listed GPU inside THIS process -- the library's whole-loop entry
     (tvdn_run, csrc/tvdn_run.hip): state in HBM of each device, halo rows by peer copies over xGMI under the interior
     sweeps, global sums, global stopping rule.  No torchrun, no RCCL; every slab must fit its device (tvdn_plan says so
@@ -328,7 +357,7 @@ def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, sto
         a.clip[q] = float(lambdaInv[q])
         a.lambda_mu[q] = float(lam_mu[q])
     x = np.ascontiguousarray(datacube)
-    recon = np.empty_like(x)
+    recon = np.empty(x.shape, x.dtype) if out is None else out      # (a memory-mapped output file receives the rows directly)
     sums = np.zeros((max(n, 1), 3))
     mse = np.zeros(n + 1)
     ran = C.c_int32(0)
@@ -369,18 +398,12 @@ def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, sto
 
 def _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device, BC_mode=2,
                    reference_data=None, out=None, exact_wrap=False):
-    """Host-resident state, wavefront schedule: anything but a stopping rule.  An in-memory cube with Jia-Zhao
-    boundaries goes through the library's own streamed loop (tvdn_run, csrc/tvdn_stream.hip; same rate as the
-    Python-driven one, measured), with either boundary condition; cubes on disk and TVDN_STREAM_ENGINE=python take
-    cytvdn_amd/wavefront.py, the same schedule driven from Python."""
+    """TVDN_STREAM_ENGINE=python: host-resident state, wavefront schedule driven from Python (cytvdn_amd/wavefront.py) --
+    the building block of slabs x staging across ranks, reachable here so that the tests can hold it against the oracle."""
     from .wavefront import WavefrontRunner
     dtype = datacube.dtype
     n_total = n_fista + n_plain
     rows, k = plan
-    if isinstance(datacube, np.ndarray) and out is None and os.environ.get("TVDN_STREAM_ENGINE", "native") == "native":
-        return _run_device_list([device], datacube, lambdaInv, lam_mu, n_fista if FISTA else 0,
-                                n_plain if unaccelerated else 0, None, reference_data, BC_mode, True,
-                                stream=(max(1, rows), max(1, k)))
     wr = WavefrontRunner(datacube, FISTA, lambdaInv, lam_mu, device=device, chunk_rows=rows, k=k, max_iters=n_total,
                          bc_mode=int(BC_mode), reference=reference_data, exact_wrap=exact_wrap)
     wr.run(n_fista if FISTA else 0, n_plain if unaccelerated else 0)
@@ -388,9 +411,13 @@ def _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fi
     b_norm = sums[:, 0].astype(dtype)
     with np.errstate(divide="ignore", invalid="ignore"):
         delta_recon = (sums[:, 1].astype(dtype) / sums[:, 2].astype(dtype)).astype(dtype)
+    recon = wr.recon()
+    if out is not None:
+        out[...] = recon
+        recon = out
     if reference_data is not None:
-        return wr.recon(out), b_norm, delta_recon, wr.mse().astype(dtype)
-    return wr.recon(out), b_norm, delta_recon
+        return recon, b_norm, delta_recon, wr.mse().astype(dtype)
+    return recon, b_norm, delta_recon
 
 
 def _run_staged(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, stop, reference_data,
@@ -426,7 +453,10 @@ def _run_staged(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista
     num, den = sums[:, 1].astype(dtype), sums[:, 2].astype(dtype)
     with np.errstate(divide="ignore", invalid="ignore"):
         delta_recon = np.where(ran, num / den, dtype.type(0)).astype(dtype)
-    recon = sr.recon(out)
+    recon = sr.recon()
+    if out is not None:
+        out[...] = recon
+        recon = out
     if reference_data is not None:
         return recon, b_norm, delta_recon, sr.mse().astype(dtype)
     return recon, b_norm, delta_recon

@@ -293,16 +293,7 @@ class HipBackend:
 
     def set_input(self, local_block):
         """local_block: torch tensor or NumPy array of layout.local_shape (halo rows included)."""
-        if hasattr(local_block, "read_rows"):
-            # a cube on disk (cytvdn_amd/cubeio.py): row blocks go file -> pinned lanes -> HBM, one at a time
-            if tuple(local_block.shape) != tuple(self.orig.shape):
-                raise ValueError("streamed input must have the local block's shape")
-            torch.cuda.current_stream(self.device).synchronize()
-            step = local_block.block_rows()
-            for a in range(0, self.orig.shape[0], step):
-                b = min(a + step, self.orig.shape[0])
-                _lib.copy_to_device(local_block.read_rows(a, b), self.orig[a:b])
-        elif isinstance(local_block, np.ndarray) and local_block.dtype == self.dtype \
+        if isinstance(local_block, np.ndarray) and local_block.dtype == self.dtype \
                 and tuple(local_block.shape) == tuple(self.orig.shape):
             # pageable host memory at PCIe speed: pinned multi-lane staging inside the library
             torch.cuda.current_stream(self.device).synchronize()
@@ -312,19 +303,11 @@ class HipBackend:
             self.orig.copy_(t, non_blocking=False)
         self.recon[self.cur].copy_(self.orig)
 
-    def recon_to_host(self, out=None):
-        """The own rows of the current reconstruction as a fresh NumPy array -- or, with `out` (a
-        cubeio.CubeWriter), written there row block by row block (returns None)."""
+    def recon_to_host(self):
+        """The own rows of the current reconstruction as a fresh NumPy array."""
         lay = self.layout
         torch.cuda.current_stream(self.device).synchronize()
-        own = self.recon_tensor()[lay.row_lo:lay.row_hi]
-        if out is None:
-            return _lib.copy_to_host(own, self.dtype)
-        row_bytes = max(1, own[0].numel() * own.element_size())
-        step = max(1, min(own.shape[0], (256 << 20) // row_bytes))
-        for a in range(0, own.shape[0], step):
-            out.write_rows(a, _lib.copy_to_host(own[a:a + step], self.dtype))
-        return None
+        return _lib.copy_to_host(self.recon_tensor()[lay.row_lo:lay.row_hi], self.dtype)
 
     def _bind(self, tk_ratio):
         """Point the argument block at the arrays of the iteration about to run."""

@@ -203,17 +203,11 @@ class StagedRunner:
         def host(fill=None):
             t = torch.empty(self.shape, dtype=tdt, pin_memory=pin)
             t.zero_()
-            if fill is not None and hasattr(fill, "read_rows"):      # a cube on disk (cubeio.LazyCube): block by block
-                own = t[own_sl]
-                step = fill.block_rows()
-                for a in range(0, own.shape[0], step):
-                    own[a:a + step].copy_(torch.from_numpy(fill.read_rows(a, min(a + step, own.shape[0]))))
-            elif fill is not None:
+            if fill is not None:
                 t[own_sl].copy_(torch.from_numpy(fill))
             return t
 
-        def as_source(x):
-            return x if hasattr(x, "read_rows") else np.ascontiguousarray(x)
+        as_source = np.ascontiguousarray
 
         # host state: orig, recon old/new, per axis up to two state arrays old/new
         if pin:     # page-locked memory cannot swap: refuse here, whoever the caller is, what this host cannot hold
@@ -414,10 +408,9 @@ class StagedRunner:
     def mse(self) -> np.ndarray:
         return self._allreduce(sum(be.mse for be in self.stages).clone()).cpu().numpy()
 
-    def recon(self, out=None):
-        """This rank's own rows of the current reconstruction (with `out`, a cubeio.CubeWriter: written there)."""
-        from .wavefront import _write_or_copy
-        return _write_or_copy(self.recon_h[self.h_old][self.ext_lo:self.ext_lo + self.own].numpy(), out)
+    def recon(self):
+        """This rank's own rows of the current reconstruction."""
+        return self.recon_h[self.h_old][self.ext_lo:self.ext_lo + self.own].numpy().copy()
 
 
 __all__ = ["StagedRunner", "plan_blocks"]

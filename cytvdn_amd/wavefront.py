@@ -27,16 +27,6 @@ from . import _lib
 from .engine import fista_ratios
 
 
-def _write_or_copy(own: np.ndarray, out):
-    if out is None:
-        return own.copy()
-    row_bytes = max(1, own[0].nbytes)
-    step = max(1, min(own.shape[0], (256 << 20) // row_bytes))
-    for a in range(0, own.shape[0], step):
-        out.write_rows(a, own[a:a + step])
-    return None
-
-
 IO_STREAMS = 1      # HIP streams per PCIe direction of the wavefront engine (TVDN_IO_STREAMS overrides)
 WINDOW_SLACK = 2    # rows a level window holds beyond the chunk height (planner.wavefront_windows uses the same)
 
@@ -120,17 +110,11 @@ class WavefrontRunner:
         def host(fill=None):
             t = torch.empty(self.shape, dtype=tdt, pin_memory=pin)
             t.zero_()
-            if fill is not None and hasattr(fill, "read_rows"):      # a cube on disk (cubeio.LazyCube): block by block
-                own = t[own_sl]
-                step = fill.block_rows()
-                for a in range(0, own.shape[0], step):
-                    own[a:a + step].copy_(torch.from_numpy(fill.read_rows(a, min(a + step, own.shape[0]))))
-            elif fill is not None:
+            if fill is not None:
                 t[own_sl].copy_(torch.from_numpy(fill))
             return t
 
-        def as_source(x):
-            return x if hasattr(x, "read_rows") else np.ascontiguousarray(x)
+        as_source = np.ascontiguousarray
 
         # Host state.  A pass reads row r of the old state (upload) at least k rows ahead of where it writes the new
         # state (download), so old and new can be the SAME pinned arrays: 1 + 1 + nd x n_state of them (10 for 4-D
@@ -491,10 +475,9 @@ class WavefrontRunner:
             self.dist.all_reduce(t, group=self.group)
         return t.cpu().numpy()
 
-    def recon(self, out=None):
-        """This rank's own rows of the current reconstruction (with `out`, a cubeio.CubeWriter: written there)."""
-        own = self.recon_h[self.h_old][self.ext_lo:self.ext_lo + (self.g1 - self.g0)].numpy()
-        return _write_or_copy(own, out)
+    def recon(self):
+        """This rank's own rows of the current reconstruction."""
+        return self.recon_h[self.h_old][self.ext_lo:self.ext_lo + (self.g1 - self.g0)].numpy().copy()
 
 
 __all__ = ["WavefrontRunner"]

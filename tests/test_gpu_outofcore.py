@@ -17,9 +17,13 @@ pytestmark = pytest.mark.gpu
     ((9, 2, 5, 7), "float32", 6, True, 2, 8, False),           # halo deeper than the cube: every block is clipped
     ((40, 3, 4, 8), "float32", 11, True, 7, 4, False),
 ])
-def test_staged_equals_in_core(oracle, monkeypatch, shape, dtype, its, fista, rows, k, with_ref):
+@pytest.mark.parametrize("engine", ["native", "python"])
+def test_staged_equals_in_core(oracle, monkeypatch, shape, dtype, its, fista, rows, k, with_ref, engine):
+    """TVDN_STAGED forces a streamed run of these (rows, k): the library's loop, or (TVDN_STREAM_ENGINE=python) the
+    trapezoid engine of outofcore.py, the building block of staged slabs across ranks."""
     import cytvdn_amd as tv
     from cytvdn_amd import synth
+    monkeypatch.setenv("TVDN_STREAM_ENGINE", engine)
     dt = np.dtype(dtype)
     nd = len(shape)
     x = synth.cube(shape, seed=57, dtype=dt) + dt.type(0.25)
@@ -37,9 +41,11 @@ def test_staged_equals_in_core(oracle, monkeypatch, shape, dtype, its, fista, ro
         np.testing.assert_allclose(a, b, rtol=1e-6 if dt == np.float32 else 1e-12)
 
 
-def test_staged_early_stop_matches(monkeypatch):
+@pytest.mark.parametrize("engine", ["native", "python"])
+def test_staged_early_stop_matches(monkeypatch, engine):
     import cytvdn_amd as tv
     from cytvdn_amd import synth
+    monkeypatch.setenv("TVDN_STREAM_ENGINE", engine)
     x = synth.cube((12, 5, 8, 12), seed=14, dtype=np.float32)
     mu = np.array([1.0, 1.0, 0.5, 0.5], np.float32)
     want = tv.denoise4D(x, mu, [30, 6], stopping_relative_change=0.03, quiet=True)
@@ -115,19 +121,29 @@ def test_wavefront_equals_in_core(oracle, monkeypatch, shape, dtype, its, fista,
         np.testing.assert_allclose(a, b, rtol=1e-6 if dt == np.float32 else 1e-12)
 
 
+@pytest.mark.parametrize("engine", ["native", "python"])
 @pytest.mark.parametrize("stop", [None, 0.05], ids=["no-stop-rule", "stop-rule"])
-def test_planner_picks_the_streamed_engines_by_itself(oracle, monkeypatch, stop):
+def test_planner_picks_the_streamed_engines_by_itself(oracle, monkeypatch, stop, engine):
     """with the HBM the planner may count on capped (TVDN_HBM_LIMIT) below the 39 MB this cube's state
-    needs, denoise4D must choose the out-of-core engine on its own -- wavefront schedule without a stopping rule,
-    trapezoid blocks with k = 1 with one -- and still return the oracle's bits."""
+    needs, denoise4D must choose the out-of-core engine on its own and still return the oracle's bits: the library's
+    streamed loop (tvdn_run with stream_rows / stream_k from tvdn_stream_plan; one iteration per pass with a stopping rule),
+    or with TVDN_STREAM_ENGINE=python the Python-driven schedules (wavefront without, trapezoid blocks with k = 1 with one)."""
     import cytvdn_amd as tv
     from cytvdn_amd import driver, synth
     calls = []
-    real_wf, real_st = driver._run_wavefront, driver._run_staged
+    real_wf, real_st, real_dl = driver._run_wavefront, driver._run_staged, driver._run_device_list
     monkeypatch.setattr(driver, "_run_wavefront", lambda plan, *a, **k: (calls.append(("wavefront", plan)), real_wf(plan, *a, **k))[1])
     monkeypatch.setattr(driver, "_run_staged", lambda plan, *a, **k: (calls.append(("trapezoid", plan)), real_st(plan, *a, **k))[1])
+
+    def spy(devices, *a, **k):
+        if k.get("stream") is not None:
+            calls.append(("library", k["stream"]))
+        return real_dl(devices, *a, **k)
+
+    monkeypatch.setattr(driver, "_run_device_list", spy)
     monkeypatch.delenv("TVDN_WAVEFRONT", raising=False)
     monkeypatch.delenv("TVDN_STAGED", raising=False)
+    monkeypatch.setenv("TVDN_STREAM_ENGINE", engine)
     monkeypatch.setenv("TVDN_HBM_LIMIT", "24M")
     shape, dt = (40, 8, 32, 64), np.dtype(np.float32)
     x = synth.cube(shape, seed=5, dtype=dt) + dt.type(0.25)
@@ -135,9 +151,11 @@ def test_planner_picks_the_streamed_engines_by_itself(oracle, monkeypatch, stop)
     its = [5, 3] if stop is None else 30
     got = tv.denoise4D(x, mu, its, FISTA=True, stopping_relative_change=stop, quiet=True)
     ref = oracle.denoise(x, mu, its, True, stopping_relative_change=stop)
-    assert calls and calls[0][0] == ("wavefront" if stop is None else "trapezoid"), calls
+    want = "library" if engine == "native" else ("wavefront" if stop is None else "trapezoid")
+    assert calls and calls[0][0] == want, calls
     if stop is not None:
-        assert calls[0][1][1] == 1                                   # k = 1: a decision after every iteration
+        if engine == "python":
+            assert calls[0][1][1] == 1                               # k = 1: a decision after every iteration
         assert 0 < np.count_nonzero(got[2]) < 30                     # the rule did fire
     assert bits_equal(got[0], ref["recon"])
     assert np.array_equal(got[2] == 0, ref["delta_recon"] == 0)

@@ -143,6 +143,46 @@ def test_streamed_run_with_resident_rows(oracle, shape, dtype, n_f, n_p, rows, k
         assert st.h2d_bytes == x.nbytes and st.d2h_bytes == x.nbytes
 
 
+@pytest.mark.parametrize("chain", ["1", "0"])
+@pytest.mark.parametrize("shape,dtype,n_f,n_p,rows,k,resident", [
+    ((23, 3, 4, 8), np.float32, 12, 0, 5, 3, 0),          # four passes, the seam between two passes inside a chunk (23 = 4 x 5 + 3)
+    ((23, 3, 4, 8), np.float32, 12, 0, 5, 3, 9),          # ... with rows resident in HBM
+    ((24, 3, 4, 8), np.float32, 7, 6, 4, 4, 0),           # hybrid: the d -> b transition inside the second of four passes
+    ((24, 3, 4, 8), np.float32, 7, 6, 4, 4, 11),
+    ((30, 6, 16), np.float64, 0, 10, 2, 3, 0),            # unaccelerated 3-D f64, passes of 3 + 3 + 2 + 2 levels
+    ((30, 6, 16), np.float64, 9, 0, 3, 2, 14),            # five passes (2 + 2 + 2 + 2 + 1)
+    ((16, 2, 5, 7), np.float32, 8, 0, 1, 4, 5),           # one-row chunks, scalar packs
+])
+def test_chained_passes(oracle, monkeypatch, shape, dtype, n_f, n_p, rows, k, resident, chain):
+    """Several passes of a Jia-Zhao run are CHAINED (pass p + 1 starts uploading while the upper levels of pass p are still
+    climbing, one running row index over all passes, launches cut at the seams) when k <= N0 - 3 rows; TVDN_STREAM_CHAIN=0
+    keeps them apart.  Either way: the resident run's and the oracle's bits, traces included; an MSE trace and a non-finite
+    first row (two sets of top-face planes, one per pass in flight) too."""
+    from cytvdn_amd import _lib, synth
+    monkeypatch.setenv("TVDN_STREAM_CHAIN", chain)
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=29, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    n = n_f + n_p
+    assert k <= shape[0] - 3 * rows                       # these cases do chain
+    st = _lib.RunStats()
+    got = _run(x, mu, n_f, n_p, stream=(rows, k), resident=resident, stats=st)
+    ref = _oracle(oracle, x, mu, n_f, n_p)
+    assert bits_equal(got[0], ref["recon"]) and got[3] == n and st.n_passes == -(-n // k)
+    _check_traces(got[1], ref, n)
+    if resident == 0:
+        clean = synth.cube(shape, seed=29, dtype=dt, kind="mean")
+        got = _run(x, mu, n_f, n_p, ref=clean, stream=(rows, k))
+        oref = _oracle(oracle, x, mu, n_f, n_p, reference_data=clean)
+        assert bits_equal(got[0], oref["recon"])
+        np.testing.assert_allclose(got[2], oref["MSE64"], rtol=2e-7 if dt == np.float32 else 1e-12)
+    x[0].flat[3] = np.inf                                 # exact wrap at the top face, passes in flight on both sides of a seam
+    got = _run(x, mu, n_f, n_p, stream=(rows, k), resident=resident)
+    ref = _oracle(oracle, x, mu, n_f, n_p)
+    assert np.isnan(ref["recon"][-1]).any() and bits_equal(got[0], ref["recon"])
+
+
 def test_streamed_hybrid_with_stopping_rule_in_place_and_nonfinite_row(oracle):
     from cytvdn_amd import _lib, synth
     dt = np.dtype(np.float32)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the fused sweep's launch-time knobs INSIDE one process on ONE allocation of the state: the knobs are environment
 variables the library reads at every launch (TVDN_CHUNK, TVDN_XCD, TVDN_PATCH, TVDN_PATCH_AFAST, ...), so variants can
-alternate step by step on the very same physical pages.  tools/ab.py starts a process per variant, and every process gets
+alternate step by step on the very same physical pages.  A process per variant (rounds 1 and 2) gives every variant
 another placement of its 60 GiB -- a +-6 % lottery (profiles/r03_placement_audition_*.jsonl) that drowned every effect
 smaller than that in rounds 1 and 2.
 

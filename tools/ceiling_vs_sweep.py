@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
     ap.add_argument("--hold", type=int, default=3)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--drop-recon", action="store_true",
+                    help="config 2: also time the 9-read / 4-write mix of a sweep that would NOT store recon (orig + the d pairs in, "
+                         "d_k+1 out): what 'fewer bytes' could reach before its wider stencil is paid for")
     a = ap.parse_args()
     shape, dt, fista = CONFIGS[a.config]
     dt = np.dtype(dt)
@@ -100,6 +103,22 @@ def main():
                     if i >= 2:
                         tt.append(e0.elapsed_time(e1))
                 tm[f"march{chunk}_ms"] = round(float(np.mean(tt)), 4)
+        if a.drop_recon and fista and nd == 4 and dt.itemsize == 4:
+            ins9 = [be.orig] + [t for S in be.S for t in (S[be.i_d], S[be.i_prev])]
+            outs4 = [S[be.i_out] for S in be.S]
+            p9 = (C.c_void_p * 9)(*[t.data_ptr() for t in ins9])
+            p4 = (C.c_void_p * 4)(*[t.data_ptr() for t in outs4])
+            tt = []
+            for i in range(a.steps + 2):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _lib.check(L.tvdn_stream_mix(9, p9, 4, p4, n_bytes, _lib.current_stream(0)))
+                e1.record()
+                torch.cuda.synchronize()
+                if i >= 2:
+                    tt.append(e0.elapsed_time(e1))
+            tm["mix_9R4W_ms"] = round(float(np.mean(tt)), 4)
+            tm["mix_9R4W_GBps"] = round(13 * n_bytes / (float(np.mean(tt)) * 1e-3) / 1e9)
         self_march.update(tm)
         return float(np.mean(ts)), float(np.min(ts)), len(ins), len(outs)
 

@@ -139,6 +139,162 @@ int main(int argc, char **argv)
         fflush(stdout);
         for (hipEvent_t e : {u0, u1, d0, d1, b0, b1}) CK(hipEventDestroy(e));
     };
+    // The streamed engine's pattern: per chunk, the compute stream waits for the upload (in_ready), records in_free which the
+    // NEXT upload waits for; the download waits for the compute stream (out_ready) and records out_free which compute waits for.
+    // coupling bits: 1 = downloads wait on compute events, 2 = compute waits on download events, 4 = the same two for uploads,
+    // 8 = nine 1/9-size copies per chunk instead of one
+    auto coupled = [&](const char *what, int coupling, int n_chunk, int kernels_per_chunk, bool up, bool down) {
+        CK(hipDeviceSynchronize());
+        std::vector<hipEvent_t> evs;
+        auto ev = [&]() {
+            hipEvent_t e;
+            CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            evs.push_back(e);
+            return e;
+        };
+        hipEvent_t u0, u1, d0, d1, b0, b1;
+        for (hipEvent_t *e : {&u0, &u1, &d0, &d1, &b0, &b1}) CK(hipEventCreate(e));
+        CK(hipEventRecord(u0, s_up));
+        CK(hipEventRecord(d0, s_dn));
+        CK(hipEventRecord(b0, s_bg));
+        hipEvent_t in_free[2] = {nullptr, nullptr}, out_free[2] = {nullptr, nullptr};
+        const int parts = (coupling & 8) ? 9 : 1;
+        const size_t part = piece / parts / 16 * 16;
+        const double t0 = now();
+        for (int c = 0; c < n_chunk; ++c) {
+            const int h = c & 1;
+            const size_t off = (size_t)h * piece;
+            hipEvent_t in_ready = nullptr;
+            if (up) {
+                if ((coupling & 4) && in_free[h]) CK(hipStreamWaitEvent(s_up, in_free[h], 0));
+                for (int k = 0; k < parts; ++k) CK(hipMemcpyAsync(d_up + off + k * part, h_up + off + k * part, part, hipMemcpyHostToDevice, s_up));
+                if (coupling & 4) {
+                    in_ready = ev();
+                    CK(hipEventRecord(in_ready, s_up));
+                    CK(hipStreamWaitEvent(s_bg, in_ready, 0));
+                }
+            }
+            if ((coupling & 2) && out_free[h]) CK(hipStreamWaitEvent(s_bg, out_free[h], 0));
+            for (int j = 0; j < kernels_per_chunk; ++j) hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((big_n + 255) / 256)), dim3(256), 0, s_bg, big, big_n);
+            if (up && (coupling & 4)) {
+                in_free[h] = ev();
+                CK(hipEventRecord(in_free[h], s_bg));
+            }
+            if (down) {
+                if (coupling & 1) {
+                    hipEvent_t out_ready = ev();
+                    CK(hipEventRecord(out_ready, s_bg));
+                    CK(hipStreamWaitEvent(s_dn, out_ready, 0));
+                }
+                for (int k = 0; k < parts; ++k) CK(hipMemcpyAsync(h_dn + off + k * part, d_dn + off + k * part, part, hipMemcpyDeviceToHost, s_dn));
+                if (coupling & 2) {
+                    out_free[h] = ev();
+                    CK(hipEventRecord(out_free[h], s_dn));
+                }
+            }
+        }
+        CK(hipEventRecord(u1, s_up));
+        CK(hipEventRecord(d1, s_dn));
+        CK(hipEventRecord(b1, s_bg));
+        CK(hipDeviceSynchronize());
+        const double wall = now() - t0;
+        float tu = 0, td = 0, tb = 0;
+        CK(hipEventElapsedTime(&tu, u0, u1));
+        CK(hipEventElapsedTime(&td, d0, d1));
+        CK(hipEventElapsedTime(&tb, b0, b1));
+        const double gb = (double)part * parts * n_chunk / 1e9;
+        printf("{\"what\": \"%s\", \"coupling\": %d, \"kernels_per_chunk\": %d, \"h2d_GBps\": %.1f, \"d2h_GBps\": %.1f, \"wall_s\": %.3f, \"compute_TBps\": %.2f}\n", what,
+               coupling, kernels_per_chunk, up ? gb / (tu * 1e-3) : 0.0, down ? gb / (td * 1e-3) : 0.0, wall,
+               (double)n_chunk * kernels_per_chunk * big_n * 32 / (tb * 1e-3) / 1e12);
+        fflush(stdout);
+        for (hipEvent_t e : evs) CK(hipEventDestroy(e));
+        for (hipEvent_t e : {u0, u1, d0, d1, b0, b1}) CK(hipEventDestroy(e));
+    };
+    if (argc > 2 && !strcmp(argv[2], "engine")) {
+        // The streamed engine itself, stripped to its transfers: NU host arrays go up and ND come down per chunk, 512 MiB each,
+        // through double-buffered boxes, with the engine's four events per chunk and `kern` HBM-bound kernels per chunk beside
+        // them; the downloads land in the SAME host arrays `lag` chunks behind the uploads (in-place host state) or in others.
+        const int NU = 10, ND = 9, NC = argc > 3 ? atoi(argv[3]) : 12;
+        std::vector<char *> hs, hs2;
+        for (int i = 0; i < NU; ++i) hs.push_back(pinned(piece * NC));
+        for (int i = 0; i < ND; ++i) hs2.push_back(pinned(piece * NC));
+        char *in_box[2], *out_box[2];
+        for (int h = 0; h < 2; ++h) {
+            CK(hipMalloc(&in_box[h], piece * NU));
+            CK(hipMalloc(&out_box[h], piece * ND));
+        }
+        auto engine = [&](const char *what, bool up, bool down, bool inplace, int kern, int lag, bool events) {
+            CK(hipDeviceSynchronize());
+            std::vector<hipEvent_t> evs;
+            auto ev = [&]() {
+                hipEvent_t e;
+                CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                evs.push_back(e);
+                return e;
+            };
+            hipEvent_t in_free[2] = {nullptr, nullptr}, out_free[2] = {nullptr, nullptr};
+            const double t0 = now();
+            for (int c = 0; c < NC + lag; ++c) {
+                const int h = c & 1;
+                if (up && c < NC) {
+                    if (events && in_free[h]) CK(hipStreamWaitEvent(s_up, in_free[h], 0));
+                    for (int i = 0; i < NU; ++i) CK(hipMemcpyAsync(in_box[h] + (size_t)i * piece, hs[i] + (size_t)c * piece, piece, hipMemcpyHostToDevice, s_up));
+                    if (events) {
+                        hipEvent_t r = ev();
+                        CK(hipEventRecord(r, s_up));
+                        CK(hipStreamWaitEvent(s_bg, r, 0));
+                    }
+                }
+                if (events && down && out_free[h]) CK(hipStreamWaitEvent(s_bg, out_free[h], 0));
+                for (int j = 0; j < kern; ++j) hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((big_n + 255) / 256)), dim3(256), 0, s_bg, big, big_n);
+                if (events && up && c < NC) {
+                    in_free[h] = ev();
+                    CK(hipEventRecord(in_free[h], s_bg));
+                }
+                if (down && c >= lag) {
+                    if (events) {
+                        hipEvent_t r = ev();
+                        CK(hipEventRecord(r, s_bg));
+                        CK(hipStreamWaitEvent(s_dn, r, 0));
+                    }
+                    for (int i = 0; i < ND; ++i)
+                        CK(hipMemcpyAsync((inplace ? hs[i + 1] : hs2[i]) + (size_t)(c - lag) * piece, out_box[h] + (size_t)i * piece, piece, hipMemcpyDeviceToHost, s_dn));
+                    if (events) {
+                        out_free[h] = ev();
+                        CK(hipEventRecord(out_free[h], s_dn));
+                    }
+                }
+            }
+            CK(hipDeviceSynchronize());
+            const double wall = now() - t0;
+            printf("{\"what\": \"%s\", \"up\": %s, \"down\": %s, \"in_place\": %s, \"kernels_per_chunk\": %d, \"lag_chunks\": %d, \"events\": %s, \"chunks\": %d, "
+                   "\"wall_s\": %.3f, \"h2d_GB\": %.1f, \"d2h_GB\": %.1f, \"total_GBps\": %.1f}\n",
+                   what, up ? "true" : "false", down ? "true" : "false", inplace ? "true" : "false", kern, lag, events ? "true" : "false", NC, wall,
+                   up ? (double)piece * NU * NC / 1e9 : 0.0, down ? (double)piece * ND * NC / 1e9 : 0.0,
+                   ((up ? (double)piece * NU * NC : 0.0) + (down ? (double)piece * ND * NC : 0.0)) / wall / 1e9);
+            fflush(stdout);
+            for (hipEvent_t e : evs) CK(hipEventDestroy(e));
+        };
+        for (int kern : {0, 38}) {
+            engine("engine: up only", true, false, true, kern, 0, true);
+            engine("engine: down only", false, true, true, kern, 0, true);
+            engine("engine: both, in place, lag 19", true, true, true, kern, 19, true);
+            engine("engine: both, in place, lag 2", true, true, true, kern, 2, true);
+            engine("engine: both, separate arrays, lag 2", true, true, false, kern, 2, true);
+            engine("engine: both, in place, lag 2, no events", true, true, true, kern, 2, false);
+        }
+        return 0;
+    }
+    if (argc > 2) {  // only the coupled experiments
+        for (int kpc : {2, 8}) {
+            for (int coupling : {0, 1, 2, 3, 4, 7, 15}) {
+                coupled("coupled both", coupling, n_piece, kpc, true, true);
+                coupled("coupled down only", coupling, n_piece, kpc, false, true);
+                coupled("coupled up only", coupling, n_piece, kpc, true, false);
+            }
+        }
+        return 0;
+    }
     for (int bg = 0; bg < 2; ++bg) {
         experiment("background alone", 0, 0, bg);
         experiment("memcpy up alone", 1, 0, bg);
