@@ -216,7 +216,12 @@ int ensure_partials(tvdn_ctx *ctx, long long nblocks);
 // tvdn_stream.hip: the out-of-core branch of tvdn_run
 int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_bytes, bool mse, bool wrap, int n_state, bool may_keep,
                         int64_t k_cap, int64_t *rows_out, int64_t *k_out, int64_t *res_out);
-int run_streamed(const tvdn_run_args *a, int64_t rows, int64_t k, int64_t resident_rows);
+// One slab of a streamed DEVICE-LIST run (tvdn_stream.hip run_streamed_slabs): the cube's state lives in page-locked host
+// arrays shared by all slabs of the process -- two sets, a pass reads one and writes the other, so a slab may read its
+// neighbours' rows (k of them beyond each interior face: the trapezoid of a temporally blocked pass) while they write theirs.
+struct SlabShare;
+int run_streamed(const tvdn_run_args *a, int64_t rows, int64_t k, int64_t resident_rows, const SlabShare *slab = nullptr);
+int run_streamed_slabs(const tvdn_run_args *a, int64_t rows, int64_t k);
 // tvdn_run.hip: the big device block of a run is KEPT when the run ends (one per device) and handed to the next run it fits
 // (releasing and re-allocating tens of GiB in quick succession costs seconds); tvdn_release_cache() returns it
 hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, bool *reused, bool any_larger);

@@ -968,9 +968,10 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
     }
     TVDN_REQUIRE(a->bc_mode == 0 || a->bc_mode == 2, "bc_mode must be 0 or 2, got %d", a->bc_mode);
     if (a->stream_rows > 0) {
-        TVDN_REQUIRE(a->n_devices <= 1, "a streamed run uses one device (slabs x streaming: cytvdn_amd.denoise_slabs(staged=...))");
         const auto ts = std::chrono::steady_clock::now();
-        const int rcs = tvdn::run_streamed(a, a->stream_rows, a->stream_k, a->stream_resident);
+        // several devices: every slab streamed through its own GPU from host arrays all of them share (tvdn_stream.hip)
+        const int rcs = a->n_devices > 1 ? tvdn::run_streamed_slabs(a, a->stream_rows, a->stream_k)
+                                         : tvdn::run_streamed(a, a->stream_rows, a->stream_k, a->stream_resident);
         if (getenv("TVDN_STREAM_TIMING"))
             fprintf(stderr, "tvdn_run streamed: whole call %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count());
         return rcs;
@@ -998,6 +999,19 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
                                                       a->n_fista > 0 ? 2 : 1, keep, a->use_stop ? 1 : a->n_fista + a->n_plain, &rows, &k, &res);
             if (rc2) return rc2;
             return tvdn::run_streamed(a, rows, k, a->stream_resident > 0 ? a->stream_resident : (keep ? res : 0));
+        }
+        if (stream_auto && over && world > 1) {
+            // asked to decide, several devices, slabs beyond their HBM: BASELINE configs[4] in structure -- every slab streamed
+            // through its own device (the depth that one slab's rings allow; no rows kept resident: the halo rows of a pass are
+            // read from the shared host arrays)
+            size_t row_bytes = a->dtype == TVDN_F32 ? 4 : 8;
+            for (int i = 1; i < a->ndim; ++i) row_bytes *= (size_t)a->shape[i];
+            int64_t rows = 0, k = 0, res = 0;
+            const int rc2 = tvdn::choose_stream_shape(a->ndim, (a->shape[0] + world - 1) / world, row_bytes, (size_t)(pl.free_bytes / same),
+                                                      a->mse_out && a->reference, false, a->n_fista > 0 ? 2 : 1, false,
+                                                      a->use_stop ? 1 : a->n_fista + a->n_plain, &rows, &k, &res);
+            if (rc2) return rc2;
+            return tvdn::run_streamed_slabs(a, rows, k);
         }
         if (over) {
             tvdn::set_error("state of %lld bytes per slab x %d slab(s) on device %d exceeds 90 %% of its %lld free bytes of HBM: use more "

@@ -105,30 +105,50 @@ struct PinnedBuf {
         TVDN_HIP(hipHostMalloc((void **)&p, b ? b : 1, hipHostMallocDefault));
         return TVDN_OK;
     }
+    void release_now()  // on the calling thread
+    {
+        if (!p) return;
+        if (mapped) {
+            (void)hipHostUnregister(p);
+            (void)munmap(p, bytes);
+        } else {
+            (void)hipHostFree(p);
+        }
+        p = nullptr;
+    }
     void release()
     {
         if (!p) return;
-        char *q = p;
-        const size_t b = bytes;
-        const bool m = mapped;
-        p = nullptr;
-        auto job = [q, b, m] {
-            if (m) {
-                (void)hipHostUnregister(q);
-                (void)munmap(q, b);
-            } else {
-                (void)hipHostFree(q);
-            }
-        };
-        if (b >= (size_t(1) << 30)) {  // big: in the background
-            g_releases_pending.fetch_add(1);
-            std::thread([job] {
-                job();
-                g_releases_pending.fetch_sub(1);
-            }).detach();
-        } else {
-            job();
+        if (bytes < (size_t(1) << 30)) {
+            release_now();
+            return;
         }
+        std::vector<std::unique_ptr<PinnedBuf>> one;
+        one.emplace_back(new PinnedBuf);
+        one[0]->p = p;
+        one[0]->bytes = bytes;
+        one[0]->mapped = mapped;
+        p = nullptr;
+        release_in_background(std::move(one));
+    }
+    // ONE thread for a whole batch: unmapping holds the process's address-space lock, and a thread per buffer would wait for
+    // it at creation (its stack is a mapping too) -- 36 blocks of 4 GiB took 5.8 s to hand over that way.
+    static void release_in_background(std::vector<std::unique_ptr<PinnedBuf>> &&bufs)
+    {
+        if (bufs.empty()) return;
+        // ... but never past the end of the process: a thread still unpinning memory while the runtime's own exit handlers
+        // run would take the process down on its way out.  Registered at first use, i.e. after the runtime's handlers, so
+        // it runs before them.
+        static std::once_flag at_exit_once;
+        std::call_once(at_exit_once, [] { std::atexit([] { wait_for_releases(); }); });
+        g_releases_pending.fetch_add(1);
+        auto *batch = new std::vector<std::unique_ptr<PinnedBuf>>(std::move(bufs));
+        std::thread([batch] {
+            for (auto &b : *batch)
+                if (b) b->release_now();
+            delete batch;
+            g_releases_pending.fetch_sub(1);
+        }).detach();
     }
     ~PinnedBuf() { release(); }
     PinnedBuf() = default;
@@ -459,6 +479,53 @@ extern "C" int tvdn_stream_plan(const tvdn_run_args *a, int64_t hbm_free_bytes, 
 
 namespace tvdn {
 
+// Threads of one streamed device-list run meet here after every pass; a slab that fails releases the others with its error.
+struct SlabBarrier {
+    std::mutex mu;
+    std::condition_variable cv;
+    int count = 1, waiting = 0;
+    long generation = 0;
+    int failed = 0;
+    std::string msg;
+    int arrive_and_wait()  // TVDN_OK, or the status of the slab that failed
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (failed) return failed;
+        const long gen = generation;
+        if (++waiting == count) {
+            waiting = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != gen || failed; });
+        }
+        return failed;
+    }
+    void fail(int rc, const char *m)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!failed) {
+            failed = rc;
+            msg = m ? m : "";
+        }
+        cv.notify_all();
+    }
+};
+
+struct SlabShare {
+    int index = 0, count = 1;
+    int64_t g0 = 0, g1 = 0;      // own rows of the cube
+    char *orig = nullptr;        // page-locked, row g of the cube at + g * row_bytes (every array below too)
+    char *ref = nullptr;
+    char *recon[2] = {nullptr, nullptr};
+    char *state[2][8] = {};      // [set][axis * n_state + s]
+    int first_new = 1;           // the set the FIRST pass writes
+    SlabBarrier *barrier = nullptr;
+    double *stop_sums = nullptr; // [count][3]: every slab's sums of the iteration just run (stopping rule)
+    int *last_set = nullptr;     // out: the set the last pass wrote
+    tvdn_run_stats *stats = nullptr;
+};
+
 namespace {
 
 // Which rows of axis 0 keep their state in HBM between the passes: `res` of the n0 rows, spread EVENLY over the cube
@@ -487,11 +554,13 @@ struct StateBlocks {
     int64_t ready = 0;  // blocks [0, ready) exist
     int failed = 0;
     std::string fail_msg;
-    int64_t n_blocks() const { return (n_slots + block_rows - 1) / block_rows; }
-    int64_t block_of(int64_t h) const { return h / block_rows; }
-    int64_t block_end(int64_t h) const { return std::min(n_slots, (block_of(h) + 1) * block_rows); }  // first slot of the next block
+    std::vector<char *> flat;  // slab mode: array `arr` is ONE caller-provided run of n_slots rows (nothing allocated, always ready)
+    int64_t n_blocks() const { return flat.empty() ? (n_slots + block_rows - 1) / block_rows : 0; }
+    int64_t block_of(int64_t h) const { return flat.empty() ? h / block_rows : 0; }
+    int64_t block_end(int64_t h) const { return flat.empty() ? std::min(n_slots, (block_of(h) + 1) * block_rows) : n_slots; }  // first slot of the next block
     char *row(int arr, int64_t h) const
     {
+        if (!flat.empty()) return flat[(size_t)arr] + (size_t)h * row_bytes;
         const int64_t b = block_of(h);
         return blocks[(size_t)b]->p + ((size_t)arr * (size_t)block_rows + (size_t)(h - b * block_rows)) * row_bytes;
     }
@@ -512,6 +581,7 @@ struct StateBlocks {
     }
     int wait_for(int64_t h)  // calling thread: until the block of host slot h exists
     {
+        if (!flat.empty()) return TVDN_OK;
         const int64_t b = block_of(h);
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return failed || ready > b; });
@@ -569,7 +639,7 @@ struct Joiner {
 
 // R rows per chunk, K iteration levels per pass; `res_req` rows keep their state in HBM between passes (-1: as many as fit
 // beside the rings in 85 % of the free HBM, 0: none).
-int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
+int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, const SlabShare *sh)
 {
     const auto t_start = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
@@ -611,6 +681,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
     }
     if (a->use_stop) K = 1;  // the stopping rule needs a decision after every iteration: one level per pass
     K = std::min<int64_t>(K, std::max<int64_t>(1, n_total));
+    if (periodic || sh) K = std::min<int64_t>(K, N0);  // (the wrapped rows / the neighbours' rows a pass reads are rows of this cube)
     // as many passes as this depth needs, of (almost) equal depth: 80 iterations at k = 38 are three PCIe round trips whether
     // they hold 38 + 38 + 4 levels or 27 + 27 + 26, and the shallower rings leave HBM for resident rows.  The deeper passes
     // come first and consecutive depths differ by one level at most (what the out boxes of chained passes are sized for).
@@ -620,10 +691,14 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
     // Periodic boundaries along axis 0: the sweeps see a virtual cube of N0 + 2 K rows -- the cube between K wrapped rows
     // at either end, which are each other's halo -- and, as at the face between two slabs, give up one row per level at
     // the two artificial faces; the wrap itself is never swept (cytvdn_amd/wavefront.py does the same).
-    if (periodic) K = std::min<int64_t>(K, N0);
-    const int64_t KX = periodic ? K : 0, NV = N0 + 2 * KX, G0 = KX, G1 = KX + N0;
+    // A slab of a device-list run (sh): the same virtual rows -- the cube between K rows at either end -- of which this slab
+    // owns [own0, own1); at its interior faces it reads K rows of its neighbours' state (shared host arrays) and gives up a row
+    // per level, as a periodic run does at both ends.
+    const int64_t KX = (periodic || sh) ? K : 0, NV = N0 + 2 * KX, G0 = KX, G1 = KX + N0;
+    const int64_t own0 = sh ? KX + sh->g0 : G0, own1 = sh ? KX + sh->g1 : G1;  // virtual rows whose results and sums are this run's
+    const bool art_lo = periodic || (sh && sh->g0 > 0), art_hi = periodic || (sh && sh->g1 < N0);  // faces that are not the cube's own
+    if (sh) res_req = 0;
     TVDN_HIP(hipSetDevice(device));
-    wait_for_releases();  // pinned memory a previous run of this process is still handing back
 
     // ---- what fits where: rings and boxes first, then as many resident rows as asked for / as fit ---------------------------
     const int64_t cap = R + 2, ocap = R + K + 3;
@@ -665,7 +740,11 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
     // BEFORE anything of the caller's is touched: can the host hold what stays there?  (page-locked: it cannot swap)
     {
         int64_t need = 0, avail = 0;
-        const int rc0 = stream_host_need(a, RES, &need, &avail);
+        int rc0 = sh ? TVDN_OK : stream_host_need(a, RES, &need, &avail);  // (slabs: the coordinator has asked for all of them)
+        if (rc0 && g_releases_pending.load() > 0) {  // pinned memory a previous run of this process is still handing back
+            wait_for_releases();
+            rc0 = stream_host_need(a, RES, &need, &avail);
+        }
         if (rc0) return rc0;
     }
 
@@ -767,7 +846,8 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
     // over the rows a later pass would upload as the data term, which therefore gets a pinned copy of its own.
     HostArr orig_h, recon_h, ref_h, recon2_h;
     StateBlocks sb[2];
-    const int n_sets = periodic ? 2 : 1;
+    const bool two_sets = periodic || sh != nullptr;  // old and new host state apart
+    const int n_sets = two_sets ? 2 : 1;
     for (int s = 0; s < n_sets; ++s) {
         sb[s].n_arr = nd * n_state;
         sb[s].n_slots = HR;
@@ -803,7 +883,21 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
         }
     };
 
+    if (sh) {  // a slab of a device-list run: the host state is the coordinator's (shared, page-locked, cube rows)
+        orig_h.p = sh->orig;
+        recon_h.p = sh->recon[0];
+        recon2_h.p = sh->recon[1];
+        ref_h.p = sh->ref;
+        orig_h.cube_rows = recon_h.cube_rows = recon2_h.cube_rows = ref_h.cube_rows = true;
+        for (int set = 0; set < 2; ++set)
+            for (int i = 0; i < nd * n_state; ++i) sb[set].flat.push_back(sh->state[set][i]);
+    }
     std::thread stager([&] {  // resident rows of the data term: pageable `data` -> store, through the library's pinned lanes
+        if (sh) {
+            staged_upto.store(N0);
+            staged_done.raise();
+            return;
+        }
         const int64_t piece = std::max<int64_t>(1, (int64_t)((size_t(1) << 30) / row_bytes));
         for (int64_t g = 0; g < N0 && RES > 0;) {
             if (!resident(g)) {
@@ -827,7 +921,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
     Joiner join_stager{stager};
     std::thread pinner([&] {
         (void)hipSetDevice(device);
-        if (HR <= 0) {
+        if (HR <= 0 || sh) {
             orig_ready.raise();
             recon_ready.raise();
             recon2_ready.raise();
@@ -881,9 +975,9 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
         }
     };
 
-    int h_old = 0;  // which set holds the current state (periodic); 0 = recon_h / sb[0]
-    auto recon_row = [&](int set, int64_t g) -> char * { return host_row((periodic && set) ? recon2_h : recon_h, g); };
-    auto wait_recon = [&](int set) -> int { return ((periodic && set) ? recon2_ready : recon_ready).wait(); };
+    int h_old = sh ? sh->first_new ^ 1 : 0;  // which set holds the current state (two sets: periodic runs, slabs); 0 = recon_h / sb[0]
+    auto recon_row = [&](int set, int64_t g) -> char * { return host_row((two_sets && set) ? recon2_h : recon_h, g); };
+    auto wait_recon = [&](int set) -> int { return ((two_sets && set) ? recon2_ready : recon_ready).wait(); };
 
     tvdn_iter_args it;
     std::memset(&it, 0, sizeof it);
@@ -891,8 +985,8 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
     it.ndim = nd;
     it.shape[0] = NV;
     for (int i = 1; i < nd; ++i) it.shape[i] = a->shape[i];
-    it.row_lo = 0;
-    it.row_hi = NV;
+    it.row_lo = periodic ? 0 : G0;  // periodic: the virtual cube with its wrapped rows; Jia-Zhao: the cube's own faces
+    it.row_hi = periodic ? NV : G1;
     it.lo_mode = TVDN_EDGE_BC;
     it.hi_mode = periodic ? TVDN_EDGE_BC : (exact_wrap ? TVDN_EDGE_WRAP : TVDN_EDGE_ZERO);
     it.bc_mode = a->bc_mode;
@@ -938,11 +1032,15 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
         // of zeros -- so the host arrays they will come down into need not exist yet.
         const bool first = n_passes == 0;
         // rows of the (virtual) cube this pass works on, and what each level can reach at an artificial face
-        const int64_t E0 = periodic ? KX - kk : 0, E1 = periodic ? G1 + kk : N0;
-        auto lo_bound = [&](int64_t level) { return periodic ? E0 + level : (int64_t)0; };
-        auto hi_bound = [&](int64_t level) { return periodic ? E1 - level : N0; };
+        // (an artificial face -- the wrap of a periodic run, the face between two slabs -- gives up a row per level; a slab
+        // whose halo would reach beyond a Jia-Zhao cube's own face stops at that face, which then is a real one)
+        const int64_t E0 = art_lo ? (periodic ? own0 - kk : std::max(G0, own0 - kk)) : G0;
+        const int64_t E1 = art_hi ? (periodic ? own1 + kk : std::min(G1, own1 + kk)) : G1;
+        const bool shrink_lo = art_lo && (periodic || E0 > G0), shrink_hi = art_hi && (periodic || E1 < G1);
+        auto lo_bound = [&](int64_t level) { return shrink_lo ? E0 + level : E0; };
+        auto hi_bound = [&](int64_t level) { return shrink_hi ? E1 - level : E1; };
         const int64_t n_chunks = (E1 - E0 + kk + R - 1) / R;
-        const int h_new = periodic ? h_old ^ 1 : h_old;
+        const int h_new = two_sets ? h_old ^ 1 : h_old;
         auto cube_row = [&](int64_t v) { return ((v - KX) % N0 + N0) % N0; };  // virtual row -> row of the cube
 
         // The host rows among the virtual rows [v0, v1) -> consecutive rows of a box, run by run: a run ends where the next
@@ -1041,10 +1139,10 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
                 if (want_mse) scatter(Fw, -1, i++, false, false);
                 rc2 = copy_rows(cdst, csrc, row_bytes, st.main);
                 if (rc2) return rc2;
-                if (exact_wrap && u0 == 0)
-                    TVDN_HIP(hipMemcpyAsync(row0[0], Rw[0].row(0), row_bytes, hipMemcpyDeviceToDevice, st.main));
-                if (want_mse && done == 0)  // MSE[0]: the input against the reference (cyTVDN.py:124-125), own rows
-                    for (int64_t g = std::max(u0, G0); g < std::min(u1, G1); ++g)
+                if (exact_wrap && u0 == G0)
+                    TVDN_HIP(hipMemcpyAsync(row0[0], Rw[0].row(G0), row_bytes, hipMemcpyDeviceToDevice, st.main));
+                if (want_mse && first)  // MSE[0]: the input against the reference (cyTVDN.py:124-125), own rows
+                    for (int64_t g = std::max(u0, own0); g < std::min(u1, own1); ++g)
                         if ((rc2 = sse_row(Rw[0].row(g), Fw.row(g), 0, g - KX))) return rc2;
                 if (from_host) {
                     TVDN_HIP(hipEventRecord(in_free[h], st.main));
@@ -1074,7 +1172,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
                     }
                 }
                 // the sums count the cube's own rows once: wrapped rows (periodic) go to the discard slot
-                const int64_t parts[3][2] = {{lo, std::min(hi, G0)}, {std::max(lo, G0), std::min(hi, G1)}, {std::max(lo, G1), hi}};
+                const int64_t parts[3][2] = {{lo, std::min(hi, own0)}, {std::max(lo, own0), std::min(hi, own1)}, {std::max(lo, own1), hi}};
                 for (int part = 0; part < 3; ++part) {
                     const int64_t p0 = parts[part][0], p1 = parts[part][1];
                     if (p0 >= p1) continue;
@@ -1087,12 +1185,12 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
                         for (int64_t g = p0; g < p1; ++g)
                             if ((rc2 = sse_row(Fw.row(g), Rw[j + 1].row(g), done + j + 1, g - KX))) return rc2;
                 }
-                if (exact_wrap && lo == 0)
-                    TVDN_HIP(hipMemcpyAsync(row0[j + 1], Rw[j + 1].row(0), row_bytes, hipMemcpyDeviceToDevice, st.main));
+                if (exact_wrap && lo == G0)
+                    TVDN_HIP(hipMemcpyAsync(row0[j + 1], Rw[j + 1].row(G0), row_bytes, hipMemcpyDeviceToDevice, st.main));
             }
             // rows that have reached the last level go home: resident rows into the store (device copies, in the same launch
             // as the gather of the others into the out box), the others across PCIe.  [lo, hi) are rows of the cube proper.
-            const int64_t lo = std::max(G0, E0 + c * R - kk), hi = std::min(G1, E0 + (c + 1) * R - kk);
+            const int64_t lo = std::max(own0, E0 + c * R - kk), hi = std::min(own1, E0 + (c + 1) * R - kk);
             if (lo < hi) {
                 const bool to_host = host_rows_in(lo, hi) > 0;
                 if (to_host && out_free_set[h]) TVDN_HIP(hipStreamWaitEvent(st.main, out_free[h], 0));
@@ -1120,7 +1218,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
                     TVDN_HIP(hipEventRecord(out_ready[h], st.main));
                     TVDN_HIP(hipStreamWaitEvent(st.down, out_ready[h], 0));
                     if ((rc2 = wait_recon(h_new))) return rc2;  // the host arrays these rows land in exist (first pass: the helper may still be at it)
-                    const HostArr &rh = (periodic && h_new) ? recon2_h : recon_h;
+                    const HostArr &rh = (two_sets && h_new) ? recon2_h : recon_h;
                     // runs of host rows: consecutive cube rows (an array page-locked in place) or consecutive host slots inside
                     // one block of host state -- a run must be one piece in every destination
                     int64_t slot = 0;
@@ -1494,9 +1592,24 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
     fista_ratios(a->n_fista, ratios.data());
     for (int i = a->n_fista; i < n_total; ++i) ratios[i] = NAN;
     int ran = 0, ran_phase[2] = {a->n_fista, a->n_plain};
+    auto meet = [&]() -> int {  // slabs of a device-list run: every pass ends at the barrier (a failed slab releases the others)
+        if (!sh) return TVDN_OK;
+        const int rcb = sh->barrier->arrive_and_wait();
+        if (rcb) set_error("another slab of this run failed: %s", sh->barrier->msg.c_str());
+        return rcb;
+    };
     auto stop_after = [&](int slot, bool &stop) -> int {
         double s3[3];
         TVDN_HIP(hipMemcpy(s3, (double *)sums_d.p + 3 * (size_t)slot, sizeof s3, hipMemcpyDeviceToHost));
+        if (sh) {  // the global criterion: the sums of every slab (written between two meetings, read between the next two)
+            for (int j = 0; j < 3; ++j) sh->stop_sums[3 * sh->index + j] = s3[j];
+            int rcb = meet();
+            if (rcb) return rcb;
+            s3[0] = s3[1] = s3[2] = 0.0;
+            for (int r = 0; r < sh->count; ++r)
+                for (int j = 0; j < 3; ++j) s3[j] += sh->stop_sums[3 * r + j];
+            if ((rcb = meet())) return rcb;
+        }
         const double delta = a->dtype == TVDN_F32 ? (double)((float)s3[1] / (float)s3[2]) : s3[1] / s3[2];
         stop = delta < a->stop;
         return TVDN_OK;
@@ -1511,15 +1624,16 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
     // tie (38.4 / 39.4: the first pass uploads little, the last one only drains); and a run that keeps most rows resident is
     // bound by its sweeps, which the download kernel disturbs (51.6 against 57.0).  profiles/r04_stream_rates.jsonl.
     // Default: chain from 3 passes on when no row is resident; TVDN_STREAM_CHAIN=1 / 0 forces it on (where possible) / off.
-    bool want_chain = RES == 0 && n_pass_plan >= 3;
+    bool want_chain = RES == 0 && n_pass_plan >= 3 && !sh;
     if (const char *e = getenv("TVDN_STREAM_CHAIN")) want_chain = atoi(e) != 0;
     const bool can_chain = want_chain && !periodic && !a->use_stop && n_pass_plan > 1 && K <= N0 - 3 * R;
     down_blocks = can_chain ? 8 : 0;
     if (const char *e = getenv("TVDN_STREAM_DOWN_BLOCKS")) down_blocks = std::max(0, atoi(e));
     if (!periodic && exact_wrap)
         for (int64_t j = 0; j <= K; ++j) row0b.push_back(row0b_base + (size_t)j * plane_b);
+    const bool drained_pass = periodic || sh != nullptr;  // the `pass` lambda: two sets of host state, artificial faces
     if (!a->use_stop) {
-        if (!periodic) {
+        if (!drained_pass) {
             std::vector<PassDesc> all;
             for (int i = 0; i < n_total;) {  // a pass may hold the last FISTA iterations and the first unaccelerated ones
                 const int kk = depth_of_pass((int)all.size());
@@ -1542,9 +1656,10 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
             }
             ran = n_total;
         } else {
-            for (int i = 0; i < n_total;) {
-                const int kk = (int)std::min<int64_t>(K, n_total - i);
+            for (int i = 0, q = 0; i < n_total; ++q) {
+                const int kk = depth_of_pass(q);
                 if ((rc = pass(ratios.data() + i, kk))) return rc;
+                if ((rc = meet())) return rc;  // (slabs) every slab has written its rows of the new set
                 if (i == 0) first_pass_s = since(t_passes);
                 ran += kk;
                 i += kk;
@@ -1560,8 +1675,9 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
             done = first;
             ran_phase[phase] = 0;
             for (int i = first; i < last; ++i) {
-                if (periodic) {
+                if (drained_pass) {
                     if ((rc = pass(ratios.data() + i, 1))) return rc;
+                    if ((rc = meet())) return rc;
                 } else {
                     std::vector<PassDesc> one(1);
                     if ((rc = describe(i, 1, ratios.data() + i, one[0]))) return rc;
@@ -1594,7 +1710,9 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
         if (rc) return rc;
         g = e;
     }
-    if (HR > 0) {
+    if (sh) {
+        *sh->last_set = h_old;  // the coordinator brings the result home (run_streamed_slabs)
+    } else if (HR > 0) {
         const HostArr &last = (periodic && h_old == 1) ? recon2_h : recon_h;  // periodic: the set the last pass wrote
         if (last.owned) pack_host_rows(last.p, (char *)a->recon_out, false);
         else if (last.p != (char *)a->recon_out) parallel_copy(a->recon_out, last.p, cube_bytes);
@@ -1635,7 +1753,15 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
     ref_h.release();
     recon2_h.release();
     lap(2);
-    for (int s = 0; s < n_sets; ++s) sb[s].blocks.clear();
+    {
+        std::vector<std::unique_ptr<PinnedBuf>> all;
+        for (int s = 0; s < n_sets; ++s) {
+            for (auto &b : sb[s].blocks)
+                if (b) all.push_back(std::move(b));
+            sb[s].blocks.clear();
+        }
+        PinnedBuf::release_in_background(std::move(all));
+    }
     lap(3);
     if (getenv("TVDN_STREAM_TIMING"))  // measurement aid: set-up apart from the passes
         fprintf(stderr, "tvdn_run streamed: rows %lld k %lld resident rows %lld of %lld, set-up %.3f s, passes %.3f s (first %.3f s), results home %.3f s; "
@@ -1655,6 +1781,183 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req)
         s.setup_s = std::chrono::duration<double>(t_passes - t_start).count();
         s.loop_s = std::chrono::duration<double>(t_end_passes - t_passes).count();
         s.total_s = since(t_start);
+    }
+    return TVDN_OK;
+}
+
+// ---- a device list whose slabs do not fit their devices: every slab streamed through its own GPU ----------------------------
+// BASELINE configs[4] in structure, inside ONE process (what replaces cyTVDN/mpi.py:131-239 + :314-434 on a node: tiling,
+// per-rank load, halo patching): axis 0 is cut into one slab per entry of `devices`, the state of the WHOLE cube lives in
+// page-locked host arrays shared by all slabs -- two sets, a pass reads one and writes the other -- and every slab streams its
+// rows through its device with the wavefront schedule, reading K rows of its neighbours' state beyond each interior face from
+// those same arrays (no messages: the neighbours' rows ARE in this process's memory) and giving up a row per level there.
+// One host thread per slab; all of them meet after every pass.  Sums, stopping rule and MSE trace are global.  (Across
+// PROCESSES the same decomposition is cytvdn_amd.distributed.denoise_slabs(staged=...).)
+int run_streamed_slabs(const tvdn_run_args *a, int64_t R, int64_t K)
+{
+    const auto t_start = std::chrono::steady_clock::now();
+    const int world = a->n_devices;
+    const int nd = a->ndim;
+    const size_t item = a->dtype == TVDN_F32 ? 4 : 8;
+    size_t plane = 1;
+    for (int i = 1; i < nd; ++i) plane *= (size_t)a->shape[i];
+    const size_t row_bytes = plane * item;
+    const int64_t N0 = a->shape[0];
+    const size_t cube_bytes = (size_t)N0 * row_bytes;
+    const int n_total = a->n_fista + a->n_plain;
+    const int n_state = a->n_fista > 0 ? 2 : 1;
+    const bool want_mse = a->mse_out != nullptr && a->reference != nullptr;
+    const bool periodic = a->bc_mode == TVDN_BC_PERIODIC;
+    TVDN_REQUIRE(world >= 2 && world <= TVDN_MAX_DEVICES, "a streamed device list needs 2..%d entries", TVDN_MAX_DEVICES);
+    TVDN_REQUIRE(N0 >= world, "axis 0 (%lld rows) cannot be cut into %d slabs", (long long)N0, world);
+    TVDN_REQUIRE(R >= 1 && K >= 1, "stream_rows and stream_k must be >= 1");
+    if (n_total == 0) {  // nothing to iterate: the one-device path knows what to do
+        tvdn_run_args one = *a;
+        one.n_devices = 0;
+        one.device = a->devices[0];
+        return run_streamed(&one, R, K, 0);
+    }
+    if (!periodic) {  // the exact Jia-Zhao wrap of a non-finite first row needs row 0 of every level on the LAST slab's device
+        bool bad = false;
+        if (a->dtype == TVDN_F32) {
+            const float *p0 = (const float *)a->data;
+            for (size_t i = 0; i < plane && !bad; ++i) bad = !std::isfinite(p0[i]);
+        } else {
+            const double *p0 = (const double *)a->data;
+            for (size_t i = 0; i < plane && !bad; ++i) bad = !std::isfinite(p0[i]);
+        }
+        if (bad) {
+            set_error("the cube's first row holds Inf / NaN: a streamed device list closes the Jia-Zhao wrap with the constant that holds "
+                      "for finite data only; run it resident (more devices), on one device, or with denoise_slabs(staged=...)");
+            return TVDN_ERR_UNSUPPORTED;
+        }
+    }
+    const bool aliased = arrays_overlap(a->data, a->recon_out, cube_bytes);
+    {   // can the host hold two sets of the state page-locked?  before anything of the caller's is touched
+        const double need = (double)(1 + (aliased ? 1 : 0) + 2 + 2 * nd * n_state + (want_mse ? 1 : 0)) * (double)cube_bytes;
+        const size_t avail = host_available_bytes();
+        if (avail == 0 || need > 0.8 * (double)avail) {
+            set_error("a streamed device list keeps two sets of the state page-locked on the host: %.0f bytes, which exceeds what the host "
+                      "has available (%zu bytes, of which 80 %% are used at most)", need, avail);
+            return TVDN_ERR_UNSUPPORTED;
+        }
+    }
+    // ---- host state: the caller's arrays page-locked in place where possible, the rest from huge-page memory -------------------
+    HostArr orig_h, ref_h, recon0_h;
+    PinnedBuf recon1;
+    std::unique_ptr<PinnedBuf[]> state(new PinnedBuf[(size_t)2 * nd * n_state]);
+    int rc = aliased ? orig_h.alloc(cube_bytes) : orig_h.pin_in_place(const_cast<void *>(a->data), cube_bytes, cube_bytes, false);
+    if (rc) return rc;
+    if (orig_h.owned) parallel_copy(orig_h.p, a->data, cube_bytes);
+    if (want_mse) {
+        if ((rc = ref_h.pin_in_place(const_cast<void *>(a->reference), cube_bytes, cube_bytes, false))) return rc;
+        if (ref_h.owned) parallel_copy(ref_h.p, a->reference, cube_bytes);
+    }
+    if ((rc = recon0_h.pin_in_place(a->recon_out, cube_bytes, cube_bytes, !aliased))) return rc;
+    if ((rc = recon1.alloc(cube_bytes))) return rc;
+    for (int i = 0; i < 2 * nd * n_state; ++i)
+        if ((rc = state[(size_t)i].alloc(cube_bytes))) return rc;
+    // the set the first pass writes: chosen so that the LAST pass lands in recon_out (unknown with a stopping rule: copied then)
+    const int64_t k_eff = a->use_stop ? 1 : std::min<int64_t>({K, (int64_t)n_total, N0});
+    const int n_pass = a->use_stop ? n_total : (int)((n_total + k_eff - 1) / k_eff);
+    const int first_new = a->use_stop ? 1 : ((n_pass - 1) & 1);
+
+    SlabBarrier bar;
+    bar.count = world;
+    std::vector<SlabShare> shares((size_t)world);
+    std::vector<tvdn_run_args> args((size_t)world, *a);
+    std::vector<std::vector<double>> sums((size_t)world, std::vector<double>((size_t)3 * n_total, 0.0));
+    std::vector<std::vector<double>> mses((size_t)world, std::vector<double>((size_t)n_total + 1, 0.0));
+    std::vector<tvdn_run_stats> stats((size_t)world);
+    std::vector<int32_t> iters((size_t)world, 0);
+    std::vector<int32_t> phases((size_t)2 * world, 0);
+    std::vector<double> stop_sums((size_t)3 * world, 0.0);
+    std::vector<int> last_set((size_t)world, 0), rcs((size_t)world, 0);
+    std::vector<std::string> msgs((size_t)world);
+    for (int r = 0; r < world; ++r) {
+        SlabShare &sh = shares[(size_t)r];
+        sh.index = r;
+        sh.count = world;
+        sh.g0 = (int64_t)r * N0 / world;
+        sh.g1 = (int64_t)(r + 1) * N0 / world;
+        sh.orig = orig_h.p;
+        sh.ref = want_mse ? ref_h.p : nullptr;
+        sh.recon[0] = recon0_h.p;
+        sh.recon[1] = recon1.p;
+        for (int set = 0; set < 2; ++set)
+            for (int i = 0; i < nd * n_state; ++i) sh.state[set][i] = state[(size_t)set * nd * n_state + i].p;
+        sh.first_new = first_new;
+        sh.barrier = &bar;
+        sh.stop_sums = stop_sums.data();
+        sh.last_set = &last_set[(size_t)r];
+        tvdn_run_args &x = args[(size_t)r];
+        x.n_devices = 0;
+        x.device = a->devices[r];
+        x.sums_out = sums[(size_t)r].data();
+        x.mse_out = want_mse ? mses[(size_t)r].data() : nullptr;
+        x.iters_run = &iters[(size_t)r];
+        x.phase_iters = &phases[(size_t)2 * r];
+        x.stats = &stats[(size_t)r];
+        x.stream_resident = 0;
+        if (r != 0) x.progress = nullptr;
+    }
+    const auto t_threads = std::chrono::steady_clock::now();
+    {
+        std::vector<std::thread> th;
+        for (int r = 0; r < world; ++r)
+            th.emplace_back([&, r] {
+                DeviceRestore restore;
+                rcs[(size_t)r] = run_streamed(&args[(size_t)r], R, K, 0, &shares[(size_t)r]);
+                if (rcs[(size_t)r]) {
+                    msgs[(size_t)r] = tvdn_last_error();
+                    bar.fail(rcs[(size_t)r], msgs[(size_t)r].c_str());
+                }
+            });
+        for (auto &t : th) t.join();
+    }
+    for (int r = 0; r < world; ++r)
+        if (rcs[(size_t)r] && msgs[(size_t)r].find("another slab") == std::string::npos) {  // the slab that failed first-hand
+            set_error("slab %d (device %d): %s", r, a->devices[r], msgs[(size_t)r].c_str());
+            return rcs[(size_t)r];
+        }
+    for (int r = 0; r < world; ++r)
+        if (rcs[(size_t)r]) {
+            set_error("%s", msgs[(size_t)r].c_str());
+            return rcs[(size_t)r];
+        }
+    const auto t_done = std::chrono::steady_clock::now();
+    // ---- results home ----------------------------------------------------------------------------------------------------------
+    std::memset(a->sums_out, 0, sizeof(double) * 3 * (size_t)n_total);
+    for (int r = 0; r < world; ++r)
+        for (size_t i = 0; i < (size_t)3 * n_total; ++i) a->sums_out[i] += sums[(size_t)r][i];
+    if (want_mse) {
+        std::memset(a->mse_out, 0, sizeof(double) * ((size_t)n_total + 1));
+        for (int r = 0; r < world; ++r)
+            for (size_t i = 0; i <= (size_t)n_total; ++i) a->mse_out[i] += mses[(size_t)r][i];
+    }
+    if (last_set[0] == 1)
+        parallel_copy(a->recon_out, recon1.p, cube_bytes);
+    else if (recon0_h.owned)
+        parallel_copy(a->recon_out, recon0_h.p, cube_bytes);
+    if (a->iters_run) *a->iters_run = iters[0];
+    if (a->phase_iters) {
+        a->phase_iters[0] = phases[0];
+        a->phase_iters[1] = phases[1];
+    }
+    if (a->stats) {
+        tvdn_run_stats &o = *a->stats;
+        std::memset(&o, 0, sizeof o);
+        o.engine = TVDN_ENGINE_STREAMED;
+        o.stream_rows = stats[0].stream_rows;
+        o.stream_k = stats[0].stream_k;
+        o.n_passes = stats[0].n_passes;
+        for (int r = 0; r < world; ++r) {
+            o.h2d_bytes += stats[(size_t)r].h2d_bytes;
+            o.d2h_bytes += stats[(size_t)r].d2h_bytes;
+        }
+        o.setup_s = std::chrono::duration<double>(t_threads - t_start).count();
+        o.loop_s = std::chrono::duration<double>(t_done - t_threads).count();
+        o.total_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     }
     return TVDN_OK;
 }

@@ -134,8 +134,13 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
 
     if isinstance(device, (list, tuple)):
         if len(device) > 1:
+            # the library decides: slabs resident where they fit their devices, else every slab streamed through its own
+            # device from host arrays all of them share (tvdn_run, stream_rows / stream_k = -1 / -1); TVDN_WAVEFRONT=rows,k
+            # forces the streamed form
+            wf_ = os.environ.get("TVDN_WAVEFRONT")
             return _run_device_list([int(d) for d in device], datacube, lambdaInv, lam_mu, n_fista, n_plain,
-                                    stopping_relative_change, reference_data, BC_mode, quiet, out=out)
+                                    stopping_relative_change, reference_data, BC_mode, quiet, out=out,
+                                    stream=tuple(int(v) for v in wf_.split(",")) if wf_ else (-1, -1))
         device = int(device[0]) if len(device) else None
     if device is None:
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
@@ -339,11 +344,11 @@ def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, sto
     dtype = datacube.dtype
     nd = datacube.ndim
     n = n_fista + n_plain
-    if not quiet and stream is None and announce:
+    if not quiet and (stream is None or len(devices) > 1) and announce:
         print(f"Cutting axis 0 into {len(devices)} slabs on devices {devices} (one process, peer copies)", flush=True)
     a = _lib.RunArgs(dtype=_lib.dtype_code(dtype), ndim=nd, bc_mode=int(BC_mode), device=devices[0], n_fista=n_fista,
                      n_plain=n_plain, use_stop=int(stop is not None), stop=float(stop or 0.0),
-                     n_devices=len(devices) if stream is None else 0)
+                     n_devices=len(devices) if (stream is None or len(devices) > 1) else 0)
     if stream is not None:
         a.stream_rows, a.stream_k = int(stream[0]), int(stream[1])
         a.stream_resident = -1       # the low rows whose state fits beside the rings stay in HBM between the passes

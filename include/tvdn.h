@@ -221,8 +221,10 @@ int tvdn_iterate_many(tvdn_ctx *ctx, tvdn_many_args *state, int32_t n_fista, con
  *             copies over xGMI, on a copy stream per slab) while the interior rows are swept -- the
  *             single-process form of the slab decomposition that replaces cyTVDN/mpi.py:314-434 (the
  *             multi-process form over RCCL is cytvdn_amd.distributed.denoise_slabs).  Each slab's state must fit
- *             its device's HBM (90 % of what is free, tvdn_plan); a cube beyond the HBM of ONE device is streamed
- *             through it instead when stream_rows / stream_k ask for it (below).
+ *             its device's HBM (90 % of what is free, tvdn_plan); what does not fit is streamed when stream_rows /
+ *             stream_k ask for it (below): a cube beyond the HBM of ONE device through that device, and with a device
+ *             list every slab through its own device from page-locked host arrays all slabs share (BASELINE configs[4]
+ *             in structure, inside one process).
  *   data / recon_out may be the same array or overlap (denoise in place): the resident run uploads `data` before it
  *             writes anything; the streamed run then keeps the data term in a pinned copy of its own (one more cube
  *             of host memory, counted by tvdn_stream_host_need).
@@ -280,12 +282,16 @@ typedef struct tvdn_run_args {
     double *mse_out;
     int32_t *iters_run;
     int32_t devices[TVDN_MAX_DEVICES];
-    /* Out-of-core (ABI 3).  A cube whose state does not fit its ONE device is streamed through it from pinned host
-     * memory with the wavefront schedule: chunks of stream_rows rows, stream_k iterations per PCIe round trip, every
-     * row of every iteration swept once (row rings, tvdn_iter_args.ring_rows); bit-identical to the resident run.
+    /* Out-of-core (ABI 3).  A cube whose state does not fit its device(s) is streamed from pinned host memory with the
+     * wavefront schedule: chunks of stream_rows rows, stream_k iterations per PCIe round trip, every row of every iteration
+     * swept once (row rings, tvdn_iter_args.ring_rows); bit-identical to the resident run.
      * 0 / 0: never (a state beyond the HBM is refused with TVDN_ERR_UNSUPPORTED and the arithmetic in the message);
-     * -1 / -1: decided here -- resident when it fits, else the deepest stream_k whose rings fit 85 % of the free HBM;
-     * both > 0: stream with exactly these.  A cube whose state the host cannot hold page-locked either is refused
+     * -1 / -1: decided here -- resident when it fits, else streamed with the library's own plan (tvdn_stream_plan);
+     * both > 0: stream with exactly these.  With a device list (ABI 6) every slab is streamed through its own device: the
+     * state of the whole cube lives in page-locked host arrays shared by the slabs (two sets: a pass reads one and writes the
+     * other), a slab reads stream_k rows of its neighbours' state beyond each interior face from them and gives up a row per
+     * level there, the slabs meet after every pass; sums, stopping rule and MSE trace are global (a cube whose first row
+     * holds Inf / NaN is refused in this form).  A cube whose state the host cannot hold page-locked either is refused
      * before any of the caller's arrays is touched.  Both boundary conditions (periodic: the cube is swept between
      * stream_k wrapped rows at either end, and old and new host state are two sets of arrays); with use_stop one iteration per
      * pass.  `data` / `recon_out` / `reference` are page-locked in place for the duration of the call when they are

@@ -210,3 +210,19 @@ def test_planner_counts_what_torchs_cache_holds():
     assert held <= base - (2 << 30) + (64 << 20)
     assert cached >= free_now + (2 << 30) - (64 << 20) and abs(cached - base) <= (64 << 20)
     torch.cuda.empty_cache()
+
+
+def test_device_list_streams_its_slabs_when_told_to(oracle, monkeypatch):
+    """denoise4D(device=[0, 0, 0]) with TVDN_WAVEFRONT=rows,k: three slabs, each STREAMED through its device from host arrays
+    they share (tvdn_run with a device list and stream_rows / stream_k; BASELINE configs[4] in structure) -- the oracle's bits
+    and traces, hybrid schedule included."""
+    import cytvdn_amd as tv
+    from cytvdn_amd import synth
+    dt = np.dtype(np.float32)
+    x = synth.cube((26, 4, 8, 16), seed=61, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6], dt)
+    monkeypatch.setenv("TVDN_WAVEFRONT", "3,4")
+    got = tv.denoise4D(x, mu, [6, 3], quiet=True, device=[0, 0, 0])
+    ref = oracle.denoise(x, mu, [6, 3], True)
+    assert bits_equal(got[0], ref["recon"])
+    np.testing.assert_allclose(got[1].astype(np.float64), ref["b_norm64"].astype(dt).astype(np.float64), rtol=1e-6)

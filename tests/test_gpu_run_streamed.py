@@ -33,7 +33,7 @@ def _check_traces(sums, ref, n):
     np.testing.assert_allclose(sums[:n, 2], ref["rnorm64"][:n], rtol=1e-9)
 
 
-def _run(x, mu, n_f, n_p, stop=None, ref=None, stream=None, device=0, bc=2, resident=0, stats=None):
+def _run(x, mu, n_f, n_p, stop=None, ref=None, stream=None, device=0, bc=2, resident=0, stats=None, devices=None):
     from cytvdn_amd import _lib
     dt = x.dtype
     nd = x.ndim
@@ -46,6 +46,10 @@ def _run(x, mu, n_f, n_p, stop=None, ref=None, stream=None, device=0, bc=2, resi
         a.stream_resident = resident
     if stats is not None:
         a.stats = C.addressof(stats)
+    if devices is not None:
+        a.n_devices = len(devices)
+        for i, d in enumerate(devices):
+            a.devices[i] = d
     for i, s in enumerate(x.shape):
         a.shape[i] = s
     for q in range(nd):
@@ -363,3 +367,74 @@ def test_streamed_run_with_periodic_boundaries(oracle, shape, dtype, n_f, n_p, r
     n_run = np.nonzero(ran)[0]
     np.testing.assert_allclose(got[2][0], ref["MSE64"][0], rtol=2e-7)
     np.testing.assert_allclose(got[2][n_run + 1], ref["MSE64"][n_run + 1], rtol=2e-7)
+
+
+@pytest.mark.parametrize("shape,dtype,n_f,n_p,rows,k,bc,slabs,stop", [
+    ((23, 3, 4, 8), np.float32, 9, 0, 5, 3, 2, 2, None),       # two slabs (11 + 12 rows), three passes
+    ((23, 3, 4, 8), np.float32, 9, 0, 2, 4, 2, 3, None),       # three slabs, passes of 3 + 3 + 3 levels
+    ((23, 3, 4, 8), np.float32, 5, 4, 3, 9, 2, 3, None),       # hybrid in ONE pass deeper than a slab is tall: halos reach past the neighbour
+    ((40, 4, 8, 16), np.float32, 7, 6, 3, 4, 2, 4, None),      # hybrid over four passes, four slabs
+    ((17, 6, 16), np.float64, 0, 7, 3, 5, 2, 2, None),         # unaccelerated, 3-D, f64
+    ((17, 6, 16), np.float64, 7, 0, 4, 2, 0, 3, None),         # periodic: every face artificial, the first and the last slab wrap
+    ((23, 3, 4, 8), np.float32, 9, 0, 5, 3, 0, 2, None),
+    ((9, 2, 5, 7), np.float32, 6, 0, 2, 8, 2, 3, None),        # scalar packs; more levels than rows
+    ((12, 5, 8, 12), np.float32, 0, 40, 4, 6, 2, 3, 0.02),     # the GLOBAL stopping rule: one level per pass, sums over the slabs
+    ((11, 3, 7, 9), np.float64, 30, 6, 3, 4, 0, 2, 0.03),      # ... periodic, both phases
+])
+def test_streamed_device_list(oracle, shape, dtype, n_f, n_p, rows, k, bc, slabs, stop):
+    """A device list whose slabs are STREAMED (BASELINE configs[4] in structure, inside one process): the state of the whole
+    cube in page-locked host arrays shared by the slabs (two sets), every slab streamed through its device (here: several
+    slabs on device 0) reading k rows of its neighbours' state beyond each interior face, the slabs meeting after every pass;
+    global sums, global stopping rule, MSE trace.  The oracle's bits (the reference has no counterpart that works:
+    cyTVDN/mpi.py:131-239 + :314-434, SURVEY B-7)."""
+    from cytvdn_amd import _lib, synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=37, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    n = n_f + n_p
+    st = _lib.RunStats()
+    got = _run(x, mu, n_f, n_p, stop=stop, stream=(rows, k), bc=bc, devices=[0] * slabs, stats=st)
+    ref = _oracle_bc(oracle, x, mu, n_f, n_p, bc, **({"stopping_relative_change": stop} if stop is not None else {}))
+    assert bits_equal(got[0], ref["recon"])
+    assert st.engine == 1
+    if stop is None:
+        assert got[3] == n
+        _check_traces(got[1], ref, n)
+    else:
+        assert 0 < got[3] == ref["iters_done"] < n
+        ran = got[1][:, 2] != 0
+        np.testing.assert_allclose(got[1][ran, 0], ref["b_norm64"][ran], rtol=1e-9)
+        np.testing.assert_allclose(got[1][ran, 1], ref["delta64"][ran], rtol=1e-9)
+
+
+def test_streamed_device_list_mse_in_place_and_refusals(oracle):
+    from cytvdn_amd import _lib, synth
+    dt = np.dtype(np.float32)
+    shape = (21, 3, 6, 8)
+    x = synth.cube(shape, seed=41, dtype=dt) + dt.type(0.5)
+    clean = synth.cube(shape, seed=41, dtype=dt, kind="mean")
+    mu = np.array([1.0, 0.8, 0.5, 0.6], dt)
+    got = _run(x, mu, 6, 2, ref=clean, stream=(3, 3), devices=[0, 0, 0])
+    oref = _oracle(oracle, x, mu, 6, 2, reference_data=clean)
+    assert bits_equal(got[0], oref["recon"])
+    np.testing.assert_allclose(got[2], oref["MSE64"], rtol=2e-7)
+    # in place: data is recon_out
+    lam = mu / dt.type(32.0)
+    buf = x.copy()
+    a = _lib.RunArgs(dtype=0, ndim=4, bc_mode=2, n_fista=7, n_plain=0, stream_rows=3, stream_k=2, n_devices=2)
+    for i, s_ in enumerate(shape):
+        a.shape[i] = s_
+        a.clip[i] = float((1.0 / lam)[i])
+        a.lambda_mu[i] = float((lam / mu).astype(dt)[i])
+    sums = np.zeros((7, 3))
+    a.data = a.recon_out = buf.ctypes.data
+    a.sums_out = sums.ctypes.data
+    _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+    ref = _oracle(oracle, x, mu, 7, 0)
+    assert bits_equal(buf, ref["recon"])
+    _check_traces(sums, ref, 7)
+    # a non-finite first row is refused in this form (the exact wrap would need row 0 of every level on the last device)
+    x[0, 1, 2, 3] = np.inf
+    with pytest.raises(NotImplementedError, match="first row"):
+        _run(x, mu, 3, 0, stream=(3, 2), devices=[0, 0])
