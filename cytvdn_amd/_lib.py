@@ -89,6 +89,20 @@ class StreamPlanOut(C.Structure):
                 ("host_bytes", C.c_int64)]
 
 
+SLAB_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int64)
+SLAB_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
+SLAB_RELAY = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64)
+
+
+class SlabIO(C.Structure):
+    """struct tvdn_slab_io (include/tvdn.h, ABI 6): one slab of a multi-process streamed run and its hooks."""
+    _fields_ = [
+        ("global_rows", C.c_int64), ("row0", C.c_int64), ("rank", C.c_int32), ("world", C.c_int32),
+        ("first_row_nonfinite", C.c_int32), ("reserved", C.c_int32),
+        ("exchange", SLAB_EXCHANGE), ("allreduce", SLAB_ALLREDUCE), ("relay_row0", SLAB_RELAY), ("user", C.c_void_p),
+    ]
+
+
 class RunArgs(C.Structure):
     """struct tvdn_run_args (include/tvdn.h)."""
     _fields_ = [
@@ -107,6 +121,7 @@ class RunArgs(C.Structure):
         ("workspace_bytes", C.c_int64),
         ("stats", C.c_void_p),
         ("stream_resident", C.c_int64),
+        ("slab", C.POINTER(SlabIO)),
     ]
 
 

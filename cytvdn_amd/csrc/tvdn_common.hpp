@@ -70,7 +70,7 @@ inline int canon_axis(int ndim, int ax) { return (ndim == 4 || ax == 0) ? ax : a
 
 // ---- the host side of an iteration, defined ONCE ---------------------------------------------------
 // Every loop in the tree -- tvdn_iterate_many, tvdn_run (resident and streamed), and through the exported
-// tvdn_fista_ratios / tvdn_roles_bind / tvdn_roles_advance the Python engines -- takes its schedule from here.
+// tvdn_fista_ratios / tvdn_roles_bind / tvdn_roles_advance the Python loop of engine.SlabRunner -- takes its schedule from here.
 
 // (tk-1)/tk_new of iterations 0..n-1: the float64 recurrence of cyTVDN.py:153-156, tk starting at 1.
 inline void fista_ratios(int n, double *out)
@@ -222,6 +222,7 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
 struct SlabShare;
 int run_streamed(const tvdn_run_args *a, int64_t rows, int64_t k, int64_t resident_rows, const SlabShare *slab = nullptr);
 int run_streamed_slabs(const tvdn_run_args *a, int64_t rows, int64_t k);
+int run_streamed_rank(const tvdn_run_args *a, int64_t rows, int64_t k);  // one slab of a multi-process run (tvdn_slab_io)
 // tvdn_run.hip: the big device block of a run is KEPT when the run ends (one per device) and handed to the next run it fits
 // (releasing and re-allocating tens of GiB in quick succession costs seconds); tvdn_release_cache() returns it
 hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, bool *reused, bool any_larger);

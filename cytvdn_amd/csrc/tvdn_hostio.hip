@@ -185,7 +185,7 @@ extern "C" int tvdn_copy_to_host(void *dst_host, const void *src_device, size_t 
 }
 
 // ---- many equal-sized copies behind one launch (HBM <-> HBM, or HBM <-> pinned host memory) ---------------------------
-// The wavefront engine (cytvdn_amd/wavefront.py) slides ~150 level windows and fills / drains ~20 staging boxes per
+// A streamed run (csrc/tvdn_stream.hip; round 2's Python engine before it) moves ~150 level windows and fills / drains ~20 staging boxes per
 // chunk.  As individual hipMemcpyAsync calls those are blit kernels of the runtime that reach ~1 TB/s on 512 MiB
 // (rocprofv3: 81 % of the GPU time of a pass on 256 MiB planes); batched here they are one streaming kernel per group.
 namespace tvdn {

@@ -347,7 +347,7 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
     // 12.1 / 12.6 ms for the same 60 GiB at identical clocks).  Before a run long enough to pay for it, further
     // candidates are allocated beside the first while they fit 80 % of the free HBM, each is timed for two sweeps on a
     // zero-filled state (the sweep is branch-free), the fastest is kept.  cytvdn_amd/engine.py HipBackend.best_of is the
-    // same thing for the Python engines; TVDN_AUDITION=n overrides the count (1 = take the first allocation).
+    // same thing for engine.SlabRunner (slabs across ranks); TVDN_AUDITION=n overrides the count (1 = take the first allocation).
     if (world == 1) {
         Slab &s = sl[0];
         const char *e = getenv("TVDN_AUDITION");
@@ -967,6 +967,11 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
         return TVDN_ERR_UNSUPPORTED;
     }
     TVDN_REQUIRE(a->bc_mode == 0 || a->bc_mode == 2, "bc_mode must be 0 or 2, got %d", a->bc_mode);
+    if (a->slab) {  // one slab of a multi-process streamed run: the caller's hooks carry what crosses process boundaries
+        TVDN_REQUIRE(a->stream_rows > 0 && a->stream_k > 0, "a slab of a multi-process run (tvdn_run_args.slab) is streamed: stream_rows and stream_k must be positive");
+        TVDN_REQUIRE(a->n_devices <= 1, "a slab of a multi-process run uses one device");
+        return tvdn::run_streamed_rank(a, a->stream_rows, a->stream_k);
+    }
     if (a->stream_rows > 0) {
         const auto ts = std::chrono::steady_clock::now();
         // several devices: every slab streamed through its own GPU from host arrays all of them share (tvdn_stream.hip)

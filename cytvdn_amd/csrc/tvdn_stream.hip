@@ -1,6 +1,6 @@
 // tvdn_run for a cube whose state does not fit the HBM of its device: the out-of-core wavefront schedule in C++
-// (include/tvdn.h, tvdn_run_args.stream_rows / stream_k).  Same schedule as cytvdn_amd/wavefront.py for one process:
-// the state lives in pinned host memory, streams through the GPU once per pass in chunks of R rows, and iteration
+// (include/tvdn.h, tvdn_run_args.stream_rows / stream_k) -- the ONE streamed engine of the tree (one device, a device list,
+// a rank of a multi-process run): the state lives in pinned host memory, streams through the GPU once per pass in chunks of R rows, and iteration
 // level j+1 trails level j by one row, so every row of every level is swept exactly once and crosses PCIe once per
 // k iterations.  Every level keeps a ring of R+2 rows per array in HBM (tvdn_iter_args.ring_rows); the sweeps are
 // tvdn_iterate_fused launches, so the bits are those of the resident engine.  Upstream has no counterpart: its
@@ -524,6 +524,15 @@ struct SlabShare {
     double *stop_sums = nullptr; // [count][3]: every slab's sums of the iteration just run (stopping rule)
     int *last_set = nullptr;     // out: the set the last pass wrote
     tvdn_run_stats *stats = nullptr;
+    // One slab per PROCESS (run_streamed_rank): the arrays are this process's own -- halo + own + halo rows, virtual row v at
+    // + (v - local_v0) * row_bytes, both "sets" the same arrays (a pass writes its own rows k rows behind where it reads) --
+    // and what crosses process boundaries goes through the caller's hooks.
+    bool local_rows = false;
+    int64_t local_v0 = 0;
+    bool exact_wrap = false;                             // Jia-Zhao, first row of the cube not finite (the same on every slab)
+    std::function<int()> before_pass;                    // before every pass but the first: refresh the halo rows of recon / state
+    std::function<int(double *)> allreduce;              // one iteration's three sums -> over all slabs (stopping rule)
+    std::function<int(int, void *, int)> relay_row0;     // (send, planes, n): row 0 of every level, first slab -> last slab
 };
 
 namespace {
@@ -690,7 +699,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
     if (!a->use_stop) K = depth_of_pass(0);
     // Periodic boundaries along axis 0: the sweeps see a virtual cube of N0 + 2 K rows -- the cube between K wrapped rows
     // at either end, which are each other's halo -- and, as at the face between two slabs, give up one row per level at
-    // the two artificial faces; the wrap itself is never swept (cytvdn_amd/wavefront.py does the same).
+    // the two artificial faces; the wrap itself is never swept.
     // A slab of a device-list run (sh): the same virtual rows -- the cube between K rows at either end -- of which this slab
     // owns [own0, own1); at its interior faces it reads K rows of its neighbours' state (shared host arrays) and gives up a row
     // per level, as a periodic run does at both ends.
@@ -750,7 +759,9 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
 
     // Jia-Zhao wrap at the top face: exact (TVDN_EDGE_WRAP, row 0 of every level kept aside) when row 0 is not finite
     bool exact_wrap = false;
-    if (periodic) {
+    if (sh) {
+        exact_wrap = !periodic && sh->exact_wrap;  // (the coordinator has looked: a slab may not hold the cube's first row)
+    } else if (periodic) {
         // the wrap is swept for real on the extended cube
     } else if (a->dtype == TVDN_F32) {
         const float *p0 = (const float *)a->data;
@@ -976,8 +987,15 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
     };
 
     int h_old = sh ? sh->first_new ^ 1 : 0;  // which set holds the current state (two sets: periodic runs, slabs); 0 = recon_h / sb[0]
-    auto recon_row = [&](int set, int64_t g) -> char * { return host_row((two_sets && set) ? recon2_h : recon_h, g); };
     auto wait_recon = [&](int set) -> int { return ((two_sets && set) ? recon2_ready : recon_ready).wait(); };
+    // row of a host array by cube row g / virtual row v (a slab of its own process addresses its local arrays by v)
+    const bool local_rows = sh && sh->local_rows;
+    auto hrow = [&](const HostArr &h, int64_t g, int64_t v) -> char * {
+        return local_rows ? h.p + (size_t)(v - sh->local_v0) * row_bytes : host_row(h, g);
+    };
+    auto srow = [&](int set, int arr, int64_t g, int64_t v) -> char * {
+        return local_rows ? sb[set].flat[(size_t)arr] + (size_t)(v - sh->local_v0) * row_bytes : sb[set].row(arr, rm.host_below(g));
+    };
 
     tvdn_iter_args it;
     std::memset(&it, 0, sizeof it);
@@ -1006,6 +1024,9 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
                                      st.main);
     };
 
+    PinnedBuf row0_host;  // exact wrap across processes: row 0 of every level on its way from the first slab to the last
+    if (exact_wrap && sh && sh->relay_row0 && (rc = row0_host.alloc((size_t)(K + 1) * row_bytes))) return rc;
+
     // ---- one pass: `kk` iteration levels over the whole cube ------------------------------------------------------------
     bool d_form = fista;
     double tk_prev = 0.0;
@@ -1031,6 +1052,16 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
         // uploaded -- the level-0 rows of recon are device copies of the data-term rows, those of the state copies of a plane
         // of zeros -- so the host arrays they will come down into need not exist yet.
         const bool first = n_passes == 0;
+        if (sh && sh->before_pass && !first) {  // a slab of its own process: the neighbours' new rows into my halo rows
+            const int rcb = sh->before_pass();
+            if (rcb) return rcb;
+        }
+        // exact Jia-Zhao wrap across processes: the slab that owns row 0 sends row 0 of every level to the one that owns the
+        // top face, once per pass (hooks of the caller; a slab in between has nothing to do with it)
+        const bool relay_send = exact_wrap && sh && sh->relay_row0 && sh->g0 == 0 && sh->g1 < N0;
+        const bool relay_recv = exact_wrap && sh && sh->relay_row0 && sh->g1 == N0 && sh->g0 > 0;
+        int planes_ready = 0;
+        bool relayed = false;
         // rows of the (virtual) cube this pass works on, and what each level can reach at an artificial face
         // (an artificial face -- the wrap of a periodic run, the face between two slabs -- gives up a row per level; a slab
         // whose halo would reach beyond a Jia-Zhao cube's own face stops at that face, which then is a real one)
@@ -1045,7 +1076,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
 
         // The host rows among the virtual rows [v0, v1) -> consecutive rows of a box, run by run: a run ends where the next
         // row is resident, where the cube wraps and where `contiguous(g, g + 1)` says the host memory is not in one piece.
-        auto up_rows = [&](char *box, int64_t v0, int64_t v1, const std::function<char *(int64_t)> &src_row,
+        auto up_rows = [&](char *box, int64_t v0, int64_t v1, const std::function<char *(int64_t, int64_t)> &src_row,
                            const std::function<bool(int64_t)> &joins_next) -> int {
             int64_t slot = 0;
             for (int64_t v = v0; v < v1;) {
@@ -1056,7 +1087,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
                 }
                 int64_t n = 1;
                 while (v + n < v1 && g + n < N0 && !resident(g + n) && joins_next(g + n - 1)) ++n;
-                TVDN_HIP(hipMemcpyAsync(box + (size_t)slot * row_bytes, src_row(g), (size_t)n * row_bytes, hipMemcpyHostToDevice, st.up));
+                TVDN_HIP(hipMemcpyAsync(box + (size_t)slot * row_bytes, src_row(g, v), (size_t)n * row_bytes, hipMemcpyHostToDevice, st.up));
                 bytes_up += n * (int64_t)row_bytes;
                 slot += n;
                 v += n;
@@ -1079,21 +1110,22 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
                 return std::function<bool(int64_t)>([&ha](int64_t) { (void)ha; return true; });
             };
             int i = 0;
-            if ((rcu = up_rows(inbox[h][i++], u0, u1, [&](int64_t g) { return host_row(orig_h, g); }, joins(orig_h)))) return rcu;
+            if ((rcu = up_rows(inbox[h][i++], u0, u1, [&](int64_t g, int64_t v) { return hrow(orig_h, g, v); }, joins(orig_h)))) return rcu;
             if (!first) {
                 if ((rcu = wait_recon(h_old))) return rcu;
-                if ((rcu = up_rows(inbox[h][i++], u0, u1, [&](int64_t g) { return recon_row(h_old, g); }, joins(recon_h)))) return rcu;
+                const HostArr &ro = (two_sets && h_old) ? recon2_h : recon_h;
+                if ((rcu = up_rows(inbox[h][i++], u0, u1, [&](int64_t g, int64_t v) { return hrow(ro, g, v); }, joins(recon_h)))) return rcu;
                 for (int q = 0; q < nd; ++q)
                     for (int s = 0; s < n_in_state; ++s) {
                         const int arr = q * n_state + s;
-                        if ((rcu = up_rows(inbox[h][i++], u0, u1, [&](int64_t g) { return sb[h_old].row(arr, rm.host_below(g)); },
+                        if ((rcu = up_rows(inbox[h][i++], u0, u1, [&](int64_t g, int64_t v) { return srow(h_old, arr, g, v); },
                                            [&](int64_t g) { return sb[h_old].block_of(rm.host_below(g)) == sb[h_old].block_of(rm.host_below(g + 1)); })))
                             return rcu;
                     }
             } else {
                 i += 1 + nd * n_in_state;
             }
-            if (want_mse && (rcu = up_rows(inbox[h][i++], u0, u1, [&](int64_t g) { return host_row(ref_h, g); }, joins(ref_h)))) return rcu;
+            if (want_mse && (rcu = up_rows(inbox[h][i++], u0, u1, [&](int64_t g, int64_t v) { return hrow(ref_h, g, v); }, joins(ref_h)))) return rcu;
             TVDN_HIP(hipEventRecord(in_ready[h], st.up));
             return TVDN_OK;
         };
@@ -1139,8 +1171,10 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
                 if (want_mse) scatter(Fw, -1, i++, false, false);
                 rc2 = copy_rows(cdst, csrc, row_bytes, st.main);
                 if (rc2) return rc2;
-                if (exact_wrap && u0 == G0)
+                if (exact_wrap && u0 <= G0 && G0 < u1) {
                     TVDN_HIP(hipMemcpyAsync(row0[0], Rw[0].row(G0), row_bytes, hipMemcpyDeviceToDevice, st.main));
+                    planes_ready = 1;
+                }
                 if (want_mse && first)  // MSE[0]: the input against the reference (cyTVDN.py:124-125), own rows
                     for (int64_t g = std::max(u0, own0); g < std::min(u1, own1); ++g)
                         if ((rc2 = sse_row(Rw[0].row(g), Fw.row(g), 0, g - KX))) return rc2;
@@ -1153,6 +1187,16 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
             for (int j = 0; j < kk; ++j) {
                 const int64_t lo = std::max(lo_bound(j + 1), E0 + c * R - (j + 1)), hi = std::min(hi_bound(j + 1), E0 + (c + 1) * R - (j + 1));
                 if (lo >= hi) continue;
+                if (relay_recv && !relayed && hi == G1) {  // my first sweep at the cube's top face: row 0 of every level, from its owner
+                    int rcr = sh->relay_row0(0, row0_host.p, kk);
+                    if (rcr) {
+                        set_error("the row-0 relay of a slab run failed (status %d)", rcr);
+                        return TVDN_ERR_INVALID;
+                    }
+                    for (int q = 0; q < kk; ++q)
+                        TVDN_HIP(hipMemcpyAsync(row0[(size_t)q], row0_host.p + (size_t)q * row_bytes, row_bytes, hipMemcpyHostToDevice, st.main));
+                    relayed = true;
+                }
                 it.mode = modes[j];
                 it.tk = modes[j] == TVDN_ITER_FISTA_D ? ratios[j] : 0.0;
                 it.tk_prev = tkp[j];
@@ -1185,8 +1229,21 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
                         for (int64_t g = p0; g < p1; ++g)
                             if ((rc2 = sse_row(Fw.row(g), Rw[j + 1].row(g), done + j + 1, g - KX))) return rc2;
                 }
-                if (exact_wrap && lo == G0)
+                if (exact_wrap && lo == G0) {
                     TVDN_HIP(hipMemcpyAsync(row0[j + 1], Rw[j + 1].row(G0), row_bytes, hipMemcpyDeviceToDevice, st.main));
+                    planes_ready = j + 2;
+                }
+            }
+            if (relay_send && !relayed && planes_ready >= kk) {  // planes 0 .. kk-1 are what the top face's sweeps read
+                for (int q = 0; q < kk; ++q)
+                    TVDN_HIP(hipMemcpyAsync(row0_host.p + (size_t)q * row_bytes, row0[(size_t)q], row_bytes, hipMemcpyDeviceToHost, st.main));
+                TVDN_HIP(hipStreamSynchronize(st.main));
+                const int rcr = sh->relay_row0(1, row0_host.p, kk);
+                if (rcr) {
+                    set_error("the row-0 relay of a slab run failed (status %d)", rcr);
+                    return TVDN_ERR_INVALID;
+                }
+                relayed = true;
             }
             // rows that have reached the last level go home: resident rows into the store (device copies, in the same launch
             // as the gather of the others into the out box), the others across PCIe.  [lo, hi) are rows of the cube proper.
@@ -1233,10 +1290,10 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
                         while (g + n < hi - KX && !resident(g + n) && sb[h_new].block_of(hs + n) == sb[h_new].block_of(hs)) ++n;
                         const size_t boff = (size_t)slot * row_bytes, len = (size_t)n * row_bytes;
                         i = 0;
-                        TVDN_HIP(hipMemcpyAsync(host_row(rh, g), outbox[h][i++] + boff, len, hipMemcpyDeviceToHost, st.down));
+                        TVDN_HIP(hipMemcpyAsync(hrow(rh, g, g + KX), outbox[h][i++] + boff, len, hipMemcpyDeviceToHost, st.down));
                         for (int q = 0; q < nd; ++q)
                             for (int s = 0; s < n_out_state; ++s)
-                                TVDN_HIP(hipMemcpyAsync(sb[h_new].row(q * n_state + s, hs), outbox[h][i++] + boff, len, hipMemcpyDeviceToHost, st.down));
+                                TVDN_HIP(hipMemcpyAsync(srow(h_new, q * n_state + s, g, g + KX), outbox[h][i++] + boff, len, hipMemcpyDeviceToHost, st.down));
                         bytes_down += (int64_t)len * (1 + (int64_t)n_out_state * nd);
                         slot += n;
                         g += n;
@@ -1593,7 +1650,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
     for (int i = a->n_fista; i < n_total; ++i) ratios[i] = NAN;
     int ran = 0, ran_phase[2] = {a->n_fista, a->n_plain};
     auto meet = [&]() -> int {  // slabs of a device-list run: every pass ends at the barrier (a failed slab releases the others)
-        if (!sh) return TVDN_OK;
+        if (!sh || !sh->barrier) return TVDN_OK;
         const int rcb = sh->barrier->arrive_and_wait();
         if (rcb) set_error("another slab of this run failed: %s", sh->barrier->msg.c_str());
         return rcb;
@@ -1601,7 +1658,13 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
     auto stop_after = [&](int slot, bool &stop) -> int {
         double s3[3];
         TVDN_HIP(hipMemcpy(s3, (double *)sums_d.p + 3 * (size_t)slot, sizeof s3, hipMemcpyDeviceToHost));
-        if (sh) {  // the global criterion: the sums of every slab (written between two meetings, read between the next two)
+        if (sh && sh->allreduce) {  // a slab of its own process: the caller adds the slabs up
+            const int rca = sh->allreduce(s3);
+            if (rca) {
+                set_error("the all-reduce hook of a slab run failed (status %d)", rca);
+                return TVDN_ERR_INVALID;
+            }
+        } else if (sh) {  // the global criterion: the sums of every slab (written between two meetings, read between the next two)
             for (int j = 0; j < 3; ++j) sh->stop_sums[3 * sh->index + j] = s3[j];
             int rcb = meet();
             if (rcb) return rcb;
@@ -1711,7 +1774,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
         g = e;
     }
     if (sh) {
-        *sh->last_set = h_old;  // the coordinator brings the result home (run_streamed_slabs)
+        if (sh->last_set) *sh->last_set = h_old;  // the coordinator brings the result home (run_streamed_slabs / run_streamed_rank)
     } else if (HR > 0) {
         const HostArr &last = (periodic && h_old == 1) ? recon2_h : recon_h;  // periodic: the set the last pass wrote
         if (last.owned) pack_host_rows(last.p, (char *)a->recon_out, false);
@@ -1959,6 +2022,109 @@ int run_streamed_slabs(const tvdn_run_args *a, int64_t R, int64_t K)
         o.loop_s = std::chrono::duration<double>(t_done - t_threads).count();
         o.total_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     }
+    return TVDN_OK;
+}
+
+// ---- one slab of a multi-process streamed run (tvdn_slab_io) ---------------------------------------------------------------
+// The process-per-GPU form of run_streamed_slabs: this process holds ITS slab's state in page-locked arrays of halo + own +
+// halo rows (halo = the depth of a pass), streams it through its device with the same drained passes, and between passes the
+// caller's `exchange` hook refreshes the halo rows from the neighbours (cytvdn_amd/distributed.py does it with
+// torch.distributed: RCCL or gloo).  The state is updated in place: a pass writes its own rows k rows behind where it reads.
+int run_streamed_rank(const tvdn_run_args *a, int64_t R, int64_t K)
+{
+    const tvdn_slab_io *io = a->slab;
+    const int nd = a->ndim;
+    const size_t item = a->dtype == TVDN_F32 ? 4 : 8;
+    size_t plane = 1;
+    for (int i = 1; i < nd; ++i) plane *= (size_t)a->shape[i];
+    const size_t row_bytes = plane * item;
+    const int64_t own = a->shape[0], N0 = io->global_rows;
+    const int n_total = a->n_fista + a->n_plain;
+    const int n_state = a->n_fista > 0 ? 2 : 1;
+    const bool want_mse = a->mse_out != nullptr && a->reference != nullptr;
+    const bool periodic = a->bc_mode == TVDN_BC_PERIODIC;
+    TVDN_REQUIRE(io->world >= 2 && io->rank >= 0 && io->rank < io->world, "tvdn_slab_io: rank %d of %d", io->rank, io->world);
+    TVDN_REQUIRE(io->exchange != nullptr, "tvdn_slab_io.exchange is NULL");
+    TVDN_REQUIRE(!a->use_stop || io->allreduce != nullptr, "tvdn_slab_io.allreduce is NULL (needed with use_stop)");
+    TVDN_REQUIRE(own >= 1 && io->row0 >= 0 && io->row0 + own <= N0, "slab rows [%lld, %lld) are not inside the cube's %lld rows",
+                 (long long)io->row0, (long long)(io->row0 + own), (long long)N0);
+    TVDN_REQUIRE(!(io->first_row_nonfinite && !periodic) || io->relay_row0 != nullptr, "tvdn_slab_io.relay_row0 is NULL (needed when the first row is not finite)");
+    if (n_total == 0) {
+        if (a->recon_out != a->data) std::memmove(a->recon_out, a->data, (size_t)own * row_bytes);
+        if (a->iters_run) *a->iters_run = 0;
+        if (a->phase_iters) a->phase_iters[0] = a->phase_iters[1] = 0;
+        return TVDN_OK;
+    }
+    // the depth run_streamed will settle on (its own arithmetic: clamp, number of passes, equal depths) = the halo rows kept
+    int64_t kc = a->use_stop ? 1 : std::min<int64_t>({K, (int64_t)n_total, N0});
+    if (!a->use_stop) {
+        const int64_t n_pass = (n_total + kc - 1) / kc;
+        kc = n_total / n_pass + (n_total % n_pass ? 1 : 0);
+    }
+    TVDN_REQUIRE(kc <= own, "a pass of %lld levels needs %lld rows of the neighbour's state, this slab owns %lld: stream_k must not exceed the "
+                 "smallest slab's rows", (long long)kc, (long long)kc, (long long)own);
+    const int64_t local_rows = own + 2 * kc;
+    const size_t local_bytes = (size_t)local_rows * row_bytes, own_off = (size_t)kc * row_bytes, own_bytes = (size_t)own * row_bytes;
+    {
+        const double need = (double)(2 + nd * n_state + (want_mse ? 1 : 0)) * (double)local_bytes;
+        const size_t avail = host_available_bytes();
+        if (avail == 0 || need > 0.8 * (double)avail) {
+            set_error("this slab's state needs %.0f bytes of page-locked host memory, which exceeds what the host has available (%zu bytes, "
+                      "of which 80 %% are used at most; every rank on this host asks for its own)", need, avail);
+            return TVDN_ERR_UNSUPPORTED;
+        }
+    }
+    PinnedBuf orig, recon, ref;
+    std::unique_ptr<PinnedBuf[]> state(new PinnedBuf[(size_t)nd * n_state]);
+    int rc;
+    if ((rc = orig.alloc(local_bytes)) || (rc = recon.alloc(local_bytes))) return rc;
+    for (int i = 0; i < nd * n_state; ++i)
+        if ((rc = state[(size_t)i].alloc(local_bytes))) return rc;
+    parallel_copy(orig.p + own_off, a->data, own_bytes);
+    if (want_mse) {
+        if ((rc = ref.alloc(local_bytes))) return rc;
+        parallel_copy(ref.p + own_off, a->reference, own_bytes);
+    }
+    {   // the data term's halo rows: once
+        void *arr[1] = {orig.p};
+        if (io->exchange(io->user, 1, arr, local_rows, kc, kc + own, (int32_t)kc, (int64_t)row_bytes)) {
+            set_error("the exchange hook of a slab run failed (data term)");
+            return TVDN_ERR_INVALID;
+        }
+    }
+    SlabShare sh;
+    sh.index = 0;
+    sh.count = 1;
+    sh.g0 = io->row0;
+    sh.g1 = io->row0 + own;
+    sh.orig = orig.p;
+    sh.ref = want_mse ? ref.p : nullptr;
+    sh.recon[0] = sh.recon[1] = recon.p;
+    for (int i = 0; i < nd * n_state; ++i) sh.state[0][i] = sh.state[1][i] = state[(size_t)i].p;
+    sh.first_new = 0;
+    sh.local_rows = true;
+    sh.local_v0 = io->row0;  // virtual row = K + global row, the local arrays start K rows below the first own row
+    sh.exact_wrap = !periodic && io->first_row_nonfinite != 0;
+    std::vector<void *> swap_arrays;
+    swap_arrays.push_back(recon.p);
+    for (int i = 0; i < nd * n_state; ++i) swap_arrays.push_back(state[(size_t)i].p);
+    sh.before_pass = [&]() -> int {
+        if (io->exchange(io->user, (int32_t)swap_arrays.size(), swap_arrays.data(), local_rows, kc, kc + own, (int32_t)kc, (int64_t)row_bytes)) {
+            set_error("the exchange hook of a slab run failed");
+            return TVDN_ERR_INVALID;
+        }
+        return TVDN_OK;
+    };
+    if (io->allreduce) sh.allreduce = [&](double *s3) { return io->allreduce(io->user, s3); };
+    if (io->relay_row0) sh.relay_row0 = [&](int send, void *planes, int n) { return io->relay_row0(io->user, send, planes, n, (int64_t)row_bytes); };
+    tvdn_run_args x = *a;
+    x.shape[0] = N0;  // run_streamed sees the cube; its rows outside this slab's halo are never addressed
+    x.stream_resident = 0;
+    x.n_devices = 0;
+    x.slab = nullptr;
+    rc = run_streamed(&x, R, K, 0, &sh);
+    if (rc) return rc;
+    parallel_copy(a->recon_out, recon.p + own_off, own_bytes);
     return TVDN_OK;
 }
 

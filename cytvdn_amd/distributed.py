@@ -31,9 +31,10 @@ def denoise_slabs(my_rows, global_shape, mu, iterations=10, FISTA=True, stopping
     `lam` defaults and the stopping rule follow cyTVDN/cyTVDN.py:67-68 / :294-295, :99-108, :189-195.
 
     `staged=(rows, k)` keeps each rank's slab in pinned host memory and streams it through the GPU, k iterations
-    per PCIe round trip (cytvdn_amd/wavefront.py; cytvdn_amd/outofcore.py when a stopping rule needs a decision
-    every iteration, or with `staged=(rows, k, "trapezoid")`): for cubes whose state exceeds the HBM of the GPUs
-    at hand (BASELINE config 5).  Without it the slab must fit in HBM."""
+    per PCIe round trip -- the library's streamed loop (tvdn_run with a tvdn_slab_io, csrc/tvdn_stream.hip), which
+    calls back here for the k rows of state it swaps with its neighbours per pass, the sums and the wrap row; with a
+    stopping rule one iteration per pass.  For cubes whose state exceeds the HBM of the GPUs at hand (BASELINE
+    config 5).  Without it the slab must fit in HBM."""
     import torch.distributed as dist
     if not dist.is_initialized():
         raise RuntimeError("initialise torch.distributed first (backend 'nccl' = RCCL on ROCm)")
@@ -137,60 +138,156 @@ def denoise_slabs(my_rows, global_shape, mu, iterations=10, FISTA=True, stopping
     return (own if is_t and my_rows.is_cuda else own.cpu().numpy()), b_norm, delta
 
 
+class _RankHooks:
+    """What crosses process boundaries in a multi-process streamed run (tvdn_slab_io): the library calls these on the calling
+    thread, at the same points of its schedule on every rank.  gloo moves host memory directly; RCCL stages rows through HBM."""
+
+    def __init__(self, dist, group, rank, world, device, periodic):
+        self.dist, self.group, self.rank, self.world = dist, group, rank, world
+        self.via_dev = dist.get_backend(group) != "gloo"
+        self.cuda = torch.device("cuda", device)
+        self.peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+        ring = periodic and world > 1
+        self.left = (rank - 1) % world if (rank > 0 or ring) else None
+        self.right = (rank + 1) % world if (rank < world - 1 or ring) else None
+        self._relay_work = self._relay_buf = None
+        self.error = None
+
+    @staticmethod
+    def _view(ptr, rows, row_bytes):
+        import ctypes as C
+        raw = np.ctypeslib.as_array(C.cast(C.c_void_p(ptr), C.POINTER(C.c_uint8)), shape=(int(rows) * int(row_bytes),))
+        return torch.from_numpy(raw).view(int(rows), int(row_bytes))
+
+    def _snd(self, t):
+        return t.to(self.cuda) if self.via_dev else t.contiguous()
+
+    def _shift(self, views, take, put, to, frm, tag0):
+        """Everybody sends rows `take` of every array to `to` and receives rows `put` from `frm` (either may be None)."""
+        dist, ops, post = self.dist, [], []
+        for i, t in enumerate(views):
+            if to is not None:
+                ops.append(dist.P2POp(dist.isend, self._snd(t[take]), self.peer(to), self.group, tag=tag0 + 4 * i))
+            if frm is not None:
+                dst = t[put]
+                buf = torch.empty(dst.shape, dtype=dst.dtype, device=self.cuda) if self.via_dev else dst
+                if self.via_dev:
+                    post.append((dst, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, self.peer(frm), self.group, tag=tag0 + 4 * i))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for dst, buf in post:
+            dst.copy_(buf)
+
+    def exchange(self, _user, n, arrays, rows_per, lo, hi, depth, row_bytes):
+        try:
+            views = [self._view(arrays[i], rows_per, row_bytes) for i in range(n)]
+            d = int(depth)
+            # two uniform shifts (no chain of dependent messages): up -- my highest own rows become the right neighbour's low
+            # halo rows --, then down
+            self._shift(views, slice(hi - d, hi), slice(lo - d, lo), self.right, self.left, 2)
+            self._shift(views, slice(lo, lo + d), slice(hi, hi + d), self.left, self.right, 1)
+            return 0
+        except Exception as e:          # never through the C frames: the library turns the status into its own error
+            self.error = e
+            return 1
+
+    def allreduce(self, _user, sums3):
+        try:
+            t = torch.tensor([sums3[0], sums3[1], sums3[2]], dtype=torch.float64)
+            if self.via_dev:
+                t = t.to(self.cuda)
+            self.dist.all_reduce(t, group=self.group)
+            t = t.cpu()
+            for j in range(3):
+                sums3[j] = float(t[j])
+            return 0
+        except Exception as e:
+            self.error = e
+            return 1
+
+    def relay_row0(self, _user, send, planes, n, row_bytes):
+        """Row 0 of every level of a pass, from the rank that owns it to the rank that owns the cube's top face."""
+        try:
+            v = self._view(planes, n, row_bytes)
+            if send:
+                if self._relay_work is not None:
+                    self._relay_work.wait()
+                self._relay_buf = self._snd(v).clone()
+                self._relay_work = self.dist.isend(self._relay_buf, self.peer(self.world - 1), group=self.group, tag=1000)
+            else:
+                buf = torch.empty(v.shape, dtype=v.dtype, device=self.cuda) if self.via_dev else v
+                self.dist.recv(buf, self.peer(0), group=self.group, tag=1000)
+                if self.via_dev:
+                    v.copy_(buf)
+            return 0
+        except Exception as e:
+            self.error = e
+            return 1
+
+    def finish(self):
+        if self._relay_work is not None:
+            self._relay_work.wait()
+            self._relay_work = self._relay_buf = None
+
+
 def _denoise_slabs_staged(my_rows, lay, dtype, mu, lam, FISTA, unacc, n_f, n_p, stop, group, device, staged, rank, world,
                           exact_wrap=False):
-    from .outofcore import StagedRunner
-    from .wavefront import WavefrontRunner
-    rows, k = int(staged[0]), int(staged[1])
+    """Every rank streams ITS slab through its GPU from its own page-locked host memory with the library's streamed loop
+    (tvdn_run with tvdn_run_args.slab, csrc/tvdn_stream.hip run_streamed_rank); between the passes the hooks above refresh
+    the k halo rows of recon and of the accumulator state from the neighbours."""
+    import ctypes as C
+    import torch.distributed as dist
+    from . import _lib
+    rows, k = max(1, int(staged[0])), max(1, int(staged[1]))
     n = n_f + n_p
     own = my_rows.cpu().numpy() if isinstance(my_rows, torch.Tensor) else np.ascontiguousarray(my_rows)
-    # every rank keeps its slab's state (plus k halo rows per side) page-locked: refuse what this host cannot hold for
-    # the ranks it runs, before anything is allocated
-    from .planner import check_host_fits
     nd = own.ndim
-    per_rank = (3 + 2 * nd * (2 if FISTA else 1)) * (own.shape[0] + 2 * k) * int(np.prod(own.shape[1:])) * own.dtype.itemsize
-    check_host_fits(dict(mode="slabs+staged", k=k, host_bytes_per_rank=per_rank),
-                    ranks_on_host=int(os.environ.get("LOCAL_WORLD_SIZE", world)))
-    if stop is None and lay.bc_mode == 2 and not (len(staged) > 2 and staged[2] == "trapezoid"):
-        # no per-iteration host decision: the wavefront schedule (every row of every level swept once)
-        wr = WavefrontRunner(own, FISTA, 1.0 / lam, (lam / mu).astype(dtype), device=device, chunk_rows=rows,
-                             k=min(k, lay.own_rows), max_iters=n, global_rows=lay.shape[0], row0=lay.g0, group=group,
-                             world=world, rank=rank, exact_wrap=exact_wrap)
-        wr.run(n_f if FISTA else 0, n_p if unacc else 0)
-        sums = wr.sums()[:n]
-        with np.errstate(divide="ignore", invalid="ignore"):
-            return wr.recon(), sums[:, 0].astype(dtype), (sums[:, 1].astype(dtype) / sums[:, 2].astype(dtype)).astype(dtype)
-    if exact_wrap:
-        # the trapezoid engine across ranks closes the wrap with the constant zero, which is what upstream computes only
-        # while the cube's first row is finite (anisotropic.pyx:65-73): say so instead of returning other numbers
-        raise NotImplementedError("staged slabs with a stopping rule (or the trapezoid engine) on a cube whose first row "
-                                  "holds Inf/NaN: run without the stopping rule (wavefront engine, exact) or in-core slabs")
-    if stop is not None:
-        k = 1
-    sr = StagedRunner(own, FISTA, 1.0 / lam, (lam / mu).astype(dtype), bc_mode=lay.bc_mode, device=device,
-                      block_rows=rows, k=min(k, lay.own_rows), max_iters=n, global_rows=lay.shape[0], row0=lay.g0,
-                      group=group, world=world, rank=rank)
-    ran = np.zeros(n, dtype=bool)
+    if world == 1:          # nothing crosses a process boundary: the one-device streamed run
+        from .driver import _run_device_list
+        return _run_device_list([int(device)], own, 1.0 / lam, (lam / mu).astype(dtype), n_f if FISTA else 0,
+                                n_p if unacc else 0, stop, None, lay.bc_mode, True, stream=(rows, k))[:3]
+    k = min(k, lay.shape[0] // world)       # a pass reads k rows of the neighbour's state: at most the smallest slab's rows
+    hooks = _RankHooks(dist, group, rank, world, device, lay.bc_mode == 0)
+    io = _lib.SlabIO(global_rows=int(lay.shape[0]), row0=int(lay.g0), rank=int(rank), world=int(world),
+                     first_row_nonfinite=int(bool(exact_wrap)))
+    cb = (_lib.SLAB_EXCHANGE(hooks.exchange), _lib.SLAB_ALLREDUCE(hooks.allreduce), _lib.SLAB_RELAY(hooks.relay_row0))
+    io.exchange, io.allreduce, io.relay_row0 = cb
+    a = _lib.RunArgs(dtype=_lib.dtype_code(dtype), ndim=nd, bc_mode=int(lay.bc_mode), device=int(device),
+                     n_fista=n_f if FISTA else 0, n_plain=n_p if unacc else 0, use_stop=int(stop is not None),
+                     stop=float(stop or 0.0), stream_rows=rows, stream_k=k)
+    for i, v in enumerate(own.shape):
+        a.shape[i] = int(v)
+    lam_inv, lam_mu = 1.0 / lam, (lam / mu).astype(dtype)
+    for q in range(nd):
+        a.clip[q], a.lambda_mu[q] = float(lam_inv[q]), float(lam_mu[q])
+    recon = np.empty_like(own)
+    sums = np.zeros((max(n, 1), 3))
+    phases = (C.c_int32 * 2)(0, 0)
+    a.data, a.recon_out, a.sums_out = own.ctypes.data, recon.ctypes.data, sums.ctypes.data
+    a.phase_iters = C.addressof(phases)
+    a.slab = C.pointer(io)
+    rc = _lib.lib().tvdn_run(C.byref(a))
+    hooks.finish()
+    if hooks.error is not None:
+        raise hooks.error
+    _lib.check(rc)
+    t = torch.from_numpy(sums[:n].copy())
+    if n:
+        if hooks.via_dev:
+            t = t.to(hooks.cuda)
+        dist.all_reduce(t, group=group)          # the traces are global and identical on every rank
+        t = t.cpu()
+    sums = t.numpy()
+    done = np.zeros(n, dtype=bool)
+    done[:phases[0]] = True
+    done[(n_f if FISTA else 0):(n_f if FISTA else 0) + phases[1]] = True
     dt = dtype.type
-
-    def on_ss(first, count):
-        ran[first:first + count] = True
-        if stop is None:
-            return False
-        sm = sr.sums()[first]                     # all-reduced: the same decision on every rank
-        with np.errstate(divide="ignore", invalid="ignore"):
-            return bool(dt(dt(sm[1]) / dt(sm[2])) < stop)
-
-    if FISTA and n_f:
-        sr.run(n_f, 0, on_ss)
-        sr.iters_done = n_f
-    if unacc and n_p:
-        sr.run(0, n_p, on_ss)
-    sums = sr.sums()[:n]
-    b_norm = np.where(ran, sums[:, 0], 0.0).astype(dtype)
+    b_norm = np.where(done, sums[:, 0], 0.0).astype(dtype)
     with np.errstate(divide="ignore", invalid="ignore"):
-        delta = np.where(ran, sums[:, 1].astype(dtype) / sums[:, 2].astype(dtype), dt(0)).astype(dtype)
-    return sr.recon(), b_norm, delta
+        delta = np.where(done, sums[:, 1].astype(dtype) / sums[:, 2].astype(dtype), dt(0)).astype(dtype)
+    return recon, b_norm, delta
 
 
 _VERIFIED = {}

@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from .engine import DEFAULT_STATE, HipBackend, SlabLayout, SlabRunner, hbm_plan
-from .planner import check_host_fits, plan_run
+from .planner import plan_run
 
 try:  # tqdm is what upstream shows (cyTVDN.py:148-152); it is optional here
     from tqdm import tqdm as _tqdm
@@ -145,53 +145,30 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
     if device is None:
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
     # engine choice (cytvdn_amd/planner.py): in-core when the state fits in the free HBM (or in TVDN_HBM_LIMIT),
-    # otherwise streamed from pinned host memory -- wavefront schedule, or trapezoid blocks with k = 1 when a
-    # stopping rule needs a host decision after every iteration.  TVDN_WAVEFRONT / TVDN_STAGED = "rows,k" force one.
+    # otherwise streamed from pinned host memory by the library's own loop (tvdn_run, csrc/tvdn_stream.hip): wavefront
+    # schedule, rows resident in HBM where they fit, chained passes; one iteration per pass when a stopping rule needs a
+    # decision after every iteration.  TVDN_WAVEFRONT / TVDN_STAGED = "rows,k" force the streamed form on a cube that fits.
+    # The library refuses what the host cannot hold before anything is allocated (tvdn_stream_host_need) and switches
+    # the exact wrap on by itself when the first row is not finite.
     stop = stopping_relative_change
-    wf, st = os.environ.get("TVDN_WAVEFRONT"), os.environ.get("TVDN_STAGED")
-    # streamed engines, Jia-Zhao: exact wrap at the cube's top face when the FIRST row is not finite (engine.py)
-    exact_wrap = bool(BC_mode == 2 and not np.isfinite(datacube[:1]).all())
+    forced = os.environ.get("TVDN_WAVEFRONT") or os.environ.get("TVDN_STAGED")
     plan = plan_run(datacube.shape, dtype, FISTA, 1, stop=stop is not None, device=device)
-    if plan["mode"] == "does-not-fit" and not (wf or st):
+    if plan["mode"] == "does-not-fit" and not forced:
         raise MemoryError(f"cube of shape {datacube.shape} cannot be streamed through {_fmt_bytes(plan['hbm_bytes'])} "
                           f"of HBM: {plan['why']}")
-    native = os.environ.get("TVDN_STREAM_ENGINE", "native") == "native"
-    if (wf or st or plan["mode"] in ("wavefront", "trapezoid")) and not native:
-        # the streamed engines keep the whole state page-locked on the host: refuse what the host cannot hold BEFORE
-        # anything is allocated (a host driven out of memory takes every process on it down).  (The library's own streamed
-        # loop makes this check itself, with the rows it keeps resident in HBM taken off: tvdn_stream_host_need.)
-        forced = dict(plan)
-        if plan.get("host_bytes_per_rank") is None:     # engine forced by TVDN_WAVEFRONT / TVDN_STAGED on a cube that fits
-            forced.update(mode="streamed (forced)", k=None,
-                          host_bytes_per_rank=(3 + 2 * nd * (2 if FISTA else 1)) * int(np.prod(datacube.shape)) * dtype.itemsize)
-        check_host_fits(forced)
-    if wf or st or plan["mode"] in ("wavefront", "trapezoid"):
-        # Streamed: ONE engine, the library's own (tvdn_run, csrc/tvdn_stream.hip) -- wavefront schedule, rows resident in HBM
-        # where they fit, chained passes; with a stopping rule one iteration per pass.  TVDN_STREAM_ENGINE=python keeps the
-        # Python-driven schedules (wavefront.py / outofcore.py), which exist for slabs x staging across ranks
-        # (distributed.denoise_slabs(staged=...)) and are tested through this switch.
-        if wf:
-            rows, k = (int(v) for v in wf.split(","))
-        elif st:
-            rows, k = (int(v) for v in st.split(","))
-        elif native:
-            # the library's own plan for this much HBM: chunk height, depth, rows resident (csrc/tvdn_stream.hip choose_stream_shape)
+    if forced or plan["mode"] == "wavefront":
+        if forced:
+            rows, k = (int(v) for v in forced.split(","))
+        else:
+            # the library's own plan for this much HBM: chunk height, depth, rows resident (choose_stream_shape)
             rows, k = _library_stream_plan(datacube, n_fista if FISTA else 0, n_plain if unaccelerated else 0, stop is not None,
                                            reference_data is not None, BC_mode, device, plan["hbm_bytes"])
-        else:
-            rows, k = plan["chunk_rows"], plan["k"]
         rows, k = max(1, rows), max(1, k)
         if not quiet:
             print(f"State exceeds HBM: streaming the cube from pinned host memory, {1 if stop is not None else k} iterations per pass "
                   f"(wavefront schedule, {rows}-row chunks)", flush=True)
-        if native:
-            return _run_device_list([device], datacube, lambdaInv, lam_mu, n_fista if FISTA else 0, n_plain if unaccelerated else 0,
-                                    stop, reference_data, BC_mode, True, stream=(rows, k), out=out)
-        if stop is None and not st:
-            return _run_wavefront((rows, k), datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device,
-                                  BC_mode, reference_data, out, exact_wrap)
-        return _run_staged((rows, 1 if stop is not None else k), datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista,
-                           n_plain, stop, reference_data, BC_mode, quiet, device, out, exact_wrap)
+        return _run_device_list([device], datacube, lambdaInv, lam_mu, n_fista if FISTA else 0, n_plain if unaccelerated else 0,
+                                stop, reference_data, BC_mode, True, stream=(rows, k), out=out)
     if DEFAULT_STATE == "compact" and os.environ.get("TVDN_LOOP", "run") == "run":
         # A NumPy cube that fits: the whole call behind the library's entry point (tvdn_run, csrc/tvdn_run.hip) -- state
         # allocation and placement audition, the loop, stopping rule and MSE trace, and for long-enough Jia-Zhao runs
@@ -398,72 +375,6 @@ def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, sto
         print(f"Stopping condition reached after {int(np.nonzero(done)[0][-1])} iterations, stopping.")
     if reference_data is not None:
         return recon, b_norm, delta_recon, mse.astype(dtype)
-    return recon, b_norm, delta_recon
-
-
-def _run_wavefront(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, device, BC_mode=2,
-                   reference_data=None, out=None, exact_wrap=False):
-    """TVDN_STREAM_ENGINE=python: host-resident state, wavefront schedule driven from Python (cytvdn_amd/wavefront.py) --
-    the building block of slabs x staging across ranks, reachable here so that the tests can hold it against the oracle."""
-    from .wavefront import WavefrontRunner
-    dtype = datacube.dtype
-    n_total = n_fista + n_plain
-    rows, k = plan
-    wr = WavefrontRunner(datacube, FISTA, lambdaInv, lam_mu, device=device, chunk_rows=rows, k=k, max_iters=n_total,
-                         bc_mode=int(BC_mode), reference=reference_data, exact_wrap=exact_wrap)
-    wr.run(n_fista if FISTA else 0, n_plain if unaccelerated else 0)
-    sums = wr.sums()[:n_total] if n_total else np.zeros((0, 3))
-    b_norm = sums[:, 0].astype(dtype)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        delta_recon = (sums[:, 1].astype(dtype) / sums[:, 2].astype(dtype)).astype(dtype)
-    recon = wr.recon()
-    if out is not None:
-        out[...] = recon
-        recon = out
-    if reference_data is not None:
-        return recon, b_norm, delta_recon, wr.mse().astype(dtype)
-    return recon, b_norm, delta_recon
-
-
-def _run_staged(plan, datacube, lambdaInv, lam_mu, FISTA, unaccelerated, n_fista, n_plain, stop, reference_data,
-                BC_mode, quiet, device, out=None, exact_wrap=False):
-    from .outofcore import StagedRunner
-    if BC_mode != 2:
-        raise NotImplementedError("a host-staged run with a stopping rule or reference_data supports BC_mode=2 only")
-    dtype = datacube.dtype
-    n_total = n_fista + n_plain
-    rows, k = plan
-    if not quiet:
-        print(f"State exceeds HBM: staging {rows}-row blocks through pinned host memory, {k} iterations per pass",
-              flush=True)
-    sr = StagedRunner(datacube, FISTA, lambdaInv, lam_mu, bc_mode=int(BC_mode), device=device, block_rows=rows, k=k,
-                      max_iters=n_total, reference=reference_data, exact_wrap=exact_wrap)
-    ran = np.zeros(n_total, dtype=bool)
-
-    def on_ss(first, count):
-        ran[first:first + count] = True
-        if stop is None:
-            return False
-        sm = sr.sums()[first]
-        with np.errstate(divide="ignore", invalid="ignore"):
-            return bool(dtype.type(dtype.type(sm[1]) / dtype.type(sm[2])) < stop)
-
-    if FISTA and n_fista:
-        sr.run(n_fista, 0, on_ss)
-        sr.iters_done = n_fista
-    if unaccelerated and n_plain:
-        sr.run(0, n_plain, on_ss)
-    sums = sr.sums()[:n_total] if n_total else np.zeros((0, 3))
-    b_norm = np.where(ran, sums[:, 0], 0.0).astype(dtype)
-    num, den = sums[:, 1].astype(dtype), sums[:, 2].astype(dtype)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        delta_recon = np.where(ran, num / den, dtype.type(0)).astype(dtype)
-    recon = sr.recon()
-    if out is not None:
-        out[...] = recon
-        recon = out
-    if reference_data is not None:
-        return recon, b_norm, delta_recon, sr.mse().astype(dtype)
     return recon, b_norm, delta_recon
 
 

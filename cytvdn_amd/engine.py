@@ -12,10 +12,10 @@ update with a constant (TVDN_EDGE_ZERO) instead of a message from rank 0.  If ro
 (and the single-slab run here, which wraps for real) gets NaN from Inf - Inf in that accumulator and propagates it
 into the LAST row.  `SlabLayout(..., wrap_row=True)` reproduces that: rank 0 then also sends its first row to the last
 rank every iteration, which forms the wrapped accumulator from it as upstream does (TVDN_EDGE_WRAP).  `denoise_slabs`,
-`denoise3D/4D` (wavefront / staged engines, single process) and `tvdn_run` switch it on by themselves when the first
-row of the input is not finite; `bench.py` and finite data never pay for the extra message.  Staged slabs across ranks
-(`denoise_slabs(staged=...)`, wavefront schedule) relay row 0 of every level of a pass from rank 0 to the last rank
-(outofcore.Row0Relay); with a stopping rule (trapezoid engine across ranks) such a cube is refused.
+`denoise3D/4D` and `tvdn_run` (resident and streamed) switch it on by themselves when the first row of the input is
+not finite; `bench.py` and finite data never pay for the extra message.  Staged slabs across ranks
+(`denoise_slabs(staged=...)`) relay row 0 of every level of a pass from rank 0 to the last rank (tvdn.h, tvdn_slab_io
+relay_row0; csrc/tvdn_stream.hip), with or without a stopping rule.
 
 Pieces
 ------
@@ -188,7 +188,7 @@ class HipBackend:
         if self.nd not in (3, 4):
             raise TypeError("No matching signature found")
         # raises without a GPU: no CPU fallback.  A private context = own reduction scratch, needed when two
-        # backends are driven from two streams at once (cytvdn_amd/outofcore.py)
+        # backends are driven from two streams or threads at once (the audition, driver.py)
         self._private_ctx = bool(private_ctx)
         self.ctx = _lib.new_ctx(self.device) if private_ctx else _lib.ctx(self.device)
         tdt = torch.float32 if self.dtype == np.float32 else torch.float64
@@ -440,30 +440,13 @@ class HipBackend:
         # (profiles/r03_e2e_pipelined.txt), which a process that denoises cube after cube would pay on every call
         return keep
 
-    # -- staging support (cytvdn_amd/outofcore.py): a backend reused for blocks of varying height ----------
-    def set_block(self, rows: int, hi_mode: int):
-        """Use only the first `rows` rows of every array (a contiguous prefix) as the local block."""
-        if not (1 <= rows <= self.orig.shape[0]):
-            raise ValueError("block height out of range")
-        a = self._args
-        a.shape[0] = int(rows)
-        a.row_lo, a.row_hi = 0, int(rows)
-        a.lo_mode, a.hi_mode = _lib.EDGE_BC, int(hi_mode)
-        a.wrap_recon = None                     # TVDN_EDGE_WRAP callers point it at their plane before each step
-
     def set_form(self, d_form: bool, tk_prev: float):
         """Declare what the state arrays hold after an upload: (d_k, d_k-1) pairs or b."""
         if self.state != "compact":
-            raise ValueError("staging uses the compact state")
+            raise ValueError("only the compact state has forms")
         m = self._roles
         m.cur, m.i_d, m.i_prev, m.i_out, m.i_b, m.i_bout = 0, 0, 1, 2, 0, 1
         m.d_form, m.tk_prev = int(bool(d_form)), float(tk_prev)
-
-    def state_tensors(self):
-        """Per axis, the arrays that define the accumulator state right now (upload/download order)."""
-        if self.d_form:
-            return [[S[self.i_d], S[self.i_prev]] for S in self.S]
-        return [[S[self.i_b]] for S in self.S]
 
     def recon_next(self) -> torch.Tensor:
         """The buffer the sweeps of the current iteration write into."""

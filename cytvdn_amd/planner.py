@@ -7,12 +7,13 @@ prints a table; the choice is left to the user.  Here the same sum is done for H
     plan["mode"]      "in-core"            one GPU holds the whole state: one fused sweep per iteration
                       "slabs"              axis 0 cut into plan["n_slabs"] slabs, one GPU each, halo rows over RCCL
                       "wavefront"          one GPU, state in pinned host memory, streamed plan["k"] iterations per
-                                           pass in plan["chunk_rows"]-row chunks (cytvdn_amd/wavefront.py)
-                      "trapezoid"          the same with a decision after every iteration (stopping rule; k = 1)
+                                           pass in plan["chunk_rows"]-row chunks (tvdn_run, csrc/tvdn_stream.hip); with
+                                           a stopping rule k = 1: a decision after every iteration
                       "slabs+wavefront"    every GPU streams its own slab from pinned host memory (BASELINE config 5)
                       "does-not-fit"       not even one chunk window fits
 
-`denoise3D/4D` call it with n_gpus = 1 for their own choice (driver._run); `check_memory` prints it.
+`denoise3D/4D` call it with n_gpus = 1 for the choice between resident and streamed (driver._run); the streamed run's own
+shape -- chunk height, depth, rows kept resident in HBM -- is then the library's (tvdn_stream_plan); `check_memory` prints it.
 The HBM figure is the free memory of the device (`torch.cuda.mem_get_info`) unless `hbm_bytes` is given or the
 environment variable TVDN_HBM_LIMIT (bytes; suffixes K/M/G/T = KiB.. allowed, e.g. "48G") caps it -- the knob that
 lets a test, or a cautious user sharing a GPU, drive the automatic out-of-core branch on a small cube.
@@ -124,8 +125,9 @@ def state_arrays(ndim: int, fista: bool) -> int:
 
 
 def wavefront_windows(ndim: int, rows: int, k: int) -> int:
-    """Rows of HBM the wavefront engine keeps resident for chunk height `rows` and depth k (wavefront.py: recon
-    windows for levels 0..k, accumulator windows for levels -1..k per axis, the input window, in/out boxes)."""
+    """Rows of HBM a streamed run keeps resident for chunk height `rows` and depth k with no row of the cube resident
+    (csrc/tvdn_stream.hip: recon rings for levels 0..k, accumulator rings for levels -1..k per axis, the input ring,
+    in/out boxes)."""
     return ((k + 1) + (k + 2) * ndim) * (rows + 2) + (rows + k + 3) + 2 * (3 + 4 * ndim) * rows
 
 
@@ -171,18 +173,6 @@ def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int =
     # streamed from pinned host memory: deepest temporal blocking whose windows fit
     s = max_slabs
     rows_own = -(-n0 // s)
-    if stop:
-        # a stopping rule wants a host decision after every iteration: trapezoid engine, k = 1, three staging buffers
-        per_row = 3 * (n_arr + 1) * plane
-        rows = int(min(STAGING_FRACTION, 0.7) * avail / per_row) - 2     # k = 1 here: block height buys little, keep the slack
-        if rows < 1:
-            out.update(mode="does-not-fit", bytes_per_gpu=per_row * 3, why="not even a one-row block fits")
-            return out
-        out.update(mode="trapezoid" if s == 1 else "slabs+trapezoid", n_slabs=s, chunk_rows=min(rows, rows_own), k=1,
-                   bytes_per_gpu=per_row * (min(rows, rows_own) + 2),
-                   host_bytes_per_rank=(3 + 2 * nd * (2 if FISTA else 1)) * (rows_own + 2) * plane,
-                   why="state exceeds HBM and the stopping rule needs a decision every iteration")
-        return out
     # Depth first: PCIe traffic per iteration falls as 1/k, and a streamed run is PCIe-bound until k ~ 100 (measured on
     # config-2 planes: k 32 -> 36, k 64 -> 55-58, k 128 -> 60 Gvoxel-iters/s).  For every chunk height the deepest k
     # whose level windows fit is taken (the need is linear in k); among those the deepest wins, taller chunks on ties.
@@ -192,7 +182,7 @@ def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int =
         rows = min(rows, max(2, rows_own))
         slope = wavefront_windows(nd, rows, 2) - wavefront_windows(nd, rows, 1)
         k = (budget - wavefront_windows(nd, rows, 0)) // slope if slope > 0 else 0
-        k = int(min(k, MAX_DEPTH, max(1, rows_own)))
+        k = int(min(k, 1 if stop else MAX_DEPTH, max(1, rows_own)))     # a stopping rule decides after every iteration
         if k >= 1 and wavefront_windows(nd, rows, k) <= budget and (best is None or k > best[0]):
             best = (k, rows)
     if best is not None:

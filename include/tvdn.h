@@ -262,6 +262,34 @@ typedef struct tvdn_run_stats {
     double audition_ms[8]; /* probe time per sweep of each candidate, in the order tried                            */
 } tvdn_run_stats;
 
+/* ABI 6.  One slab of a cube that several PROCESSES denoise together, each streaming ITS slab through its GPU from its own
+ * page-locked host memory (BASELINE configs[4] with one process per GPU; cytvdn_amd.distributed.denoise_slabs(staged=...) is
+ * the caller; what replaces the tiling, per-rank load and halo patching of cyTVDN/mpi.py:131-239, :314-434).  With
+ * tvdn_run_args.slab set, shape[0] / data / recon_out / reference describe this slab's OWN rows only, stream_rows / stream_k
+ * must be positive and the same on every slab (stream_k at most the own rows of the smallest slab), and what crosses process
+ * boundaries goes through the hooks below, all called on the calling thread, at the same points of the schedule on every slab.
+ * sums_out / mse_out receive this slab's share (the caller adds the slabs up); bit-identical to the one-process run. */
+typedef struct tvdn_slab_io {
+    int64_t global_rows;  /* rows of the WHOLE cube along axis 0                                                       */
+    int64_t row0;         /* global index of this slab's first own row                                                  */
+    int32_t rank, world;  /* position in the chain (Jia-Zhao) / ring (periodic) of slabs; world >= 2                    */
+    int32_t first_row_nonfinite; /* Jia-Zhao: the cube's first row holds Inf / NaN (the same value on every slab)       */
+    int32_t reserved;
+    /* arrays[i]: a page-locked array of rows_per_array = depth + own + depth rows, own rows at [own_lo, own_hi).  Fill the
+     * `depth` halo rows next to every face this slab shares with a neighbour with that neighbour's outermost `depth` own rows
+     * (and give it mine).  Called once for the data term before the first pass, then before every later pass for recon and
+     * the accumulator state.  Non-zero return aborts the run. */
+    int (*exchange)(void *user, int32_t n_arrays, void *const *arrays, int64_t rows_per_array, int64_t own_lo, int64_t own_hi,
+                    int32_t depth, int64_t row_bytes);
+    /* sums3: one iteration's three sums over this slab -> over all slabs, in place.  Only with use_stop, once per iteration. */
+    int (*allreduce)(void *user, double *sums3);
+    /* Only with first_row_nonfinite: once per pass the first slab calls it with send = 1 and row 0 of every level of the pass
+     * (n_planes contiguous row-planes, page-locked), the last slab with send = 0 before its first sweep at the cube's top face
+     * (the callee fills the planes). */
+    int (*relay_row0)(void *user, int32_t send, void *planes, int32_t n_planes, int64_t row_bytes);
+    void *user;
+} tvdn_slab_io;
+
 typedef struct tvdn_run_args {
     int32_t dtype;
     int32_t ndim;
@@ -328,6 +356,8 @@ typedef struct tvdn_run_args {
      * library weighs depth against kept rows itself); n > 0: that many (at most what fits).  Jia-Zhao runs without an MSE
      * trace; ignored otherwise.  Bit-identical to the resident run whatever the split. */
     int64_t stream_resident;
+    /* ABI 6.  Optional: this call is ONE slab of a multi-process streamed run (struct above). */
+    const tvdn_slab_io *slab;
 } tvdn_run_args;
 
 int tvdn_run(const tvdn_run_args *args);

@@ -166,7 +166,8 @@ def test_struct_layouts_match_the_c_header(tmp_path):
                    '  P(tvdn_iter_args, orig_ring_rows); P(tvdn_iter_args, accumulate);\n'
                    '  printf("tvdn_many_args %zu\\n", sizeof(tvdn_many_args)); P(tvdn_many_args, recon); P(tvdn_many_args, S); P(tvdn_many_args, tk_prev);\n'
                    '  printf("tvdn_run_args %zu\\n", sizeof(tvdn_run_args)); P(tvdn_run_args, stop); P(tvdn_run_args, data); P(tvdn_run_args, devices);\n'
-                   '  P(tvdn_run_args, stream_rows); P(tvdn_run_args, stream_k); P(tvdn_run_args, phase_iters); P(tvdn_run_args, progress_user); P(tvdn_run_args, workspace_bytes); P(tvdn_run_args, n_devices); P(tvdn_run_args, stats); P(tvdn_run_args, stream_resident);\n'
+                   '  P(tvdn_run_args, stream_rows); P(tvdn_run_args, stream_k); P(tvdn_run_args, phase_iters); P(tvdn_run_args, progress_user); P(tvdn_run_args, workspace_bytes); P(tvdn_run_args, n_devices); P(tvdn_run_args, stats); P(tvdn_run_args, stream_resident); P(tvdn_run_args, slab);\n'
+                   '  printf("tvdn_slab_io %zu\\n", sizeof(tvdn_slab_io)); P(tvdn_slab_io, row0); P(tvdn_slab_io, first_row_nonfinite); P(tvdn_slab_io, exchange); P(tvdn_slab_io, relay_row0); P(tvdn_slab_io, user);\n'
                    '  printf("tvdn_run_stats %zu\\n", sizeof(tvdn_run_stats)); P(tvdn_run_stats, resident_rows); P(tvdn_run_stats, d2h_bytes); P(tvdn_run_stats, total_s);\n'
                    '  P(tvdn_run_stats, audition_kept); P(tvdn_run_stats, audition_ms);\n'
                    '  printf("tvdn_plan_out %zu\\n", sizeof(tvdn_plan_out)); P(tvdn_plan_out, fits); P(tvdn_plan_out, min_slabs);\n'
@@ -175,7 +176,7 @@ def test_struct_layouts_match_the_c_header(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
     got = dict(line.rsplit(" ", 1) for line in subprocess.check_output([str(exe)], text=True).splitlines())
     mirrors = {"tvdn_iter_args": _lib.IterArgs, "tvdn_many_args": _lib.ManyArgs, "tvdn_run_args": _lib.RunArgs,
-               "tvdn_plan_out": _lib.PlanOut, "tvdn_run_stats": _lib.RunStats}
+               "tvdn_plan_out": _lib.PlanOut, "tvdn_run_stats": _lib.RunStats, "tvdn_slab_io": _lib.SlabIO}
     for key, val in got.items():
         name, _, field = key.partition(".")
         want = getattr(mirrors[name], field).offset if field else ctypes.sizeof(mirrors[name])

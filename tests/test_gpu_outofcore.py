@@ -1,5 +1,5 @@
-"""Out-of-core (host-staged, temporally blocked) engine against the in-core engine and the oracle:
-bit-identical recon, identical scalar traces, for every mix of block height and iterations-per-pass."""
+"""Out-of-core (host-resident, temporally blocked) runs through denoise3D/4D against the in-core run and the oracle:
+bit-identical recon, identical scalar traces, for every mix of chunk height and iterations-per-pass."""
 import numpy as np
 import pytest
 
@@ -17,13 +17,11 @@ pytestmark = pytest.mark.gpu
     ((9, 2, 5, 7), "float32", 6, True, 2, 8, False),           # halo deeper than the cube: every block is clipped
     ((40, 3, 4, 8), "float32", 11, True, 7, 4, False),
 ])
-@pytest.mark.parametrize("engine", ["native", "python"])
-def test_staged_equals_in_core(oracle, monkeypatch, shape, dtype, its, fista, rows, k, with_ref, engine):
-    """TVDN_STAGED forces a streamed run of these (rows, k): the library's loop, or (TVDN_STREAM_ENGINE=python) the
-    trapezoid engine of outofcore.py, the building block of staged slabs across ranks."""
+def test_staged_equals_in_core(oracle, monkeypatch, shape, dtype, its, fista, rows, k, with_ref):
+    """TVDN_STAGED forces a streamed run of these (rows, k) on a cube that fits: the library's loop (tvdn_run,
+    csrc/tvdn_stream.hip)."""
     import cytvdn_amd as tv
     from cytvdn_amd import synth
-    monkeypatch.setenv("TVDN_STREAM_ENGINE", engine)
     dt = np.dtype(dtype)
     nd = len(shape)
     x = synth.cube(shape, seed=57, dtype=dt) + dt.type(0.25)
@@ -41,11 +39,9 @@ def test_staged_equals_in_core(oracle, monkeypatch, shape, dtype, its, fista, ro
         np.testing.assert_allclose(a, b, rtol=1e-6 if dt == np.float32 else 1e-12)
 
 
-@pytest.mark.parametrize("engine", ["native", "python"])
-def test_staged_early_stop_matches(monkeypatch, engine):
+def test_staged_early_stop_matches(monkeypatch):
     import cytvdn_amd as tv
     from cytvdn_amd import synth
-    monkeypatch.setenv("TVDN_STREAM_ENGINE", engine)
     x = synth.cube((12, 5, 8, 12), seed=14, dtype=np.float32)
     mu = np.array([1.0, 1.0, 0.5, 0.5], np.float32)
     want = tv.denoise4D(x, mu, [30, 6], stopping_relative_change=0.03, quiet=True)
@@ -63,12 +59,10 @@ def test_staged_early_stop_matches(monkeypatch, engine):
     ((15, 3, 4, 8), "float32", 8, True, 1, 5, 0),             # one-row chunks
     ((12, 5, 8, 12), "float32", 6, False, 3, 2, 0),           # unaccelerated
 ])
-@pytest.mark.parametrize("engine", ["native", "python"])
-def test_wavefront_periodic(oracle, monkeypatch, shape, dtype, its, fista, rows, k, bc, engine):
-    """Periodic boundaries beyond HBM, by the library's own streamed loop (csrc/tvdn_stream.hip: virtual cube between k
-    wrapped rows, old and new host state apart) and by the Python-driven engine: the oracle's bits."""
+def test_wavefront_periodic(oracle, monkeypatch, shape, dtype, its, fista, rows, k, bc):
+    """Periodic boundaries beyond HBM, by the library's streamed loop (csrc/tvdn_stream.hip: virtual cube between k
+    wrapped rows, old and new host state apart): the oracle's bits."""
     import cytvdn_amd as tv
-    monkeypatch.setenv("TVDN_STREAM_ENGINE", engine)
     from cytvdn_amd import synth
     dt = np.dtype(dtype)
     nd = len(shape)
@@ -96,12 +90,9 @@ def test_wavefront_periodic(oracle, monkeypatch, shape, dtype, its, fista, rows,
     ((19, 3, 4, 8), "float32", [6, 3], True, 1, 7),           # one-row chunks: rings of three rows per level
     ((13, 5, 12), "float64", 8, True, 1, 4),
 ])
-@pytest.mark.parametrize("engine", ["native", "python"])
-def test_wavefront_equals_in_core(oracle, monkeypatch, shape, dtype, its, fista, rows, k, engine):
+def test_wavefront_equals_in_core(oracle, monkeypatch, shape, dtype, its, fista, rows, k):
     """The wavefront (parallelogram) schedule: every row of every iteration level computed once, still bit-identical
-    (recon and the b_norm / delta_recon / MSE traces) -- driven by the library's own loop (tvdn_run, stream_rows /
-    stream_k) and by cytvdn_amd/wavefront.py."""
-    monkeypatch.setenv("TVDN_STREAM_ENGINE", engine)
+    (recon and the b_norm / delta_recon / MSE traces) -- the library's loop (tvdn_run, stream_rows / stream_k)."""
     import cytvdn_amd as tv
     from cytvdn_amd import synth
     dt = np.dtype(dtype)
@@ -121,19 +112,15 @@ def test_wavefront_equals_in_core(oracle, monkeypatch, shape, dtype, its, fista,
         np.testing.assert_allclose(a, b, rtol=1e-6 if dt == np.float32 else 1e-12)
 
 
-@pytest.mark.parametrize("engine", ["native", "python"])
 @pytest.mark.parametrize("stop", [None, 0.05], ids=["no-stop-rule", "stop-rule"])
-def test_planner_picks_the_streamed_engines_by_itself(oracle, monkeypatch, stop, engine):
+def test_planner_picks_the_streamed_engines_by_itself(oracle, monkeypatch, stop):
     """with the HBM the planner may count on capped (TVDN_HBM_LIMIT) below the 39 MB this cube's state
     needs, denoise4D must choose the out-of-core engine on its own and still return the oracle's bits: the library's
-    streamed loop (tvdn_run with stream_rows / stream_k from tvdn_stream_plan; one iteration per pass with a stopping rule),
-    or with TVDN_STREAM_ENGINE=python the Python-driven schedules (wavefront without, trapezoid blocks with k = 1 with one)."""
+    streamed loop (tvdn_run with stream_rows / stream_k from tvdn_stream_plan; one iteration per pass with a stopping rule)."""
     import cytvdn_amd as tv
     from cytvdn_amd import driver, synth
     calls = []
-    real_wf, real_st, real_dl = driver._run_wavefront, driver._run_staged, driver._run_device_list
-    monkeypatch.setattr(driver, "_run_wavefront", lambda plan, *a, **k: (calls.append(("wavefront", plan)), real_wf(plan, *a, **k))[1])
-    monkeypatch.setattr(driver, "_run_staged", lambda plan, *a, **k: (calls.append(("trapezoid", plan)), real_st(plan, *a, **k))[1])
+    real_dl = driver._run_device_list
 
     def spy(devices, *a, **k):
         if k.get("stream") is not None:
@@ -143,7 +130,6 @@ def test_planner_picks_the_streamed_engines_by_itself(oracle, monkeypatch, stop,
     monkeypatch.setattr(driver, "_run_device_list", spy)
     monkeypatch.delenv("TVDN_WAVEFRONT", raising=False)
     monkeypatch.delenv("TVDN_STAGED", raising=False)
-    monkeypatch.setenv("TVDN_STREAM_ENGINE", engine)
     monkeypatch.setenv("TVDN_HBM_LIMIT", "24M")
     shape, dt = (40, 8, 32, 64), np.dtype(np.float32)
     x = synth.cube(shape, seed=5, dtype=dt) + dt.type(0.25)
@@ -151,11 +137,8 @@ def test_planner_picks_the_streamed_engines_by_itself(oracle, monkeypatch, stop,
     its = [5, 3] if stop is None else 30
     got = tv.denoise4D(x, mu, its, FISTA=True, stopping_relative_change=stop, quiet=True)
     ref = oracle.denoise(x, mu, its, True, stopping_relative_change=stop)
-    want = "library" if engine == "native" else ("wavefront" if stop is None else "trapezoid")
-    assert calls and calls[0][0] == want, calls
+    assert calls and calls[0][0] == "library", calls
     if stop is not None:
-        if engine == "python":
-            assert calls[0][1][1] == 1                               # k = 1: a decision after every iteration
         assert 0 < np.count_nonzero(got[2]) < 30                     # the rule did fire
     assert bits_equal(got[0], ref["recon"])
     assert np.array_equal(got[2] == 0, ref["delta_recon"] == 0)
@@ -164,35 +147,6 @@ def test_planner_picks_the_streamed_engines_by_itself(oracle, monkeypatch, stop,
     monkeypatch.setenv("TVDN_HBM_LIMIT", "4G")
     again = tv.denoise4D(x, mu, its, FISTA=True, stopping_relative_change=stop, quiet=True)
     assert not calls and bits_equal(again[0], got[0])
-
-
-@pytest.mark.parametrize("shape,dtype,bc,rows,k,n_f,n_p", [
-    ((23, 3, 4, 8), "float32", 2, 4, 3, 7, 0),
-    ((23, 3, 4, 8), "float32", 2, 2, 5, 4, 3),        # hybrid: d -> b inside a pass, state arrays change count
-    ((17, 6, 16), "float64", 0, 3, 4, 6, 0),          # periodic: wrapped halo rows at both ends
-    ((9, 2, 5, 7), "float32", 2, 16, 8, 5, 2),        # chunk taller than the cube, k deeper than it
-])
-def test_wavefront_host_state_in_place(oracle, shape, dtype, bc, rows, k, n_f, n_p):
-    """The wavefront engine keeps ONE pinned copy of the state on the host (a pass writes the new state k rows behind
-    where it reads the old one): 10 arrays instead of 19 for 4-D FISTA.  Same bits as with separate old/new arrays."""
-    from cytvdn_amd import synth
-    from cytvdn_amd.wavefront import WavefrontRunner
-    dt = np.dtype(dtype)
-    nd = len(shape)
-    x = synth.cube(shape, seed=71, dtype=dt) + dt.type(0.25)
-    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
-    lam = mu / dt.type(32.0 if nd == 4 else 16.0)
-    got = {}
-    for inplace in (True, False):
-        wr = WavefrontRunner(x, n_f > 0, 1.0 / lam, (lam / mu).astype(dt), device=0, chunk_rows=rows, k=k,
-                             max_iters=n_f + n_p, bc_mode=bc, host_inplace=inplace)
-        assert (wr.recon_h[0] is wr.recon_h[1]) == inplace
-        wr.run(n_f, n_p)
-        got[inplace] = (wr.recon(), wr.sums()[: n_f + n_p])
-    its = [n_f, n_p] if (n_f and n_p) else (n_f or n_p)
-    ref = oracle.denoise(x, mu, its, n_f > 0, BC_mode=bc)
-    assert bits_equal(got[True][0], ref["recon"]) and bits_equal(got[False][0], ref["recon"])
-    np.testing.assert_allclose(got[True][1], got[False][1], rtol=1e-12)
 
 
 def test_planner_counts_what_torchs_cache_holds():

@@ -36,7 +36,7 @@ def test_baseline_configs():
 
 def test_stop_rule_selects_per_iteration_engine():
     p = plan_run((512, 512, 256, 256), "float32", True, 1, hbm_bytes=HBM, stop=True)
-    assert p["mode"] == "trapezoid" and p["k"] == 1 and p["chunk_rows"] >= 1
+    assert p["mode"] == "wavefront" and p["k"] == 1 and p["chunk_rows"] >= 1
     assert plan_run((256, 256, 128, 128), "float32", True, 1, hbm_bytes=HBM, stop=True)["mode"] == "in-core"
 
 
@@ -46,7 +46,8 @@ def test_limit_knob_and_misfits(monkeypatch):
     monkeypatch.setenv("TVDN_HBM_LIMIT", "24M")
     p = plan_run((40, 8, 32, 64), "float32", True, 1)      # 39 MB of state against 24 MB
     assert p["hbm_bytes"] == 24 * 2 ** 20 and p["mode"] == "wavefront" and (p["chunk_rows"], p["k"]) == (2, 9)
-    assert plan_run((40, 8, 32, 64), "float32", True, 1, stop=True)["mode"] == "trapezoid"
+    ps = plan_run((40, 8, 32, 64), "float32", True, 1, stop=True)
+    assert ps["mode"] == "wavefront" and ps["k"] == 1
     monkeypatch.setenv("TVDN_HBM_LIMIT", "1G")
     assert plan_run((40, 8, 32, 64), "float32", True, 1)["mode"] == "in-core"
     monkeypatch.setenv("TVDN_HBM_LIMIT", "64K")

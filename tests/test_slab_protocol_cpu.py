@@ -212,8 +212,61 @@ def test_layout_invariants(n0, world, bc):
             assert l.lo_mode == l.hi_mode == _lib.EDGE_HALO
 
 
-def test_block_and_wavefront_plans():
-    from cytvdn_amd.outofcore import plan_blocks
-    assert plan_blocks(10, 4) == [(0, 4), (4, 8), (8, 10)]
-    assert plan_blocks(3, 8) == [(0, 3)]
-    assert plan_blocks(5, 0) == [(i, i + 1) for i in range(5)]
+def _hooks_worker(rank, world, port, periodic, outdir):
+    """What the library's streamed loop asks of a rank between passes (tvdn.h tvdn_slab_io), driven here by hand over gloo:
+    every rank holds arrays of halo + own + halo rows whose own rows carry (rank, array, row) tags."""
+    import ctypes as C
+    import torch.distributed as dist
+    from cytvdn_amd.distributed import _RankHooks
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        hooks = _RankHooks(dist, None, rank, world, 0, periodic)
+        depth, own, row_bytes, n_arr = 2, 3 + rank, 24, 3
+        lo, hi = depth, depth + own
+        arrs = [np.full((own + 2 * depth, row_bytes), 255, np.uint8) for _ in range(n_arr)]
+        for i, a in enumerate(arrs):
+            for r in range(own):
+                a[lo + r] = 16 * rank + 4 * i + (r % 4)            # a tag per (rank, array, own row mod 4)
+        ptrs = (C.c_void_p * n_arr)(*[a.ctypes.data for a in arrs])
+        assert hooks.exchange(None, n_arr, ptrs, own + 2 * depth, lo, hi, depth, row_bytes) == 0, hooks.error
+        s3 = (C.c_double * 3)(1.0 + rank, 10.0, 0.5 * rank)
+        assert hooks.allreduce(None, s3) == 0, hooks.error
+        planes = np.full((4, row_bytes), 7 + rank, np.uint8)
+        if rank == 0:
+            assert hooks.relay_row0(None, 1, planes.ctypes.data, 4, row_bytes) == 0, hooks.error
+        if rank == world - 1:
+            assert hooks.relay_row0(None, 0, planes.ctypes.data, 4, row_bytes) == 0, hooks.error
+        hooks.finish()
+        np.savez(os.path.join(outdir, f"h{rank}.npz"), arrs=np.stack(arrs), sums=np.array(list(s3)), planes=planes, own=own)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,periodic", [(2, False), (3, False), (3, True), (2, True)])
+def test_streamed_slab_hooks_over_gloo(world, periodic):
+    """The multi-process streamed run's exchange (distributed._RankHooks): after it the low halo rows of every array are the
+    left neighbour's highest own rows and the high halo rows the right neighbour's lowest, rows at the cube's two ends
+    untouched unless the boundary is periodic; the sums are all-reduced; rank 0's wrap planes arrive at the last rank."""
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.start_processes(_hooks_worker, args=(world, _free_port(), periodic, tmp), nprocs=world, join=True, start_method="spawn")
+        out = [np.load(os.path.join(tmp, f"h{r}.npz")) for r in range(world)]
+    d = 2
+    for r in range(world):
+        a, own = out[r]["arrs"], int(out[r]["own"])
+        left = (r - 1) % world if (r > 0 or periodic) else None
+        right = (r + 1) % world if (r < world - 1 or periodic) else None
+        for i in range(3):
+            if left is None:
+                assert (a[i, :d] == 255).all()
+            else:
+                lown = int(out[left]["own"])
+                assert np.array_equal(a[i, :d], out[left]["arrs"][i, d + lown - d:d + lown])
+            if right is None:
+                assert (a[i, d + own:] == 255).all()
+            else:
+                assert np.array_equal(a[i, d + own:], out[right]["arrs"][i, d:2 * d])
+            assert (a[i, d:d + own] // 16 == r).all()                # own rows never written
+        assert np.allclose(out[r]["sums"], [sum(1.0 + q for q in range(world)), 10.0 * world, sum(0.5 * q for q in range(world))])
+    assert (out[world - 1]["planes"] == 7).all()                      # rank 0's planes

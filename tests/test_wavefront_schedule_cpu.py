@@ -1,4 +1,4 @@
-"""The wavefront schedule on paper: a model of what cytvdn_amd/wavefront.py and csrc/tvdn_stream.hip do per chunk -- which
+"""The wavefront schedule on paper: a model of what csrc/tvdn_stream.hip does per chunk -- which
 rows of which iteration level a launch reads and writes, in rings of R+2 rows per level (R+K+3 for the input) -- checked
 for many (rows of the cube, chunk height, depth): every row of every level is produced exactly once, every read finds the
 row it expects still in its ring slot (nothing was overwritten while live), and every row goes home from the last level.

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Config-5-style measurement on ONE GPU: a cube held in pinned host memory, advanced by the staged
-(out-of-core, temporally blocked) engine.  Reported separately from bench.py: this mode is PCIe-bound.
+"""Config-5-style measurement on ONE GPU: a cube in host memory, streamed through the GPU by the C entry point
+(tvdn_run with stream_rows / stream_k, csrc/tvdn_stream.hip).  Reported separately from bench.py's headline: PCIe-bound.
+tools/stream_rates.py is the round-4 form of this measurement (run statistics from the library instead of a parsed line).
 
     python tools/bench_outofcore.py --shape 128x256x128x128 --rows 64 --k 16 --iters 32
 """
@@ -16,7 +17,7 @@ sys.path.insert(0, ROOT)
 
 def _default_host_limit():
     """Unless the caller says otherwise, a measurement may page-lock at most half of what the host has available
-    (TVDN_HOST_LIMIT is honoured by every streamed engine, C++ and Python): a mistyped shape gets an error, not the box."""
+    (TVDN_HOST_LIMIT is honoured by the streamed runs): a mistyped shape gets an error, not the box."""
     if "TVDN_HOST_LIMIT" in os.environ:
         return
     try:
@@ -36,15 +37,12 @@ def main():
     ap.add_argument("--rows", type=int, default=64)
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--iters", type=int, default=32)
-    ap.add_argument("--stages", type=int, default=3)
-    ap.add_argument("--engine", default="trapezoid", choices=["trapezoid", "wavefront", "native"])
+    ap.add_argument("--engine", default="native", choices=["native"], help="kept for old command lines: there is one engine")
     ap.add_argument("--check", action="store_true", help="also run in-core and compare bit for bit")
-    ap.add_argument("--no-inplace", action="store_true", help="wavefront: separate old/new host state (19 arrays, not 10)")
     a = ap.parse_args()
     import numpy as np
     import torch
     from cytvdn_amd import _lib, synth
-    from cytvdn_amd.outofcore import StagedRunner
     shape = tuple(int(v) for v in a.shape.split("x"))
     nd = len(shape)
     dt = np.dtype(np.float32)
@@ -62,7 +60,7 @@ def main():
     t_syn = time.perf_counter() - t0
     mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
     lam = mu / dt.type(32.0 if nd == 4 else 16.0)
-    if a.engine == "native":
+    if True:
         # the C entry point (tvdn_run, stream_rows / stream_k): page-locks x and the result in place, allocates the
         # pinned state, streams, returns.  TVDN_STREAM_TIMING makes the library report set-up and passes apart (stderr).
         import ctypes as C
@@ -102,31 +100,6 @@ def main():
             out["bit_identical_to_in_core"] = bool(want.tobytes() == recon.tobytes())
         print(json.dumps(out))
         return
-    t0 = time.perf_counter()
-    if a.engine == "wavefront":
-        from cytvdn_amd.wavefront import WavefrontRunner
-        sr = WavefrontRunner(x, True, 1.0 / lam, (lam / mu).astype(dt), device=0, chunk_rows=a.rows, k=a.k, max_iters=a.iters,
-                             host_inplace=not a.no_inplace)
-    else:
-        sr = StagedRunner(x, True, 1.0 / lam, (lam / mu).astype(dt), device=0, block_rows=a.rows, k=a.k, max_iters=a.iters, n_stages=a.stages)
-    t_alloc = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    sr.run(a.iters, 0)
-    torch.cuda.synchronize()
-    dt_run = time.perf_counter() - t0
-    vox = float(np.prod(shape))
-    out = {"metric": "Gvoxel-iters/s (4D aniso FISTA, out-of-core single GPU)", "value": round(vox * a.iters / dt_run / 1e9, 3),
-           "unit": "Gvoxel-iters/s", "shape": list(shape), "block_rows": a.rows, "iters_per_pass": a.k, "iters": a.iters, "stages": a.stages, "engine": a.engine,
-           "seconds": round(dt_run, 3), "h2d_GBps": round(sr.bytes_h2d / dt_run / 1e9, 1),
-           "d2h_GBps": round(sr.bytes_d2h / dt_run / 1e9, 1), "h2d_GB": round(sr.bytes_h2d / 1e9, 1),
-           "d2h_GB": round(sr.bytes_d2h / 1e9, 1), "synth_s": round(t_syn, 1), "pin_alloc_s": round(t_alloc, 1),
-           "b_norm_last": float(sr.sums()[a.iters - 1, 0])}
-    if a.check:
-        import cytvdn_amd as tv
-        want = tv.denoise4D(x, mu, a.iters, quiet=True)[0]
-        out["bit_identical_to_in_core"] = bool(want.tobytes() == sr.recon().tobytes())
-    print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Config-5 rehearsal on ONE GPU: N ranks (gloo, all on cuda:0), each with its slab of the cube in pinned host memory,
-streamed through the GPU by the wavefront engine, k rows of state swapped between neighbouring ranks per pass
+streamed through the GPU by the library's own loop, k rows of state swapped between neighbouring ranks per pass
 (`denoise_slabs(..., staged=(rows, k))`).  Reported separately from bench.py: this mode is PCIe-bound and the ranks
 share one GPU and one PCIe link here.
 
@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 
 def _default_host_limit():
     """Unless the caller says otherwise, a measurement may page-lock at most half of what the host has available
-    (TVDN_HOST_LIMIT is honoured by every streamed engine, C++ and Python): a mistyped shape gets an error, not the box."""
+    (TVDN_HOST_LIMIT is honoured by the streamed runs): a mistyped shape gets an error, not the box."""
     if "TVDN_HOST_LIMIT" in os.environ:
         return
     try:
@@ -58,22 +58,16 @@ def worker(rank, world, port, a, q):
     del buf
     mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
     lam = mu / dt.type(32.0 if nd == 4 else 16.0)
-    from cytvdn_amd.wavefront import WavefrontRunner
-    t0 = time.perf_counter()
-    # what distributed.denoise_slabs(..., staged=(rows, k)) builds (cytvdn_amd/distributed.py), timed in two parts
-    wr = WavefrontRunner(own, True, 1.0 / lam, (lam / mu).astype(dt), device=dev, chunk_rows=a.rows, k=min(a.k, g1 - g0),
-                         max_iters=a.iters, global_rows=shape[0], row0=g0, world=world, rank=rank)
-    t_pin = time.perf_counter() - t0
+    from cytvdn_amd.distributed import denoise_slabs
     dist.barrier()
     t0 = time.perf_counter()
-    wr.run(a.iters, 0)
-    torch.cuda.synchronize()
+    # the whole call of every rank: page-locking its slab, the passes of the library's streamed loop (tvdn_run with a
+    # tvdn_slab_io, csrc/tvdn_stream.hip run_streamed_rank) with the k-row state swaps between them, the release
+    recon, b_norm, _ = denoise_slabs(own, shape, mu, a.iters, FISTA=True, lam=lam, device=dev, staged=(a.rows, a.k))
     dist.barrier()
     dt_run = time.perf_counter() - t0
-    sums = wr.sums()
     if rank == 0:
-        q.put({"seconds": round(dt_run, 3), "pin_alloc_s": round(t_pin, 1), "b_norm_last": float(sums[a.iters - 1, 0]),
-               "h2d_GBps_rank0": round(wr.bytes_h2d / dt_run / 1e9, 1), "d2h_GBps_rank0": round(wr.bytes_d2h / dt_run / 1e9, 1)})
+        q.put({"seconds": round(dt_run, 3), "b_norm_last": float(b_norm[a.iters - 1])})
     dist.destroy_process_group()
 
 
