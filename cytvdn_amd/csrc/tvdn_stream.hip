@@ -541,7 +541,7 @@ namespace {
 // (row g is one of them when floor((g+1) res / n0) > floor(g res / n0)), so that every chunk of a pass has the same share of
 // rows that cross PCIe and the transfers of one chunk hide under the sweeps of the one before.  (With the resident rows in
 // one piece at the low end, the rest of a pass is PCIe-bound chunk after chunk while the link idles under the resident ones:
-// 35 Gvoxel-iters/s on config-5 planes where the evenly spread rows give XX; profiles/r04_stream_rates.jsonl.)
+// 35 Gvoxel-iters/s on config-5 planes where the evenly spread rows give 61; profiles/r04_stream_rates.jsonl.)
 struct RowMap {
     int64_t n0 = 1, res = 0;
     int64_t res_below(int64_t g) const { return res >= n0 ? g : g * res / n0; }  // resident rows among [0, g)
@@ -1706,7 +1706,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
             }
             if (can_chain) {
                 if ((rc = chain(all))) return rc;
-                first_pass_s = since(t_passes) / (double)all.size();
+                first_pass_s = 0.0;  // chained passes overlap: none of them can be timed alone
                 if (a->progress) a->progress((int32_t)n_total, a->progress_user);
             } else {
                 for (size_t q = 0; q < all.size(); ++q) {
@@ -1844,6 +1844,8 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
         s.setup_s = std::chrono::duration<double>(t_passes - t_start).count();
         s.loop_s = std::chrono::duration<double>(t_end_passes - t_passes).count();
         s.total_s = since(t_start);
+        s.first_pass_s = first_pass_s;
+        s.first_pass_iters = (int32_t)depth_of_pass(0);
     }
     return TVDN_OK;
 }
@@ -1880,19 +1882,18 @@ int run_streamed_slabs(const tvdn_run_args *a, int64_t R, int64_t K)
         one.device = a->devices[0];
         return run_streamed(&one, R, K, 0);
     }
-    if (!periodic) {  // the exact Jia-Zhao wrap of a non-finite first row needs row 0 of every level on the LAST slab's device
-        bool bad = false;
+    // The exact Jia-Zhao wrap of a non-finite first row (engine.py; upstream's Inf - Inf at the top face) needs row 0 of every
+    // level of a pass on the LAST slab's device: the first slab's thread leaves those planes in a mailbox early in its pass,
+    // the last slab's thread picks them up when its sweeps reach the cube's top face (what tvdn_slab_io.relay_row0 is across
+    // processes).
+    bool exact_wrap = false;
+    if (!periodic) {
         if (a->dtype == TVDN_F32) {
             const float *p0 = (const float *)a->data;
-            for (size_t i = 0; i < plane && !bad; ++i) bad = !std::isfinite(p0[i]);
+            for (size_t i = 0; i < plane && !exact_wrap; ++i) exact_wrap = !std::isfinite(p0[i]);
         } else {
             const double *p0 = (const double *)a->data;
-            for (size_t i = 0; i < plane && !bad; ++i) bad = !std::isfinite(p0[i]);
-        }
-        if (bad) {
-            set_error("the cube's first row holds Inf / NaN: a streamed device list closes the Jia-Zhao wrap with the constant that holds "
-                      "for finite data only; run it resident (more devices), on one device, or with denoise_slabs(staged=...)");
-            return TVDN_ERR_UNSUPPORTED;
+            for (size_t i = 0; i < plane && !exact_wrap; ++i) exact_wrap = !std::isfinite(p0[i]);
         }
     }
     const bool aliased = arrays_overlap(a->data, a->recon_out, cube_bytes);
@@ -1927,6 +1928,8 @@ int run_streamed_slabs(const tvdn_run_args *a, int64_t R, int64_t K)
 
     SlabBarrier bar;
     bar.count = world;
+    std::vector<char> mail;  // row 0 of every level of a pass on its way from the first slab to the last (exact wrap)
+    long mail_sent = 0, mail_taken = 0;
     std::vector<SlabShare> shares((size_t)world);
     std::vector<tvdn_run_args> args((size_t)world, *a);
     std::vector<std::vector<double>> sums((size_t)world, std::vector<double>((size_t)3 * n_total, 0.0));
@@ -1951,6 +1954,26 @@ int run_streamed_slabs(const tvdn_run_args *a, int64_t R, int64_t K)
             for (int i = 0; i < nd * n_state; ++i) sh.state[set][i] = state[(size_t)set * nd * n_state + i].p;
         sh.first_new = first_new;
         sh.barrier = &bar;
+        sh.exact_wrap = exact_wrap;
+        if (exact_wrap && (r == 0 || r == world - 1))
+            sh.relay_row0 = [&bar, &mail, &mail_sent, &mail_taken, row_bytes](int send, void *planes, int n) -> int {
+                std::unique_lock<std::mutex> lk(bar.mu);  // the barrier's lock and wake-ups: a slab that fails ends the wait
+                const size_t bytes = (size_t)n * row_bytes;
+                if (send) {
+                    bar.cv.wait(lk, [&] { return mail_taken == mail_sent || bar.failed; });
+                    if (bar.failed) return 1;
+                    if (mail.size() < bytes) mail.resize(bytes);
+                    std::memcpy(mail.data(), planes, bytes);
+                    ++mail_sent;
+                } else {
+                    bar.cv.wait(lk, [&] { return mail_sent > mail_taken || bar.failed; });
+                    if (bar.failed) return 1;
+                    std::memcpy(planes, mail.data(), bytes);
+                    ++mail_taken;
+                }
+                bar.cv.notify_all();
+                return 0;
+            };
         sh.stop_sums = stop_sums.data();
         sh.last_set = &last_set[(size_t)r];
         tvdn_run_args &x = args[(size_t)r];

@@ -260,6 +260,10 @@ typedef struct tvdn_run_stats {
     int32_t audition_n;    /* resident: placements of the state tried (0 / 1: the first allocation was taken)       */
     int32_t audition_kept; /* index of the one kept                                                                 */
     double audition_ms[8]; /* probe time per sweep of each candidate, in the order tried                            */
+    double first_pass_s;   /* streamed: the first pass alone -- the one the page-locking of the host state runs under
+                              (0 when the passes were chained: they overlap and cannot be told apart)                 */
+    int32_t first_pass_iters; /* ... and the iterations it held                                                     */
+    int32_t reserved;
 } tvdn_run_stats;
 
 /* ABI 6.  One slab of a cube that several PROCESSES denoise together, each streaming ITS slab through its GPU from its own
@@ -319,7 +323,7 @@ typedef struct tvdn_run_args {
      * state of the whole cube lives in page-locked host arrays shared by the slabs (two sets: a pass reads one and writes the
      * other), a slab reads stream_k rows of its neighbours' state beyond each interior face from them and gives up a row per
      * level there, the slabs meet after every pass; sums, stopping rule and MSE trace are global (a cube whose first row
-     * holds Inf / NaN is refused in this form).  A cube whose state the host cannot hold page-locked either is refused
+     * holds Inf / NaN gets the exact wrap here too: row 0 of every level goes from the first slab's thread to the last's).  A cube whose state the host cannot hold page-locked either is refused
      * before any of the caller's arrays is touched.  Both boundary conditions (periodic: the cube is swept between
      * stream_k wrapped rows at either end, and old and new host state are two sets of arrays); with use_stop one iteration per
      * pass.  `data` / `recon_out` / `reference` are page-locked in place for the duration of the call when they are

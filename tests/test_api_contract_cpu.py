@@ -169,7 +169,7 @@ def test_struct_layouts_match_the_c_header(tmp_path):
                    '  P(tvdn_run_args, stream_rows); P(tvdn_run_args, stream_k); P(tvdn_run_args, phase_iters); P(tvdn_run_args, progress_user); P(tvdn_run_args, workspace_bytes); P(tvdn_run_args, n_devices); P(tvdn_run_args, stats); P(tvdn_run_args, stream_resident); P(tvdn_run_args, slab);\n'
                    '  printf("tvdn_slab_io %zu\\n", sizeof(tvdn_slab_io)); P(tvdn_slab_io, row0); P(tvdn_slab_io, first_row_nonfinite); P(tvdn_slab_io, exchange); P(tvdn_slab_io, relay_row0); P(tvdn_slab_io, user);\n'
                    '  printf("tvdn_run_stats %zu\\n", sizeof(tvdn_run_stats)); P(tvdn_run_stats, resident_rows); P(tvdn_run_stats, d2h_bytes); P(tvdn_run_stats, total_s);\n'
-                   '  P(tvdn_run_stats, audition_kept); P(tvdn_run_stats, audition_ms);\n'
+                   '  P(tvdn_run_stats, audition_kept); P(tvdn_run_stats, audition_ms); P(tvdn_run_stats, first_pass_s); P(tvdn_run_stats, first_pass_iters);\n'
                    '  printf("tvdn_plan_out %zu\\n", sizeof(tvdn_plan_out)); P(tvdn_plan_out, fits); P(tvdn_plan_out, min_slabs);\n'
                    '  return 0; }\n')
     exe = tmp_path / "layout"

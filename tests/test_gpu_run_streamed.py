@@ -408,7 +408,7 @@ def test_streamed_device_list(oracle, shape, dtype, n_f, n_p, rows, k, bc, slabs
         np.testing.assert_allclose(got[1][ran, 1], ref["delta64"][ran], rtol=1e-9)
 
 
-def test_streamed_device_list_mse_in_place_and_refusals(oracle):
+def test_streamed_device_list_mse_in_place_and_nonfinite_first_row(oracle):
     from cytvdn_amd import _lib, synth
     dt = np.dtype(np.float32)
     shape = (21, 3, 6, 8)
@@ -434,7 +434,10 @@ def test_streamed_device_list_mse_in_place_and_refusals(oracle):
     ref = _oracle(oracle, x, mu, 7, 0)
     assert bits_equal(buf, ref["recon"])
     _check_traces(sums, ref, 7)
-    # a non-finite first row is refused in this form (the exact wrap would need row 0 of every level on the last device)
+    # a non-finite first row: the exact Jia-Zhao wrap, row 0 of every level handed from the first slab's thread to the last's
     x[0, 1, 2, 3] = np.inf
-    with pytest.raises(NotImplementedError, match="first row"):
-        _run(x, mu, 3, 0, stream=(3, 2), devices=[0, 0])
+    x[0, 2, 1, 5] = np.nan
+    for devs, n_f, n_p, stream, stop in (([0, 0], 5, 0, (3, 2), None), ([0, 0, 0], 4, 3, (2, 3), None), ([0, 0, 0, 0], 6, 0, (2, 4), 1e-9)):
+        got = _run(x, mu, n_f, n_p, stream=stream, devices=devs, stop=stop)
+        ref = _oracle(oracle, x, mu, n_f, n_p, stopping_relative_change=stop)
+        assert np.isnan(ref["recon"][-1]).any() and bits_equal(got[0], ref["recon"]), devs
