@@ -75,11 +75,11 @@ class RunStats(C.Structure):
         ("resident_rows", C.c_int64), ("n_passes", C.c_int64), ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64),
         ("setup_s", C.c_double), ("loop_s", C.c_double), ("total_s", C.c_double),
         ("audition_n", C.c_int32), ("audition_kept", C.c_int32), ("audition_ms", C.c_double * 8),
-        ("first_pass_s", C.c_double), ("first_pass_iters", C.c_int32), ("reserved", C.c_int32),
+        ("first_pass_s", C.c_double), ("first_pass_iters", C.c_int32), ("results_under_last_pass", C.c_int32),
     ]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("audition_ms", "reserved")}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "audition_ms"}
         d["audition_ms"] = [round(v, 4) for v in self.audition_ms[:max(0, min(8, self.audition_n))]]
         return d
 

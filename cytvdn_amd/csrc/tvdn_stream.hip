@@ -26,7 +26,8 @@ namespace tvdn {
 namespace {
 
 constexpr int kHostThreads = 8;
-constexpr size_t kPinInPlaceMin = size_t(256) << 20;  // bytes from which a caller's array is page-locked in place
+constexpr size_t kPinInPlaceMinDefault = size_t(256) << 20;  // bytes from which a caller's array is page-locked in place
+size_t env_bytes(const char *name);
 
 void parallel_copy(void *dst, const void *src, size_t bytes)  // src == nullptr: zero fill
 {
@@ -170,7 +171,8 @@ struct HostArr {
     {
         // Only arrays big enough to own their pages: page-locking works on whole pages, and two small arrays of the
         // caller may share one (overlapping registrations).  Small cubes are staged through pinned copies instead.
-        if (bytes < kPinInPlaceMin) return alloc(packed_bytes);
+        const size_t pin_min = getenv("TVDN_PIN_IN_PLACE_MIN") ? env_bytes("TVDN_PIN_IN_PLACE_MIN") : kPinInPlaceMinDefault;  // (tests lower it)
+        if (bytes < pin_min) return alloc(packed_bytes);
         if (fresh) {
             const uintptr_t lo = ((uintptr_t)user + (size_t(2) << 20) - 1) & ~((uintptr_t)(size_t(2) << 20) - 1);
             const uintptr_t hi = ((uintptr_t)user + bytes) & ~((uintptr_t)(size_t(2) << 20) - 1);
@@ -797,10 +799,10 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
     } mem;
     DevMem sums_d, mse_d;
     mem.device = device;
-    {
-        bool reused = false;
-        TVDN_HIP(state_acquire(&mem.p, dev_bytes, &mem.bytes, device, &reused, true));
-    }
+    const double t_before_block = since(t_start);
+    bool block_reused = false;
+    TVDN_HIP(state_acquire(&mem.p, dev_bytes, &mem.bytes, device, &block_reused, true));
+    const double t_block = since(t_start);
     TVDN_HIP(hipMemsetAsync(mem.p, 0, ring_bytes, st.main));
     char *cursor = (char *)mem.p;
     auto take = [&](size_t b) { char *p = cursor; cursor += b; return p; };
@@ -1331,6 +1333,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
         std::vector<double> tk, tkp; // momentum ratio of the level / of the level before it
         int n_in_state = 1, n_out_state = 1;
         bool first = false;          // starts from recon = data term and zero accumulators: uploads the data term only
+        bool last = false;           // the run ends with this pass (no stopping rule): resident rows send their result straight home
     };
     auto describe = [&](int it0, int kk, const double *rat, PassDesc &pd) -> int {
         pd.it0 = it0;
@@ -1339,6 +1342,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
         pd.tk.resize((size_t)kk);
         pd.tkp.resize((size_t)kk);
         pd.first = n_passes == 0 && it0 == 0;
+        pd.last = !a->use_stop && it0 + kk == n_total;
         bool form = d_form;
         pd.n_in_state = form ? 2 : 1;
         double prev = tk_prev;
@@ -1365,6 +1369,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
     // keep both directions busy all the time, so their downloads are a copy kernel of 8 workgroups writing the page-locked
     // host arrays directly; drained passes keep the runtime's copies.  TVDN_STREAM_DOWN_BLOCKS=n overrides (0: runtime copies).
     int down_blocks = 0;
+    bool recon_direct = false, recon_direct_decided = false;  // the last pass sends the resident rows' results home itself
     auto chain = [&](std::vector<PassDesc> &ps) -> int {
         const int P = (int)ps.size();
         const int64_t V1 = (int64_t)P * N0;  // running rows that are uploaded
@@ -1566,6 +1571,15 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
                 const PassDesc &pd = ps[(size_t)q];
                 const int64_t lo = std::max<int64_t>((int64_t)q * N0, t * R - pd.kk), hi = std::min<int64_t>((int64_t)(q + 1) * N0, (t + 1) * R - pd.kk);
                 if (lo >= hi) continue;
+                // The run's last pass: the state of a resident row is not needed again, and its result can cross PCIe under
+                // the pass (the link has room: a hybrid run uses half of it) instead of in one piece after it -- when the
+                // caller's result array is page-locked in place, i.e. has a place for every row.
+                if (pd.last && RES > 0 && !recon_direct_decided) {
+                    if ((rc2 = wait_recon(0))) return rc2;
+                    recon_direct = recon_h.cube_rows && getenv("TVDN_STREAM_HOME_AFTER") == nullptr;
+                    recon_direct_decided = true;
+                }
+                const bool direct = pd.last && recon_direct;
                 outs.push_back(Out{q, lo - (int64_t)q * N0, hi - (int64_t)q * N0, oslot});
                 for (int64_t v = lo; v < hi; ++v) {
                     const int64_t g = v - (int64_t)q * N0;
@@ -1574,6 +1588,12 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
                         cdst.push_back(res_row ? store_row(i_store, g) : outbox[h][ox] + (size_t)oslot * row_bytes);
                         csrc.push_back(rg.row(v));
                     };
+                    if (res_row && direct) {  // the result only, into the out box like a host row's
+                        cdst.push_back(outbox[h][0] + (size_t)oslot * row_bytes);
+                        csrc.push_back(Rw[(size_t)pd.kk].row(v));
+                        ++oslot;
+                        continue;
+                    }
                     put(1, 0, Rw[(size_t)pd.kk]);
                     for (int qx = 0; qx < nd; ++qx) {
                         put(2 + qx * n_state, ox_state(qx, 0), A(pd.kk, qx));
@@ -1596,9 +1616,22 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
                 std::vector<void *> kd, ks;  // copies of whole rows for the copy kernel (down_blocks > 0)
                 for (const Out &o : outs) {
                     const PassDesc &pd = ps[(size_t)o.q];
+                    const bool direct = pd.last && recon_direct;
                     int64_t slot = o.slot0;
                     for (int64_t g = o.g0; g < o.g1;) {
                         if (resident(g)) {
+                            if (direct) {  // its result went into the out box: one row, straight into the caller's array
+                                char *dst = recon_h.p + (size_t)g * row_bytes;
+                                const char *src = outbox[h][0] + (size_t)slot * row_bytes;
+                                if (down_blocks > 0 && row_bytes % 16 == 0 && ((uintptr_t)dst & 15) == 0) {
+                                    kd.push_back(dst);
+                                    ks.push_back((void *)src);
+                                } else {
+                                    TVDN_HIP(hipMemcpyAsync(dst, src, row_bytes, hipMemcpyDeviceToHost, st.down));
+                                }
+                                bytes_down += (int64_t)row_bytes;
+                                ++slot;
+                            }
                             ++g;
                             continue;
                         }
@@ -1762,7 +1795,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
     // ---- results home -------------------------------------------------------------------------------------------------------
     if (stager.joinable()) stager.join();
     if (pinner.joinable()) pinner.join();
-    for (int64_t g = 0; g < N0 && RES > 0;) {  // resident rows: store -> the caller's array, through the library's pinned lanes
+    for (int64_t g = 0; g < N0 && RES > 0 && !recon_direct;) {  // resident rows: store -> the caller's array, through the library's pinned lanes
         if (!resident(g)) {
             ++g;
             continue;
@@ -1827,6 +1860,10 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
     }
     lap(3);
     if (getenv("TVDN_STREAM_TIMING"))  // measurement aid: set-up apart from the passes
+        fprintf(stderr, "tvdn_run streamed: set-up in detail: context and streams %.3f s, device block of %.1f GiB %s %.3f s, the rest (events, "
+                "helper threads, waiting for the first inputs) %.3f s\n", t_before_block, (double)dev_bytes / 1073741824.0,
+                block_reused ? "reused" : "allocated", t_block - t_before_block, std::chrono::duration<double>(t_passes - t_start).count() - t_block);
+    if (getenv("TVDN_STREAM_TIMING"))
         fprintf(stderr, "tvdn_run streamed: rows %lld k %lld resident rows %lld of %lld, set-up %.3f s, passes %.3f s (first %.3f s), results home %.3f s; "
                 "released: device block %.3f s, sums/streams/context %.3f s, caller's arrays unpinned %.3f s, host state handed to the background %.3f s\n",
                 (long long)R, (long long)K, (long long)RES, (long long)N0, std::chrono::duration<double>(t_passes - t_start).count(),
@@ -1840,12 +1877,13 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
         s.resident_rows = RES;
         s.n_passes = n_passes;
         s.h2d_bytes = bytes_up + RES * (int64_t)row_bytes;
-        s.d2h_bytes = bytes_down + RES * (int64_t)row_bytes;
+        s.d2h_bytes = bytes_down + (recon_direct ? 0 : RES * (int64_t)row_bytes);
         s.setup_s = std::chrono::duration<double>(t_passes - t_start).count();
         s.loop_s = std::chrono::duration<double>(t_end_passes - t_passes).count();
         s.total_s = since(t_start);
         s.first_pass_s = first_pass_s;
         s.first_pass_iters = (int32_t)depth_of_pass(0);
+        s.results_under_last_pass = recon_direct ? 1 : 0;
     }
     return TVDN_OK;
 }

@@ -263,7 +263,8 @@ typedef struct tvdn_run_stats {
     double first_pass_s;   /* streamed: the first pass alone -- the one the page-locking of the host state runs under
                               (0 when the passes were chained: they overlap and cannot be told apart)                 */
     int32_t first_pass_iters; /* ... and the iterations it held                                                     */
-    int32_t reserved;
+    int32_t results_under_last_pass; /* streamed with resident rows: 1 when their results crossed PCIe during the last pass
+                              (result array page-locked in place, no stopping rule) instead of in one piece after it   */
 } tvdn_run_stats;
 
 /* ABI 6.  One slab of a cube that several PROCESSES denoise together, each streaming ITS slab through its GPU from its own

@@ -147,6 +147,41 @@ def test_streamed_run_with_resident_rows(oracle, shape, dtype, n_f, n_p, rows, k
         assert st.h2d_bytes == x.nbytes and st.d2h_bytes == x.nbytes
 
 
+@pytest.mark.parametrize("shape,dtype,n_f,n_p,rows,k,resident", [
+    ((36, 8, 16, 32), np.float32, 9, 0, 4, 3, 20),        # three passes: the last one sends the resident rows' results home itself
+    ((36, 8, 16, 32), np.float32, 5, 4, 3, 9, 30),        # ONE pass (first = last), hybrid schedule
+    ((36, 8, 16, 32), np.float32, 8, 0, 2, 4, 36),        # every row resident: nothing of the caller's is page-locked, results go home at the end
+    ((40, 32, 64), np.float64, 0, 7, 5, 3, 13),           # unaccelerated, 3-D, f64: 7 = 3 + 2 + 2
+])
+@pytest.mark.parametrize("home_after", [False, True])
+def test_resident_rows_with_the_callers_arrays_page_locked_in_place(oracle, monkeypatch, shape, dtype, n_f, n_p, rows, k, resident, home_after):
+    """Arrays of 256 MiB and more are page-locked where they are (no packed copies): the form every large run takes, reached
+    here on small cubes by lowering the threshold.  In that form the run's LAST pass sends the results of the resident rows
+    across PCIe as they reach the last level (tvdn_run_stats.results_under_last_pass) instead of in one piece after it;
+    TVDN_STREAM_HOME_AFTER=1 keeps the old order.  Same bits either way: the oracle's."""
+    from cytvdn_amd import _lib, synth
+    monkeypatch.setenv("TVDN_PIN_IN_PLACE_MIN", "64K")
+    if home_after:
+        monkeypatch.setenv("TVDN_STREAM_HOME_AFTER", "1")
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=29, dtype=dt) + dt.type(0.25)
+    assert x.nbytes >= 128 * 1024                              # its own pages (the allocator maps blocks of this size)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    st = _lib.RunStats()
+    x_before = x.copy()
+    got = _run(x, mu, n_f, n_p, stream=(rows, k), resident=resident, stats=st)
+    n = n_f + n_p
+    ref = _oracle(oracle, x, mu, n_f, n_p)
+    assert bits_equal(x, x_before) and bits_equal(got[0], ref["recon"])
+    _check_traces(got[1], ref, n)
+    assert st.resident_rows == resident and st.results_under_last_pass == (0 if home_after or resident == shape[0] else 1)
+    per_row = x.nbytes // shape[0]
+    hr = shape[0] - resident
+    n_state = 2 if n_f else 1
+    assert st.d2h_bytes <= per_row * (resident + st.n_passes * hr * (1 + nd * n_state))
+
+
 @pytest.mark.parametrize("chain", ["1", "0"])
 @pytest.mark.parametrize("shape,dtype,n_f,n_p,rows,k,resident", [
     ((23, 3, 4, 8), np.float32, 12, 0, 5, 3, 0),          # four passes, the seam between two passes inside a chunk (23 = 4 x 5 + 3)
