@@ -457,9 +457,13 @@ def api_streamed(shape, rows, k, iters, what, x=None, device=0, force_stream=Fal
     st = _lib.RunStats()
     a.data, a.recon_out, a.sums_out, a.stats = x.ctypes.data, recon.ctypes.data, sums.ctypes.data, C.addressof(st)
     torch.cuda.empty_cache()
+    _lib.lib().tvdn_wait_background()        # an earlier streamed call's page-locked memory is back with the OS (not this call's time)
     t0 = time.perf_counter()
     _lib.check(_lib.lib().tvdn_run(C.byref(a)))
     whole = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    _lib.lib().tvdn_wait_background()        # ... and this call's own: returned in the background, after the call
+    released = time.perf_counter() - t0
     vox = float(np.prod(shape))
     entry.update({
         "value": round(vox * iters / st.loop_s / 1e9, 3), "unit": "Gvoxel-iters/s", "iterations": iters,
@@ -469,6 +473,7 @@ def api_streamed(shape, rows, k, iters, what, x=None, device=0, force_stream=Fal
         "h2d_GBps": round(st.h2d_bytes / st.loop_s / 1e9, 2), "d2h_GBps": round(st.d2h_bytes / st.loop_s / 1e9, 2),
         "h2d_GB": round(st.h2d_bytes / 1e9, 1), "d2h_GB": round(st.d2h_bytes / 1e9, 1),
         "pinned_host_GiB": round(need.value / 2 ** 30, 1), "pcie_inclusive": True,
+        "background_release_s": round(released, 3),
         "check": {"b_norm_last": float(sums[-1, 0])}})
     if st.n_passes > 1 and 0 < st.first_pass_s < st.loop_s and 0 < st.first_pass_iters < iters:
         # the first pass is the one the host state is page-locked under (seconds that depend on the box: huge pages at hand

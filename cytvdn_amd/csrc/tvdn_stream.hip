@@ -438,6 +438,15 @@ extern "C" int tvdn_stream_host_need(const tvdn_run_args *a, int64_t *need_bytes
     return tvdn::stream_host_need(a, 0, need_bytes, avail_bytes);
 }
 
+// A streamed run returns its page-locked host state in the background (unpinning and unmapping 16 GiB takes 0.8 s; a run that
+// held 144 GiB would spend 7 s on it before it returned).  This waits until every such release has finished: the memory is
+// back with the operating system, and the next streamed call will not find the runtime busy unpinning.
+extern "C" int tvdn_wait_background(void)
+{
+    tvdn::wait_for_releases();
+    return TVDN_OK;
+}
+
 // What a streamed tvdn_run of these args would choose with `hbm_free_bytes` of HBM to work with (<= 0: ask args->device):
 // chunk height, depth, resident rows; the HBM bytes of rings + boxes + resident rows; the page-locked host bytes.  Pure
 // arithmetic when hbm_free_bytes is given (no device needed): cytvdn_amd/planner.py plans with it.
@@ -773,6 +782,109 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
         for (size_t i = 0; i < plane && !exact_wrap; ++i) exact_wrap = !std::isfinite(p0[i]);
     }
 
+    // ---- host state, made available by helper threads while the first pass runs ----------------------------------------------
+    // The HR rows that live on the host, of: the data term (the caller's `data` page-locked in place where possible), recon
+    // (`recon_out`, idem), the reference of an MSE trace, and the accumulator state in blocks of rows (StateBlocks).  The
+    // first pass needs the data term only (recon starts as a copy of it and the accumulators as zeros, cyTVDN.py:131-145:
+    // both are formed on the device), so it starts as soon as that is reachable; recon and the state blocks are needed when
+    // the first rows come back down, K rows later.  Periodic runs keep old and new state in two sets (second recon: recon2_h).
+    // `data` may be the very array the result goes to (the resident run allows it too): the passes then write recon rows
+    // over the rows a later pass would upload as the data term, which therefore gets a pinned copy of its own.
+    HostArr orig_h, recon_h, ref_h, recon2_h;
+    StateBlocks sb[2];
+    const bool two_sets = periodic || sh != nullptr;  // old and new host state apart
+    const int n_sets = two_sets ? 2 : 1;
+    for (int s = 0; s < n_sets; ++s) {
+        sb[s].n_arr = nd * n_state;
+        sb[s].n_slots = HR;
+        sb[s].row_bytes = row_bytes;
+        // blocks of ~4 GiB (all arrays together), never shorter than a chunk: short enough for the first one to exist when the
+        // first rows come down, long enough for the per-allocation costs not to matter
+        const int64_t per_row = (int64_t)sb[s].n_arr * (int64_t)row_bytes;
+        sb[s].block_rows = std::max<int64_t>({R, 1, (int64_t)((int64_t(4) << 30) / std::max<int64_t>(per_row, 1))});
+        sb[s].block_rows = std::min<int64_t>(sb[s].block_rows, std::max<int64_t>(HR, 1));
+        sb[s].blocks.resize((size_t)sb[s].n_blocks());
+    }
+    Flag orig_ready, recon_ready, recon2_ready, staged_done;
+    std::atomic<int64_t> staged_upto{0};  // resident rows g < staged_upto have their data term in the store
+    const size_t host_bytes = (size_t)HR * row_bytes;
+    // data partly overlapping recon_out (not the same array): a download into recon_out may hit rows of `data` that have
+    // not been read yet, so every input is taken out of `data` before the first pass starts
+    const bool eager = (aliased && a->recon_out != a->data) || getenv("TVDN_STREAM_EAGER") != nullptr;
+    auto host_row = [&](const HostArr &h, int64_t g) -> char * {
+        return h.cube_rows ? h.p + (size_t)g * row_bytes : h.p + (size_t)rm.host_below(g) * row_bytes;
+    };
+    // host rows of a cube-shaped user array <-> a packed buffer, run of consecutive host rows by run
+    auto pack_host_rows = [&](char *packed, char *cube, bool to_packed) {
+        for (int64_t g = 0; g < N0;) {
+            if (resident(g)) {
+                ++g;
+                continue;
+            }
+            int64_t e = g + 1;
+            while (e < N0 && !resident(e)) ++e;
+            char *pk = packed + (size_t)rm.host_below(g) * row_bytes, *cb = cube + (size_t)g * row_bytes;
+            parallel_copy(to_packed ? pk : cb, to_packed ? cb : pk, (size_t)(e - g) * row_bytes);
+            g = e;
+        }
+    };
+
+    if (sh) {  // a slab of a device-list run: the host state is the coordinator's (shared, page-locked, cube rows)
+        orig_h.p = sh->orig;
+        recon_h.p = sh->recon[0];
+        recon2_h.p = sh->recon[1];
+        ref_h.p = sh->ref;
+        orig_h.cube_rows = recon_h.cube_rows = recon2_h.cube_rows = ref_h.cube_rows = true;
+        for (int set = 0; set < 2; ++set)
+            for (int i = 0; i < nd * n_state; ++i) sb[set].flat.push_back(sh->state[set][i]);
+    }
+    // (The helper that page-locks the host arrays starts BEFORE the device block is asked for: a hipMalloc of most of the HBM
+    //  takes 0.3 - 1.7 s when the driver has freed memory to clear first, time in which the data term gets page-locked.)
+    std::thread pinner([&] {
+        (void)hipSetDevice(device);
+        if (HR <= 0 || sh) {
+            orig_ready.raise();
+            recon_ready.raise();
+            recon2_ready.raise();
+            return;
+        }
+        // 1. the data term (and the reference): inputs of the first pass
+        int rcp = aliased ? orig_h.alloc(host_bytes) : orig_h.pin_in_place(const_cast<void *>(a->data), cube_bytes, host_bytes, false);
+        if (!rcp && orig_h.owned) pack_host_rows(orig_h.p, (char *)const_cast<void *>(a->data), true);
+        if (!rcp && want_mse) {
+            rcp = ref_h.pin_in_place(const_cast<void *>(a->reference), cube_bytes, host_bytes, false);
+            if (!rcp && ref_h.owned) pack_host_rows(ref_h.p, (char *)const_cast<void *>(a->reference), true);
+        }
+        const std::string m1 = rcp ? tvdn_last_error() : "";
+        orig_ready.raise(rcp, m1);
+        // 2. where the first pass's rows come down: recon (periodic: the SECOND set) and the state blocks in slot order
+        if (!rcp) {
+            if (periodic) {
+                rcp = recon2_h.alloc(host_bytes);
+                recon2_ready.raise(rcp, rcp ? tvdn_last_error() : "");
+            } else {
+                // (a result array that is also the input holds data: not `fresh`)
+                rcp = recon_h.pin_in_place(a->recon_out, cube_bytes, host_bytes, !aliased);
+                recon_ready.raise(rcp, rcp ? tvdn_last_error() : "");
+                recon2_ready.raise();
+            }
+        }
+        const int first_set = periodic ? 1 : 0;
+        for (int64_t b = 0; b < sb[first_set].n_blocks() && !rcp; ++b) rcp = sb[first_set].allocate(b);
+        if (periodic && !rcp) {  // 3. the first set: the second pass's target
+            rcp = recon_h.pin_in_place(a->recon_out, cube_bytes, host_bytes, !aliased);
+            recon_ready.raise(rcp, rcp ? tvdn_last_error() : "");
+            for (int64_t b = 0; b < sb[0].n_blocks() && !rcp; ++b) rcp = sb[0].allocate(b);
+        }
+        if (rcp) {  // nobody waits for ever
+            const std::string m = m1.empty() ? std::string(tvdn_last_error()) : m1;
+            recon_ready.raise(rcp, m);
+            recon2_ready.raise(rcp, m);
+            for (int s = 0; s < n_sets; ++s) sb[s].fail(rcp, m);
+        }
+    });
+    Joiner join_pinner{pinner};
+
     // ---- device: rings, staging boxes, resident rows, sums ---------------------------------------------------------------
     CtxHolder ctx;
     int rc = tvdn_ctx_create(&ctx.c, device);
@@ -849,62 +961,6 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
             return rc;
     }
 
-    // ---- host state, made available by helper threads while the first pass runs ----------------------------------------------
-    // The HR rows that live on the host, of: the data term (the caller's `data` page-locked in place where possible), recon
-    // (`recon_out`, idem), the reference of an MSE trace, and the accumulator state in blocks of rows (StateBlocks).  The
-    // first pass needs the data term only (recon starts as a copy of it and the accumulators as zeros, cyTVDN.py:131-145:
-    // both are formed on the device), so it starts as soon as that is reachable; recon and the state blocks are needed when
-    // the first rows come back down, K rows later.  Periodic runs keep old and new state in two sets (second recon: recon2_h).
-    // `data` may be the very array the result goes to (the resident run allows it too): the passes then write recon rows
-    // over the rows a later pass would upload as the data term, which therefore gets a pinned copy of its own.
-    HostArr orig_h, recon_h, ref_h, recon2_h;
-    StateBlocks sb[2];
-    const bool two_sets = periodic || sh != nullptr;  // old and new host state apart
-    const int n_sets = two_sets ? 2 : 1;
-    for (int s = 0; s < n_sets; ++s) {
-        sb[s].n_arr = nd * n_state;
-        sb[s].n_slots = HR;
-        sb[s].row_bytes = row_bytes;
-        // blocks of ~4 GiB (all arrays together), never shorter than a chunk: short enough for the first one to exist when the
-        // first rows come down, long enough for the per-allocation costs not to matter
-        const int64_t per_row = (int64_t)sb[s].n_arr * (int64_t)row_bytes;
-        sb[s].block_rows = std::max<int64_t>({R, 1, (int64_t)((int64_t(4) << 30) / std::max<int64_t>(per_row, 1))});
-        sb[s].block_rows = std::min<int64_t>(sb[s].block_rows, std::max<int64_t>(HR, 1));
-        sb[s].blocks.resize((size_t)sb[s].n_blocks());
-    }
-    Flag orig_ready, recon_ready, recon2_ready, staged_done;
-    std::atomic<int64_t> staged_upto{0};  // resident rows g < staged_upto have their data term in the store
-    const size_t host_bytes = (size_t)HR * row_bytes;
-    // data partly overlapping recon_out (not the same array): a download into recon_out may hit rows of `data` that have
-    // not been read yet, so every input is taken out of `data` before the first pass starts
-    const bool eager = (aliased && a->recon_out != a->data) || getenv("TVDN_STREAM_EAGER") != nullptr;
-    auto host_row = [&](const HostArr &h, int64_t g) -> char * {
-        return h.cube_rows ? h.p + (size_t)g * row_bytes : h.p + (size_t)rm.host_below(g) * row_bytes;
-    };
-    // host rows of a cube-shaped user array <-> a packed buffer, run of consecutive host rows by run
-    auto pack_host_rows = [&](char *packed, char *cube, bool to_packed) {
-        for (int64_t g = 0; g < N0;) {
-            if (resident(g)) {
-                ++g;
-                continue;
-            }
-            int64_t e = g + 1;
-            while (e < N0 && !resident(e)) ++e;
-            char *pk = packed + (size_t)rm.host_below(g) * row_bytes, *cb = cube + (size_t)g * row_bytes;
-            parallel_copy(to_packed ? pk : cb, to_packed ? cb : pk, (size_t)(e - g) * row_bytes);
-            g = e;
-        }
-    };
-
-    if (sh) {  // a slab of a device-list run: the host state is the coordinator's (shared, page-locked, cube rows)
-        orig_h.p = sh->orig;
-        recon_h.p = sh->recon[0];
-        recon2_h.p = sh->recon[1];
-        ref_h.p = sh->ref;
-        orig_h.cube_rows = recon_h.cube_rows = recon2_h.cube_rows = ref_h.cube_rows = true;
-        for (int set = 0; set < 2; ++set)
-            for (int i = 0; i < nd * n_state; ++i) sb[set].flat.push_back(sh->state[set][i]);
-    }
     std::thread stager([&] {  // resident rows of the data term: pageable `data` -> store, through the library's pinned lanes
         if (sh) {
             staged_upto.store(N0);
@@ -932,50 +988,6 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
         staged_done.raise();
     });
     Joiner join_stager{stager};
-    std::thread pinner([&] {
-        (void)hipSetDevice(device);
-        if (HR <= 0 || sh) {
-            orig_ready.raise();
-            recon_ready.raise();
-            recon2_ready.raise();
-            return;
-        }
-        // 1. the data term (and the reference): inputs of the first pass
-        int rcp = aliased ? orig_h.alloc(host_bytes) : orig_h.pin_in_place(const_cast<void *>(a->data), cube_bytes, host_bytes, false);
-        if (!rcp && orig_h.owned) pack_host_rows(orig_h.p, (char *)const_cast<void *>(a->data), true);
-        if (!rcp && want_mse) {
-            rcp = ref_h.pin_in_place(const_cast<void *>(a->reference), cube_bytes, host_bytes, false);
-            if (!rcp && ref_h.owned) pack_host_rows(ref_h.p, (char *)const_cast<void *>(a->reference), true);
-        }
-        const std::string m1 = rcp ? tvdn_last_error() : "";
-        orig_ready.raise(rcp, m1);
-        // 2. where the first pass's rows come down: recon (periodic: the SECOND set) and the state blocks in slot order
-        if (!rcp) {
-            if (periodic) {
-                rcp = recon2_h.alloc(host_bytes);
-                recon2_ready.raise(rcp, rcp ? tvdn_last_error() : "");
-            } else {
-                // (a result array that is also the input holds data: not `fresh`)
-                rcp = recon_h.pin_in_place(a->recon_out, cube_bytes, host_bytes, !aliased);
-                recon_ready.raise(rcp, rcp ? tvdn_last_error() : "");
-                recon2_ready.raise();
-            }
-        }
-        const int first_set = periodic ? 1 : 0;
-        for (int64_t b = 0; b < sb[first_set].n_blocks() && !rcp; ++b) rcp = sb[first_set].allocate(b);
-        if (periodic && !rcp) {  // 3. the first set: the second pass's target
-            rcp = recon_h.pin_in_place(a->recon_out, cube_bytes, host_bytes, !aliased);
-            recon_ready.raise(rcp, rcp ? tvdn_last_error() : "");
-            for (int64_t b = 0; b < sb[0].n_blocks() && !rcp; ++b) rcp = sb[0].allocate(b);
-        }
-        if (rcp) {  // nobody waits for ever
-            const std::string m = m1.empty() ? std::string(tvdn_last_error()) : m1;
-            recon_ready.raise(rcp, m);
-            recon2_ready.raise(rcp, m);
-            for (int s = 0; s < n_sets; ++s) sb[s].fail(rcp, m);
-        }
-    });
-    Joiner join_pinner{pinner};
     if (eager) {
         if ((rc = staged_done.wait()) || (rc = orig_ready.wait())) return rc;
     }

@@ -378,6 +378,12 @@ int tvdn_run(const tvdn_run_args *args);
  * release it first. */
 int tvdn_release_cache(void);
 
+/* ABI 6.  A streamed tvdn_run hands the page-locked host memory it allocated back in the BACKGROUND (unpinning 144 GiB takes
+ * about 7 s; the call returns without waiting for it, and the process's exit handlers do wait).  tvdn_wait_background() returns
+ * once every such release has finished -- for a caller that wants the memory back before it goes on, or that times a second
+ * streamed call without the first one's teardown in it.  Always TVDN_OK. */
+int tvdn_wait_background(void);
+
 /* Bytes of device memory the state of a resident one-device run of these args takes (dtype, ndim, shape, n_fista > 0
  * are read): what tvdn_run allocates itself, or expects behind tvdn_run_args.workspace.  Pure host arithmetic. */
 int tvdn_run_workspace_bytes(const tvdn_run_args *args, int64_t *bytes);
