@@ -40,8 +40,13 @@ def main():
               f"distinct GPUs {pf.get('distinct_gpus')}{'' if ok else '  <-- NOT one GPU per rank'}, roofline frac {d['roofline']['frac']}")
     d = last_json(os.path.join(o, "staged_slabs.out"))
     if d:
-        print(f"staged slabs: {d.get('value')} {d.get('unit')} on {d.get('ranks')} ranks, shape {d.get('shape')}, chunk rows {d.get('chunk_rows')}, "
-              f"k {d.get('k')}, PCIe rank 0 {d.get('h2d_GBps_rank0')} + {d.get('d2h_GBps_rank0')} GB/s")
+        print(f"staged slabs (one process per GPU): {d.get('value')} {d.get('unit')} on {d.get('ranks')} ranks, shape {d.get('shape')}, "
+              f"chunk rows {d.get('chunk_rows')}, k {d.get('k')}, whole call of every rank {d.get('seconds')} s")
+    d = last_json(os.path.join(o, "device_list_streamed.out"))
+    if d:
+        print(f"streamed device list (one process): {d.get('value')} {d.get('unit')} passes only ({d.get('value_whole_call')} whole call) on "
+              f"{d.get('distinct_devices')} GPUs, shape {d.get('shape')}, chunk rows {d.get('stream_rows')}, k {d.get('stream_k')}, "
+              f"PCIe all devices {d.get('h2d_GBps_all')} + {d.get('d2h_GBps_all')} GB/s, bit-identical to one device: {d.get('bit_identical_to_one_device_resident')}")
 
 
 if __name__ == "__main__":

@@ -7,7 +7,9 @@
 #                                        each with its pre-flight (bit-exact exchange, ranks seen == world, one GPU per rank)
 #   3. tools/bench_staged_slabs.py       BASELINE configs[4] in structure: every rank streams its slab from page-locked host
 #                                        memory (needs 40 GiB of host memory per rank at the default shape)
-#   4. tools/first_node_report.py        one page: what ran, what it gave, scaling efficiency against the 1-GPU line
+#   4. tools/device_list_streamed.py     the same structure inside ONE process: tvdn_run with the node's GPUs as a device list,
+#                                        every slab streamed from host arrays the slabs share (no launcher, no messages)
+#   5. tools/first_node_report.py        one page: what ran, what it gave, scaling efficiency against the 1-GPU line
 # Usage (on the node, from the repo root):   bash tools/first_node_run.sh [OUTDIR]
 # Rehearsal on a one-GPU box (several ranks share the GPU, halo rows staged through host memory over gloo; at most 6 processes
 # may use a GPU at once on the pool's boxes, launcher included: 4 ranks is the most that rehearses safely):   TVDN_DIST_BACKEND=gloo REHEARSE_RANKS="2 4" REHEARSE_SHAPE=1 bash tools/first_node_run.sh
@@ -40,8 +42,10 @@ for n in $RANKS; do
 done
 if [ -n "${REHEARSE_SHAPE:-}" ]; then
   step staged_slabs 300 python3 tools/bench_staged_slabs.py --shape 32x64x64x64 --ranks 2 --rows 4 --k 4 --iters 8
+  step device_list_streamed 300 python3 tools/device_list_streamed.py --shape 32x64x64x64 --devices 0,0,0 --rows 4 --k 4 --iters 8 --check
 elif [ "$NGPU" -ge 2 ]; then
   # config 5 in structure at a size every node can pin: the config-2 planes, 32 rows per rank, one GPU per rank
   step staged_slabs 1200 python3 tools/bench_staged_slabs.py --shape $((32 * NGPU))x256x128x128 --ranks "$NGPU" --gpu-per-rank --rows 8 --k 24 --iters 48
+  step device_list_streamed 1200 python3 tools/device_list_streamed.py --shape $((32 * NGPU))x256x128x128 --devices "$(seq -s, 0 $((NGPU - 1)))" --rows 8 --k 24 --iters 48
 fi
 python3 tools/first_node_report.py "$O" | tee "$O/report.txt"
