@@ -1072,8 +1072,11 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
         }
         // exact Jia-Zhao wrap across processes: the slab that owns row 0 sends row 0 of every level to the one that owns the
         // top face, once per pass (hooks of the caller; a slab in between has nothing to do with it)
+        // Exact wrap over several slabs: the slab that owns row 0 hands row 0 of every level of the pass to EVERY other slab,
+        // once per pass (a broadcast: every slab takes part).  Used by the slabs whose sweeps reach the cube's top face without
+        // sweeping row 0 themselves -- the last slab, and any slab whose K-row halo reaches that far.
         const bool relay_send = exact_wrap && sh && sh->relay_row0 && sh->g0 == 0 && sh->g1 < N0;
-        const bool relay_recv = exact_wrap && sh && sh->relay_row0 && sh->g1 == N0 && sh->g0 > 0;
+        const bool relay_recv = exact_wrap && sh && sh->relay_row0 && sh->g0 > 0;
         int planes_ready = 0;
         bool relayed = false;
         // rows of the (virtual) cube this pass works on, and what each level can reach at an artificial face
@@ -1201,7 +1204,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
             for (int j = 0; j < kk; ++j) {
                 const int64_t lo = std::max(lo_bound(j + 1), E0 + c * R - (j + 1)), hi = std::min(hi_bound(j + 1), E0 + (c + 1) * R - (j + 1));
                 if (lo >= hi) continue;
-                if (relay_recv && !relayed && hi == G1) {  // my first sweep at the cube's top face: row 0 of every level, from its owner
+                if (relay_recv && !relayed && hi == G1 && E0 > G0) {  // my first sweep at the cube's top face: row 0 of every level, from its owner
                     int rcr = sh->relay_row0(0, row0_host.p, kk);
                     if (rcr) {
                         set_error("the row-0 relay of a slab run failed (status %d)", rcr);
@@ -1316,6 +1319,14 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
                     out_free_set[h] = true;
                 }
             }
+        }
+        if (relay_recv && !relayed) {  // a slab that had no use for the planes still takes part in the hand-over
+            const int rcr = sh->relay_row0(0, row0_host.p, kk);
+            if (rcr) {
+                set_error("the row-0 relay of a slab run failed (status %d)", rcr);
+                return TVDN_ERR_INVALID;
+            }
+            relayed = true;
         }
         TVDN_HIP(hipStreamSynchronize(st.down));
         TVDN_HIP(hipStreamSynchronize(st.main));
@@ -1979,7 +1990,8 @@ int run_streamed_slabs(const tvdn_run_args *a, int64_t R, int64_t K)
     SlabBarrier bar;
     bar.count = world;
     std::vector<char> mail;  // row 0 of every level of a pass on its way from the first slab to the last (exact wrap)
-    long mail_sent = 0, mail_taken = 0;
+    long mail_sent = 0;
+    std::vector<long> mail_taken((size_t)world, 0);
     std::vector<SlabShare> shares((size_t)world);
     std::vector<tvdn_run_args> args((size_t)world, *a);
     std::vector<std::vector<double>> sums((size_t)world, std::vector<double>((size_t)3 * n_total, 0.0));
@@ -2005,21 +2017,19 @@ int run_streamed_slabs(const tvdn_run_args *a, int64_t R, int64_t K)
         sh.first_new = first_new;
         sh.barrier = &bar;
         sh.exact_wrap = exact_wrap;
-        if (exact_wrap && (r == 0 || r == world - 1))
-            sh.relay_row0 = [&bar, &mail, &mail_sent, &mail_taken, row_bytes](int send, void *planes, int n) -> int {
+        if (exact_wrap)  // row 0 of every level of a pass: from the first slab's thread to every other one's, once per pass
+            sh.relay_row0 = [&bar, &mail, &mail_sent, &mail_taken, row_bytes, r](int send, void *planes, int n) -> int {
                 std::unique_lock<std::mutex> lk(bar.mu);  // the barrier's lock and wake-ups: a slab that fails ends the wait
                 const size_t bytes = (size_t)n * row_bytes;
-                if (send) {
-                    bar.cv.wait(lk, [&] { return mail_taken == mail_sent || bar.failed; });
-                    if (bar.failed) return 1;
+                if (send) {  // (every taker of the pass before has been here: the slabs meet between two passes)
                     if (mail.size() < bytes) mail.resize(bytes);
                     std::memcpy(mail.data(), planes, bytes);
                     ++mail_sent;
                 } else {
-                    bar.cv.wait(lk, [&] { return mail_sent > mail_taken || bar.failed; });
+                    bar.cv.wait(lk, [&] { return mail_sent > mail_taken[(size_t)r] || bar.failed; });
                     if (bar.failed) return 1;
                     std::memcpy(planes, mail.data(), bytes);
-                    ++mail_taken;
+                    ++mail_taken[(size_t)r];
                 }
                 bar.cv.notify_all();
                 return 0;

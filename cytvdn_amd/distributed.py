@@ -208,17 +208,18 @@ class _RankHooks:
             return 1
 
     def relay_row0(self, _user, send, planes, n, row_bytes):
-        """Row 0 of every level of a pass, from the rank that owns it to the rank that owns the cube's top face."""
+        """Row 0 of every level of a pass, from the rank that owns it to every other rank (a broadcast every rank joins once
+        per pass; the owner does not wait for the others, which arrive late in their passes)."""
         try:
             v = self._view(planes, n, row_bytes)
             if send:
                 if self._relay_work is not None:
                     self._relay_work.wait()
                 self._relay_buf = self._snd(v).clone()
-                self._relay_work = self.dist.isend(self._relay_buf, self.peer(self.world - 1), group=self.group, tag=1000)
+                self._relay_work = self.dist.broadcast(self._relay_buf, self.peer(0), group=self.group, async_op=True)
             else:
                 buf = torch.empty(v.shape, dtype=v.dtype, device=self.cuda) if self.via_dev else v
-                self.dist.recv(buf, self.peer(0), group=self.group, tag=1000)
+                self.dist.broadcast(buf, self.peer(0), group=self.group)
                 if self.via_dev:
                     v.copy_(buf)
             return 0

@@ -288,9 +288,11 @@ typedef struct tvdn_slab_io {
                     int32_t depth, int64_t row_bytes);
     /* sums3: one iteration's three sums over this slab -> over all slabs, in place.  Only with use_stop, once per iteration. */
     int (*allreduce)(void *user, double *sums3);
-    /* Only with first_row_nonfinite: once per pass the first slab calls it with send = 1 and row 0 of every level of the pass
-     * (n_planes contiguous row-planes, page-locked), the last slab with send = 0 before its first sweep at the cube's top face
-     * (the callee fills the planes). */
+    /* Only with first_row_nonfinite: a BROADCAST, once per pass, of row 0 of every level of the pass (n_planes contiguous
+     * row-planes, page-locked) from the slab that owns row 0 to every other slab.  The owner calls it with send = 1 early in
+     * its pass (the callee must not wait for the takers there: they arrive late in theirs); every other slab calls it exactly
+     * once per pass with send = 0 and gets the planes filled -- a slab whose sweeps reach the cube's top face (the last one,
+     * and any whose stream_k-row halo reaches that far) before its first sweep there, the others at the end of the pass. */
     int (*relay_row0)(void *user, int32_t send, void *planes, int32_t n_planes, int64_t row_bytes);
     void *user;
 } tvdn_slab_io;

@@ -210,3 +210,73 @@ def test_streamed_run_random(oracle, rows, plane, f64, bc, n_f, n_p, seed, chunk
     assert bits_equal(recon, ref["recon"])
     if np.isfinite(ref["b_norm64"]).all() and np.isfinite(ref["delta64"]).all():
         _check_traces(sums, ref, n_f + n_p)
+
+
+@settings(max_examples=50, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(rows=st.integers(3, 30), plane=st.one_of(st.tuples(st.integers(1, 4), st.integers(2, 5), st.sampled_from([4, 8, 12, 32])),
+                                                st.tuples(st.integers(2, 6), st.sampled_from([4, 7, 8, 16, 64]))),
+       f64=st.booleans(), n_f=st.integers(0, 7), n_p=st.integers(0, 5), seed=st.integers(0, 2 ** 31 - 1),
+       chunk=st.integers(1, 8), k=st.integers(1, 9), res_frac=st.floats(0.0, 1.0), in_place=st.booleans(), bad_row0=st.booleans(),
+       stop=st.booleans(), chain=st.booleans())
+def test_streamed_hybrid_random(oracle, rows, plane, f64, n_f, n_p, seed, chunk, k, res_frac, in_place, bad_row0, stop, chain):
+    """The resident + streamed hybrid with any share of the rows resident, the caller's arrays page-locked where they are or
+    staged through packed copies, chained or drained passes, with and without a stopping rule, a non-finite first row now and
+    then: the oracle's bits and traces."""
+    import os
+    from test_gpu_run_streamed import _check_traces, _oracle, _run
+    if n_f + n_p == 0:
+        n_f = 2
+    shape = (rows,) + tuple(plane)
+    dt = np.dtype(np.float64 if f64 else np.float32)
+    nd = len(shape)
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(shape) * 2 + rng.poisson(3.0, shape)).astype(dt)
+    if bad_row0:
+        x[(0,) + tuple(int(rng.integers(s)) for s in shape[1:])] = np.nan
+    mu = np.array([1.0, 0.7, 0.5, 1.3][:nd], dt)
+    resident = int(round(res_frac * rows))
+    stop_v = 0.02 if stop else None
+    env = {"TVDN_PIN_IN_PLACE_MIN": "4K" if in_place else "1G", "TVDN_STREAM_CHAIN": "1" if chain else "0"}
+    old = {k_: os.environ.get(k_) for k_ in env}
+    os.environ.update(env)
+    try:
+        recon, sums, _, ran = _run(x, mu, n_f, n_p, stream=(chunk, k), resident=resident, stop=stop_v)
+    finally:
+        for k_, v in old.items():
+            if v is None:
+                del os.environ[k_]
+            else:
+                os.environ[k_] = v
+    ref = _oracle(oracle, x, mu, n_f, n_p, stopping_relative_change=stop_v)
+    assert bits_equal(recon, ref["recon"])
+    if stop_v is None:
+        assert ran == n_f + n_p
+        if np.isfinite(ref["b_norm64"]).all() and np.isfinite(ref["delta64"]).all():
+            _check_traces(sums, ref, n_f + n_p)
+    else:
+        assert ran == ref["iters_done"]
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(rows=st.integers(4, 28), plane=st.tuples(st.integers(1, 4), st.integers(2, 5), st.sampled_from([4, 8, 12])),
+       f64=st.booleans(), bc=st.sampled_from([0, 2]), n_f=st.integers(0, 6), n_p=st.integers(0, 4), seed=st.integers(0, 2 ** 31 - 1),
+       chunk=st.integers(1, 6), k=st.integers(1, 7), slabs=st.integers(2, 4), bad_row0=st.booleans(), stop=st.booleans())
+def test_streamed_device_list_random(oracle, rows, plane, f64, bc, n_f, n_p, seed, chunk, k, slabs, bad_row0, stop):
+    """tvdn_run with a device list AND stream_rows / stream_k (BASELINE configs[4] in structure, one process): slabs streamed
+    from host arrays they share, any cut, both boundary conditions, stopping rule, non-finite first row: the oracle's bits."""
+    from test_gpu_run_streamed import _oracle_bc, _run
+    if n_f + n_p == 0:
+        n_p = 2
+    slabs = min(slabs, rows)
+    shape = (rows,) + tuple(plane)
+    dt = np.dtype(np.float64 if f64 else np.float32)
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(shape) * 2 + rng.poisson(3.0, shape)).astype(dt)
+    if bad_row0 and bc == 2:
+        x[(0,) + tuple(int(rng.integers(s)) for s in shape[1:])] = np.inf
+    mu = np.array([1.0, 0.7, 0.5, 1.3], dt)
+    stop_v = 0.02 if stop else None
+    ref = _oracle_bc(oracle, x, mu, n_f, n_p, bc, stopping_relative_change=stop_v)
+    recon, sums, _, ran = _run(x, mu, n_f, n_p, stream=(chunk, k), bc=bc, devices=[0] * slabs, stop=stop_v)
+    assert bits_equal(recon, ref["recon"])
+    assert ran == (ref["iters_done"] if stop_v is not None else n_f + n_p)

@@ -115,10 +115,12 @@ def test_denoise_slabs_switches_the_wrap_row_on_by_itself(oracle):
     (2, (20, 3, 4, 8), "float32", 9, (4, 3)),            # three passes of three levels, several chunks per rank
     (3, (19, 6, 16), "float64", [5, 4], (3, 4)),         # hybrid, the d -> b transition inside a pass, uneven slabs
     (2, (24, 2, 5, 7), "float32", 7, (2, 8)),            # more levels than chunk rows: row 0 of level j is final only in chunk j / R
+    (3, (9, 3, 4, 8), "float32", 7, (2, 3)),             # the MIDDLE rank's 3-row halo reaches the cube's top face: it needs row 0 too
+    (3, (12, 6, 16), "float64", [4, 3], (3, 4)),
 ])
 def test_staged_slabs_carry_the_wrap_row_across_ranks(oracle, world, shape, dtype, its, staged):
-    """Slabs in pinned host memory, wavefront schedule inside each (BASELINE config 5 in structure): rank 0 sends row 0 of
-    every level of a pass to the last rank, which closes the Jia-Zhao wrap with it (TVDN_EDGE_WRAP) -- the NaN upstream
+    """Slabs in pinned host memory, wavefront schedule inside each (BASELINE config 5 in structure): rank 0 broadcasts row 0
+    of every level of a pass; the ranks whose sweeps reach the cube's top face close the Jia-Zhao wrap with it (TVDN_EDGE_WRAP) -- the NaN upstream
     carries from a non-finite first row into the LAST row (anisotropic.pyx:65-73, utils.pyx:98-101) must appear."""
     import torch.multiprocessing as mp
     with tempfile.TemporaryDirectory() as tmp:

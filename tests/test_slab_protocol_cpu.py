@@ -234,10 +234,7 @@ def _hooks_worker(rank, world, port, periodic, outdir):
         s3 = (C.c_double * 3)(1.0 + rank, 10.0, 0.5 * rank)
         assert hooks.allreduce(None, s3) == 0, hooks.error
         planes = np.full((4, row_bytes), 7 + rank, np.uint8)
-        if rank == 0:
-            assert hooks.relay_row0(None, 1, planes.ctypes.data, 4, row_bytes) == 0, hooks.error
-        if rank == world - 1:
-            assert hooks.relay_row0(None, 0, planes.ctypes.data, 4, row_bytes) == 0, hooks.error
+        assert hooks.relay_row0(None, 1 if rank == 0 else 0, planes.ctypes.data, 4, row_bytes) == 0, hooks.error   # a broadcast
         hooks.finish()
         np.savez(os.path.join(outdir, f"h{rank}.npz"), arrs=np.stack(arrs), sums=np.array(list(s3)), planes=planes, own=own)
     finally:
@@ -248,7 +245,7 @@ def _hooks_worker(rank, world, port, periodic, outdir):
 def test_streamed_slab_hooks_over_gloo(world, periodic):
     """The multi-process streamed run's exchange (distributed._RankHooks): after it the low halo rows of every array are the
     left neighbour's highest own rows and the high halo rows the right neighbour's lowest, rows at the cube's two ends
-    untouched unless the boundary is periodic; the sums are all-reduced; rank 0's wrap planes arrive at the last rank."""
+    untouched unless the boundary is periodic; the sums are all-reduced; rank 0's wrap planes arrive at every other rank."""
     with tempfile.TemporaryDirectory() as tmp:
         mp.start_processes(_hooks_worker, args=(world, _free_port(), periodic, tmp), nprocs=world, join=True, start_method="spawn")
         out = [np.load(os.path.join(tmp, f"h{r}.npz")) for r in range(world)]
@@ -269,4 +266,4 @@ def test_streamed_slab_hooks_over_gloo(world, periodic):
                 assert np.array_equal(a[i, d + own:], out[right]["arrs"][i, d:2 * d])
             assert (a[i, d:d + own] // 16 == r).all()                # own rows never written
         assert np.allclose(out[r]["sums"], [sum(1.0 + q for q in range(world)), 10.0 * world, sum(0.5 * q for q in range(world))])
-    assert (out[world - 1]["planes"] == 7).all()                      # rank 0's planes
+    assert all((out[r]["planes"] == 7).all() for r in range(world))     # rank 0's planes, on every rank
