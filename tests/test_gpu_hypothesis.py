@@ -217,13 +217,13 @@ def test_streamed_run_random(oracle, rows, plane, f64, bc, n_f, n_p, seed, chunk
                                                 st.tuples(st.integers(2, 6), st.sampled_from([4, 7, 8, 16, 64]))),
        f64=st.booleans(), n_f=st.integers(0, 7), n_p=st.integers(0, 5), seed=st.integers(0, 2 ** 31 - 1),
        chunk=st.integers(1, 8), k=st.integers(1, 9), res_frac=st.floats(0.0, 1.0), in_place=st.booleans(), bad_row0=st.booleans(),
-       stop=st.booleans(), chain=st.booleans())
-def test_streamed_hybrid_random(oracle, rows, plane, f64, n_f, n_p, seed, chunk, k, res_frac, in_place, bad_row0, stop, chain):
+       stop=st.booleans(), chain=st.booleans(), bc=st.sampled_from([2, 2, 0]), with_mse=st.booleans())
+def test_streamed_hybrid_random(oracle, rows, plane, f64, n_f, n_p, seed, chunk, k, res_frac, in_place, bad_row0, stop, chain, bc, with_mse):
     """The resident + streamed hybrid with any share of the rows resident, the caller's arrays page-locked where they are or
     staged through packed copies, chained or drained passes, with and without a stopping rule, a non-finite first row now and
     then: the oracle's bits and traces."""
     import os
-    from test_gpu_run_streamed import _check_traces, _oracle, _run
+    from test_gpu_run_streamed import _check_traces, _oracle_bc, _run
     if n_f + n_p == 0:
         n_f = 2
     shape = (rows,) + tuple(plane)
@@ -231,7 +231,8 @@ def test_streamed_hybrid_random(oracle, rows, plane, f64, n_f, n_p, seed, chunk,
     nd = len(shape)
     rng = np.random.default_rng(seed)
     x = (rng.standard_normal(shape) * 2 + rng.poisson(3.0, shape)).astype(dt)
-    if bad_row0:
+    clean = rng.poisson(3.0, shape).astype(dt) if with_mse else None
+    if bad_row0 and bc == 2:
         x[(0,) + tuple(int(rng.integers(s)) for s in shape[1:])] = np.nan
     mu = np.array([1.0, 0.7, 0.5, 1.3][:nd], dt)
     resident = int(round(res_frac * rows))
@@ -240,19 +241,21 @@ def test_streamed_hybrid_random(oracle, rows, plane, f64, n_f, n_p, seed, chunk,
     old = {k_: os.environ.get(k_) for k_ in env}
     os.environ.update(env)
     try:
-        recon, sums, _, ran = _run(x, mu, n_f, n_p, stream=(chunk, k), resident=resident, stop=stop_v)
+        recon, sums, mse, ran = _run(x, mu, n_f, n_p, stream=(chunk, k), resident=resident, stop=stop_v, bc=bc, ref=clean)
     finally:
         for k_, v in old.items():
             if v is None:
                 del os.environ[k_]
             else:
                 os.environ[k_] = v
-    ref = _oracle(oracle, x, mu, n_f, n_p, stopping_relative_change=stop_v)
+    ref = _oracle_bc(oracle, x, mu, n_f, n_p, bc, stopping_relative_change=stop_v, reference_data=clean)
     assert bits_equal(recon, ref["recon"])
     if stop_v is None:
         assert ran == n_f + n_p
         if np.isfinite(ref["b_norm64"]).all() and np.isfinite(ref["delta64"]).all():
             _check_traces(sums, ref, n_f + n_p)
+            if with_mse:
+                np.testing.assert_allclose(mse[:ran + 1], ref["MSE64"][:ran + 1], rtol=1e-6 if dt == np.float32 else 1e-11)
     else:
         assert ran == ref["iters_done"]
 
