@@ -344,14 +344,16 @@ static int64_t stream_planes(int nd, int64_t rows, int64_t k, bool mse, bool wra
     return ((k + 1) + (k + 2) * nd) * (rows + 2) + (rows + k + 3) * (mse ? 2 : 1) + 2 * (3 + 4 * nd) * rows + 2 * (1 + 2 * nd) + (wrap ? 2 * (k + 1) : 0) + 1;
 }
 
-// Chunk height R, depth K and the number of low rows whose state STAYS in HBM between passes (the resident + streamed hybrid).
+// Chunk height R, depth K and the number of rows whose state STAYS in HBM between passes (the resident + streamed hybrid).
 // A pass costs max(PCIe time of the streamed rows, sweep time of all rows + the device copies of the resident rows); the
 // choice minimises that per iteration over every (R, K) whose rings fit 85 % of the free HBM, the rows kept being what the
 // rest of that budget holds (2 + nd x n_state arrays per row: data term, recon, accumulator state).  Without kept rows this is
-// "the deepest K": a streamed pass is PCIe-bound until K ~ 100 (256 MiB planes: K = 30 / 38 / 44 -> 28.4 / 33.6 / 37.0
-// Gvoxel-iters/s, profiles/r03_outofcore_depth.jsonl).  With them, depth and kept rows compete for the same HBM and the
-// model decides: rates measured on MI355X -- both PCIe directions together 60 GB/s through the runtime's copies, the sweep
-// on rings at 0.82 x 5.6 TB/s of moved bytes, device copies at 4.8 TB/s.
+// "the deepest K the sweeps can keep up with": depth and chunk height compete for the HBM (a level costs R + 2 rows per array),
+// and one-row chunks buy a third more depth than two-row ones at 6 % slower sweeps.  With kept rows, depth and kept rows
+// compete and the model decides.  Rates measured on MI355X (profiles/r04_stream_rates.jsonl, r04_pcie_duplex.jsonl): a row
+// crosses the link in max(up / 55 GB/s, down / 42.5 GB/s) when both directions are busy (runtime copies up, an 8-workgroup copy
+// kernel down; a pass of N rows at depth K takes N + K such steps: 3 x 64 rows at K = 50 modelled 13.8 s, measured 13.8 s);
+// sweeps on rings at 0.82 x 5.6 TB/s of moved bytes (0.77 x in one-row launches); device copies at 4.8 TB/s.
 int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_bytes, bool mse, bool wrap, int n_state, bool may_keep,
                         int64_t k_cap, int64_t *rows_out, int64_t *k_out, int64_t *res_out)
 {
@@ -359,26 +361,38 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
     const double rb = (double)row_bytes;
     const int n_in = 2 + nd * n_state, n_out = 1 + nd * n_state, moved = 3 + nd * (n_state + 1);
     k_cap = std::max<int64_t>(1, std::min<int64_t>({k_cap, 128, std::max<int64_t>(1, n_rows)}));
+    const double row_step = std::max((double)n_in * rb / 55e9, (double)n_out * rb / 42.5e9);  // one streamed row, both directions busy
     int64_t best_k = 0, best_r = 0, best_res = 0;
     double best_t = 0.0;
-    for (int64_t r : {32, 16, 8, 4, 2}) {
-        r = std::min<int64_t>(r, std::max<int64_t>(2, n_rows));
+    for (int64_t r : {32, 16, 8, 4, 2, 1}) {
+        if (r > 1) r = std::min<int64_t>(r, std::max<int64_t>(2, n_rows));
         // sweeps on rings, launches of r rows: 0.86 ms per 256 MiB plane and level whether r is 2, 4 or 8 (83 % of the resident
-        // sweep's rate; all rows resident, profiles/r04_stream_rates.jsonl)
-        const double eff = 0.82;
+        // sweep's rate; all rows resident, profiles/r04_stream_rates.jsonl), 0.92 ms in one-row launches
+        const double eff = r == 1 ? 0.77 : 0.82;
         for (int64_t k = 1; k <= k_cap; ++k) {
             const int64_t planes = stream_planes(nd, r, k, mse, wrap);
             if (planes > budget) break;
-            const int64_t res = may_keep ? std::min<int64_t>(n_rows, (budget - planes) / n_in) : 0;
-            const double t_pcie = (double)(n_rows - res) * (n_in + n_out) * rb / 60e9;
-            const double t_gpu = (double)n_rows * (double)k * moved * rb / (5.6e12 * eff) + (double)res * (n_in + n_out) * 2.0 * rb / 4.8e12;
-            const double t = std::max(t_pcie, t_gpu) / (double)k;
-            if (best_k == 0 || t < best_t * 0.999) {
-                best_t = t;
-                best_k = k;
-                best_r = r;
-                best_res = res;
-            }
+            const double t_sweeps = (double)n_rows * (double)k * moved * rb / (5.6e12 * eff);
+            auto offer = [&](int64_t res, double t_pass) {
+                const double t = t_pass / (double)k;
+                if (best_k == 0 || t < best_t * 0.999) {
+                    best_t = t;
+                    best_k = k;
+                    best_r = r;
+                    best_res = res;
+                }
+            };
+            // (a) nothing kept: the pipeline of a pass fills and drains over K rows; chained passes share that between them
+            //     (half of it counted)
+            offer(0, std::max(((double)n_rows + 0.5 * (double)std::min<int64_t>(k, n_rows)) * row_step, t_sweeps));
+            // (b) what the rest of the budget holds kept.  The streamed rows are spread over a pass that is drained, both
+            //     directions together at 60 GB/s (round 4's first model, which the kept-row measurements were planned and
+            //     verified with).  Not with one-row chunks: (1, 20, 47 kept) ran at 46.6 Gvoxel-iters/s where (2, 12, 56 kept)
+            //     runs at 57.8 (profiles/r04_stream_rates.jsonl).
+            const int64_t res = may_keep && r > 1 ? std::min<int64_t>(n_rows, (budget - planes) / n_in) : 0;
+            if (res > 0)
+                offer(res, std::max((double)(n_rows - res) * (n_in + n_out) * rb / 60e9,
+                                    t_sweeps + (double)res * (n_in + n_out) * 2.0 * rb / 4.8e12));
         }
     }
     if (best_k < 1) {

@@ -1,0 +1,16 @@
+# round 4: the planner's choices after one-row chunks were limited to runs that keep nothing
+set -o pipefail
+O=gpurun_out/r4aj; mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_gpu_run_streamed.py tests/test_gpu_outofcore.py tests/test_gpu_cubeio.py tests/test_gpu_hypothesis.py -x -q > $O/tests.log 2>&1 || { tail -30 $O/tests.log; exit 1; }
+tail -2 $O/tests.log
+export TVDN_STREAM_TIMING=1
+run() { name=$1; shift; timeout -k 10 300 python tools/stream_rates.py "$@" > $O/$name.json 2> $O/$name.err || { echo "FAILED $name"; tail -5 $O/$name.err; return 1; }; python - <<PY
+import json
+d=json.load(open("$O/$name.json"))
+print("$name", {k:d.get(k) for k in ("value","value_later_passes","stream_rows","stream_k","resident_rows","passes","passes_s","setup_s","whole_call_s","h2d_GBps","d2h_GBps","skipped")})
+PY
+}
+run hybrid_auto 64x1024x256x256 -1 -1 80 &&
+run all_auto_3p 64x1024x256x256 -1 -1 -3 0 &&
+run all_old_3p 64x1024x256x256 2 36 108 0 &&
+run all_auto_5p 64x1024x256x256 -1 -1 -5 0

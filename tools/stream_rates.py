@@ -16,11 +16,10 @@ import bench  # noqa: E402
 def main():
     shape = tuple(int(v) for v in sys.argv[1].split("x"))
     rows, k, iters = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-    if len(sys.argv) > 5:
-        os.environ["TVDN_STREAM_RESIDENT"] = sys.argv[5]
+    resident = int(sys.argv[5]) if len(sys.argv) > 5 else -1     # rows kept in HBM: -1 = as many as the plan says, 0 = none
     os.environ.setdefault("OMP_NUM_THREADS", str(bench.host_cores()))
     e = bench.api_streamed(shape, rows, k, iters, f"streamed tvdn_run {sys.argv[1]} rows {rows} k {k}", None, 0,
-                           force_stream=True)
+                           force_stream=True, resident=resident)
     print(json.dumps(e), flush=True)
 
 
