@@ -222,6 +222,10 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
 struct SlabShare;
 int run_streamed(const tvdn_run_args *a, int64_t rows, int64_t k, int64_t resident_rows, const SlabShare *slab = nullptr);
 int run_streamed_slabs(const tvdn_run_args *a, int64_t rows, int64_t k);
+// tvdn_stream.hip: the caller's result array page-locked in place (see there); TVDN_OK, or a status with which the caller keeps
+// to the pinned lanes
+int host_pin_result(void *user, size_t bytes);
+void host_unpin_result(void *user);
 int run_streamed_rank(const tvdn_run_args *a, int64_t rows, int64_t k);  // one slab of a multi-process run (tvdn_slab_io)
 // tvdn_run.hip: the big device block of a run is KEPT when the run ends (one per device) and handed to the next run it fits
 // (releasing and re-allocating tens of GiB in quick succession costs seconds); tvdn_release_cache() returns it

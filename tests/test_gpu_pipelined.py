@@ -369,3 +369,25 @@ def test_the_state_block_is_kept_between_runs_without_a_workspace(oracle, monkey
     monkeypatch.setenv("TVDN_KEEP_STATE", "0")
     assert bits_equal(_run(big, mu, 3, 0)[0], ref_big["recon"])
     assert f0 - free() <= 8 << 20
+
+
+@pytest.mark.parametrize("lanes", [False, True], ids=["page-locked-result", "lanes"])
+def test_result_rows_go_straight_into_a_page_locked_result_array(oracle, monkeypatch, lanes):
+    """The pipelined download: a helper page-locks the caller's result array where it is while the middle iterations run, and the
+    finished rows cross PCIe straight into it (arrays of 256 MiB and more; the threshold lowered here); TVDN_RESULT_LANES=1 keeps
+    the pinned lanes.  Same bits either way, the input untouched, also when the result array IS the input."""
+    import cytvdn_amd as tv
+    from cytvdn_amd import synth
+    monkeypatch.setenv("TVDN_PIN_IN_PLACE_MIN", "64K")
+    monkeypatch.setenv("TVDN_PIPELINE", "8,3,4")
+    if lanes:
+        monkeypatch.setenv("TVDN_RESULT_LANES", "1")
+    dt = np.dtype(np.float32)
+    shape = (40, 8, 32, 64)
+    x = synth.cube(shape, seed=77, dtype=dt) + dt.type(0.25)
+    keep = x.copy()
+    mu = np.array([1.0, 0.8, 0.5, 0.6], dt)
+    got = tv.denoise4D(x, mu, [7, 4], quiet=True)
+    ref = oracle.denoise(keep, mu, [7, 4], True)
+    assert bits_equal(x, keep) and bits_equal(got[0], ref["recon"])
+    np.testing.assert_allclose(got[1].astype(np.float64), ref["b_norm64"].astype(dt).astype(np.float64), rtol=1e-6)
