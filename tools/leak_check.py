@@ -22,7 +22,11 @@ mu = np.array([1, 1, .5, .5], np.float32)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 kinds = {"resident, pipelined": ({}, {}), "resident, plain order": ({"TVDN_PIPELINE": "0"}, {}),
          "device list [0, 0]": ({}, {"device": [0, 0]}), "streamed 8 rows x 3": ({"TVDN_WAVEFRONT": "8,3"}, {}),
-         "loop in Python (TVDN_LOOP=native)": ({"TVDN_LOOP": "native"}, {})}
+         "loop in Python (TVDN_LOOP=native)": ({"TVDN_LOOP": "native"}, {}),
+         # round 4: rows resident in HBM beside the streamed ones; a device list whose slabs are streamed; a stopping rule
+         "streamed 4 rows x 3, rows resident": ({"TVDN_WAVEFRONT": "4,3"}, {}),
+         "streamed device list [0, 0, 0]": ({"TVDN_WAVEFRONT": "4,3"}, {"device": [0, 0, 0]}),
+         "streamed with a stopping rule": ({"TVDN_STAGED": "8,1"}, {"stopping_relative_change": 1e-9})}
 for name, (env, kw) in kinds.items():
     os.environ.update(env)
     for _ in range(3):
