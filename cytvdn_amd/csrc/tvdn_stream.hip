@@ -575,6 +575,12 @@ struct SlabShare {
     // and what crosses process boundaries goes through the caller's hooks.
     bool local_rows = false;
     int64_t local_v0 = 0;
+    // ... of which `resident_rows` interior own rows (none within K of a face shared with a neighbour) keep their state in HBM
+    // between passes and have NO slot in the local arrays (those are packed: local slot of virtual row v = v - local_v0 -
+    // resident rows below it); their data term comes from / their result goes to the caller's own-row arrays directly
+    int64_t resident_rows = 0;
+    const char *own_data = nullptr;
+    char *own_recon = nullptr;
     bool exact_wrap = false;                             // Jia-Zhao, first row of the cube not finite (the same on every slab)
     std::function<int()> before_pass;                    // before every pass but the first: refresh the halo rows of recon / state
     std::function<int(double *)> allreduce;              // one iteration's three sums -> over all slabs (stopping rule)
@@ -590,9 +596,18 @@ namespace {
 // 35 Gvoxel-iters/s on config-5 planes where the evenly spread rows give 61; profiles/r04_stream_rates.jsonl.)
 struct RowMap {
     int64_t n0 = 1, res = 0;
-    int64_t res_below(int64_t g) const { return res >= n0 ? g : g * res / n0; }  // resident rows among [0, g)
+    int64_t e0 = 0, e1 = -1;  // the rows that may be resident: [e0, e1) (e1 < 0: the whole cube).  A slab of a multi-process run
+                              // keeps the rows its neighbours read -- K at each shared face -- on the host, where the exchange
+                              // hook finds them.
+    int64_t res_below(int64_t g) const  // resident rows among [0, g); any g, also beyond the cube (halo rows of a slab)
+    {
+        const int64_t hi = e1 < 0 ? n0 : e1, n = hi - e0;
+        if (n <= 0 || res <= 0) return 0;
+        const int64_t x = std::min(std::max(g, e0), hi) - e0;
+        return res >= n ? x : x * res / n;
+    }
     bool resident(int64_t g) const { return res_below(g + 1) > res_below(g); }
-    int64_t host_below(int64_t g) const { return g - res_below(g); }             // host rows among [0, g)
+    int64_t host_below(int64_t g) const { return g - res_below(g); }  // host rows among [0, g)
     int64_t host_rows() const { return n0 - res; }
 };
 
@@ -692,6 +707,21 @@ struct Joiner {
 
 }  // namespace
 
+// HBM bytes of everything a streamed run keeps on the device besides resident rows -- rings of R + 2 rows per level and array,
+// the data-term ring(s), two in and two out boxes, the planes of an exact wrap, the plane of zeros -- and of ONE resident row
+// (data term, recon, accumulator state).  One definition: run_streamed allocates by it, run_streamed_rank sizes a slab's
+// packed host arrays by it before run_streamed runs.
+static size_t stream_device_bytes(int nd, int n_state, bool want_mse, int64_t R, int64_t K, size_t row_bytes, size_t *per_resident_row)
+{
+    auto aligned = [](size_t b) { return (b + 255) / 256 * 256; };
+    const int n_in = 2 + nd * n_state + (want_mse ? 1 : 0), n_out = 1 + nd * n_state, n_store = 2 + nd * n_state;
+    const size_t ring_b = aligned((size_t)(R + 2) * row_bytes), oring_b = aligned((size_t)(R + K + 3) * row_bytes);
+    const size_t box_b = aligned((size_t)R * row_bytes), obox_b = aligned((size_t)(R + 1) * row_bytes), plane_b = aligned(row_bytes);
+    const size_t n_rings = (size_t)(K + 1) + (size_t)(K + 2) * nd;
+    if (per_resident_row) *per_resident_row = (size_t)n_store * plane_b;
+    return n_rings * ring_b + oring_b * (want_mse ? 2 : 1) + 2 * ((size_t)n_in * box_b + (size_t)n_out * obox_b) + 2 * (size_t)(K + 1) * plane_b + plane_b;
+}
+
 // R rows per chunk, K iteration levels per pass; `res_req` rows keep their state in HBM between passes (-1: as many as fit
 // beside the rings in 85 % of the free HBM, 0: none).
 int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, const SlabShare *sh)
@@ -752,7 +782,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
     const int64_t KX = (periodic || sh) ? K : 0, NV = N0 + 2 * KX, G0 = KX, G1 = KX + N0;
     const int64_t own0 = sh ? KX + sh->g0 : G0, own1 = sh ? KX + sh->g1 : G1;  // virtual rows whose results and sums are this run's
     const bool art_lo = periodic || (sh && sh->g0 > 0), art_hi = periodic || (sh && sh->g1 < N0);  // faces that are not the cube's own
-    if (sh) res_req = 0;
+    if (sh) res_req = sh->local_rows ? sh->resident_rows : 0;  // (a device list shares host arrays indexed by cube row: none kept)
     TVDN_HIP(hipSetDevice(device));
 
     // ---- what fits where: rings and boxes first, then as many resident rows as asked for / as fit ---------------------------
@@ -765,8 +795,8 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
     // three passes: 27 + 27 + 26) the last rows of one and the first rows of the next come down in the same chunk
     const size_t obox_b = aligned((size_t)(R + 1) * row_bytes);
     const size_t n_rings = (size_t)(K + 1) + (size_t)(K + 2) * nd;
-    const size_t dev_bytes_max = n_rings * ring_b + oring_b * (want_mse ? 2 : 1) + 2 * ((size_t)n_in * box_b + (size_t)n_out * obox_b) +
-                                 2 * (size_t)(K + 1) * plane_b + plane_b;
+    const size_t dev_bytes_max = stream_device_bytes(nd, n_state, want_mse, R, K, row_bytes, nullptr);
+    (void)n_rings;
     size_t free_b = 0, total_b = 0;
     TVDN_HIP(hipMemGetInfo(&free_b, &total_b));
     free_b += state_kept_bytes(device);  // the block the last run kept is this run's to take over or to release
@@ -782,7 +812,20 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
     // schedule walks a wrapped virtual cube whose ends are both streamed; the reference cube of an MSE trace stays on the host).
     RowMap rm;
     rm.n0 = N0;
-    if (!periodic && !want_mse && res_req != 0) {
+    if (sh) {  // a slab keeps none of the rows its neighbours read
+        rm.e0 = sh->g0 + (art_lo ? K : 0);
+        rm.e1 = std::max(rm.e0, sh->g1 - (art_hi ? K : 0));
+    }
+    if (sh && res_req > 0) {  // a slab of a multi-process run: its coordinator has sized the packed local arrays for exactly this
+        TVDN_REQUIRE(!want_mse && res_req <= rm.e1 - rm.e0, "a slab cannot keep %lld rows resident (%lld interior rows; none with an MSE trace)",
+                     (long long)res_req, (long long)(rm.e1 - rm.e0));
+        const size_t need_b = dev_bytes_max + (size_t)res_req * (size_t)n_store * plane_b;
+        if (need_b > (size_t)(0.92 * (double)free_b)) {
+            set_error("streamed slab with %lld resident rows needs %zu bytes of HBM, device %d has %zu free", (long long)res_req, need_b, device, free_b);
+            return TVDN_ERR_UNSUPPORTED;
+        }
+        rm.res = res_req;
+    } else if (!periodic && !want_mse && res_req != 0) {
         auto fits = [&](double share) -> int64_t {
             const size_t lim = (size_t)(share * (double)free_b);
             return lim > dev_bytes_max ? (int64_t)((lim - dev_bytes_max) / ((size_t)n_store * plane_b)) : 0;
@@ -997,11 +1040,13 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
     }
 
     std::thread stager([&] {  // resident rows of the data term: pageable `data` -> store, through the library's pinned lanes
-        if (sh) {
+        if (sh && RES <= 0) {
             staged_upto.store(N0);
             staged_done.raise();
             return;
         }
+        // (a slab of a multi-process run: the caller's array holds its OWN rows only, row g at + (g - first own row))
+        const char *data_rows = sh ? sh->own_data - (size_t)sh->g0 * row_bytes : (const char *)a->data;
         const int64_t piece = std::max<int64_t>(1, (int64_t)((size_t(1) << 30) / row_bytes));
         for (int64_t g = 0; g < N0 && RES > 0;) {
             if (!resident(g)) {
@@ -1010,7 +1055,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
             }
             int64_t e = g + 1;
             while (e < N0 && e - g < piece && resident(e)) ++e;
-            const int rcs = tvdn_copy_to_device(store_row(0, g), (const char *)a->data + (size_t)g * row_bytes, (size_t)(e - g) * row_bytes, device);
+            const int rcs = tvdn_copy_to_device(store_row(0, g), data_rows + (size_t)g * row_bytes, (size_t)(e - g) * row_bytes, device);
             if (rcs) {
                 staged_upto.store(-1);
                 staged_done.raise(rcs, tvdn_last_error());
@@ -1039,11 +1084,12 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
     auto wait_recon = [&](int set) -> int { return ((two_sets && set) ? recon2_ready : recon_ready).wait(); };
     // row of a host array by cube row g / virtual row v (a slab of its own process addresses its local arrays by v)
     const bool local_rows = sh && sh->local_rows;
+    auto local_slot = [&](int64_t v) { return (v - sh->local_v0) - rm.res_below(v - KX); };  // packed: resident rows have no slot
     auto hrow = [&](const HostArr &h, int64_t g, int64_t v) -> char * {
-        return local_rows ? h.p + (size_t)(v - sh->local_v0) * row_bytes : host_row(h, g);
+        return local_rows ? h.p + (size_t)local_slot(v) * row_bytes : host_row(h, g);
     };
     auto srow = [&](int set, int arr, int64_t g, int64_t v) -> char * {
-        return local_rows ? sb[set].flat[(size_t)arr] + (size_t)(v - sh->local_v0) * row_bytes : sb[set].row(arr, rm.host_below(g));
+        return local_rows ? sb[set].flat[(size_t)arr] + (size_t)local_slot(v) * row_bytes : sb[set].row(arr, rm.host_below(g));
     };
 
     tvdn_iter_args it;
@@ -1191,7 +1237,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
             if (u0 < u1) {
                 const bool from_host = host_rows_in(u0, u1) > 0;
                 if (from_host) TVDN_HIP(hipStreamWaitEvent(st.main, in_ready[h], 0));
-                if (first && RES > 0 && (rc2 = wait_staged(u1))) return rc2;
+                if (first && RES > 0 && (rc2 = wait_staged(std::min<int64_t>(N0, std::max<int64_t>(0, u1 - KX))))) return rc2;
                 cdst.clear();
                 csrc.clear();
                 // row v of ring `rg` <- array `i_store` of the store (resident rows), box `i_box` (host rows, in their order),
@@ -1860,7 +1906,8 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
         }
         int64_t e = g + 1;
         while (e < N0 && resident(e)) ++e;
-        rc = tvdn_copy_to_host((char *)a->recon_out + (size_t)g * row_bytes, store_row(1, g), (size_t)(e - g) * row_bytes, device);
+        char *home = sh ? sh->own_recon - (size_t)sh->g0 * row_bytes : (char *)a->recon_out;  // (a slab: the caller's own-row array)
+        rc = tvdn_copy_to_host(home + (size_t)g * row_bytes, store_row(1, g), (size_t)(e - g) * row_bytes, device);
         if (rc) return rc;
         g = e;
     }
@@ -2143,6 +2190,59 @@ int run_streamed_slabs(const tvdn_run_args *a, int64_t R, int64_t K)
     return TVDN_OK;
 }
 
+// What one slab of a multi-process streamed run holds where: the depth its passes settle on (= the halo rows it keeps of each
+// neighbour), the interior rows that stay resident in HBM, the rows of its packed local host arrays.  One definition: the run
+// allocates by it, tvdn_slab_host_need tells the caller beforehand (so that the ranks of one host can add up what they will
+// page-lock BEFORE any of them does).  Looks at the device's free memory unless nothing can be kept anyway.
+static int slab_shape(const tvdn_run_args *a, int64_t R, int64_t K, int64_t *kc_out, int64_t *res_out, int64_t *local_rows_out)
+{
+    const tvdn_slab_io *io = a->slab;
+    TVDN_REQUIRE(io != nullptr, "tvdn_run_args.slab is NULL");
+    TVDN_REQUIRE(a->dtype == TVDN_F32 || a->dtype == TVDN_F64, "bad dtype %d", a->dtype);
+    TVDN_REQUIRE(a->ndim == 3 || a->ndim == 4, "ndim must be 3 or 4, got %d", a->ndim);
+    TVDN_REQUIRE(R >= 1 && K >= 1, "a slab run needs stream_rows >= 1 and stream_k >= 1");
+    const int nd = a->ndim;
+    size_t row_bytes = a->dtype == TVDN_F32 ? 4 : 8;
+    for (int i = 1; i < nd; ++i) row_bytes *= (size_t)a->shape[i];
+    const int64_t own = a->shape[0], N0 = io->global_rows;
+    const int n_total = a->n_fista + a->n_plain;
+    const int n_state = a->n_fista > 0 ? 2 : 1;
+    const bool want_mse = a->mse_out != nullptr && a->reference != nullptr;
+    const bool periodic = a->bc_mode == TVDN_BC_PERIODIC;
+    // the depth run_streamed will settle on (its own arithmetic: clamp, number of passes, equal depths) = the halo rows kept
+    int64_t kc = a->use_stop ? 1 : std::min<int64_t>({K, (int64_t)std::max(n_total, 1), N0});
+    if (!a->use_stop && n_total > 0) {
+        const int64_t n_pass = (n_total + kc - 1) / kc;
+        kc = n_total / n_pass + (n_total % n_pass ? 1 : 0);
+    }
+    // Interior own rows -- none of the kc rows a neighbour reads at a shared face -- may keep their state in HBM between the
+    // passes (the resident + streamed hybrid, as on one device): as many as fit beside the rings in 85 % of the free HBM, evenly
+    // spread over the interior (stream_resident / TVDN_STREAM_RESIDENT cap the count; none with an MSE trace or periodic
+    // boundaries).  They have no slot in the local arrays, which shrink accordingly: what makes BASELINE configs[4] fit the host
+    // memory of ONE node (10 arrays x (128 + 2 k) rows of 256 MiB per rank is 3.2 TB over 8 ranks at k = 16; with 50 rows per
+    // rank resident, 2.2 TB).
+    const bool face_lo = periodic || io->row0 > 0, face_hi = periodic || io->row0 + own < N0;  // faces shared with a neighbour
+    const int64_t interior = std::max<int64_t>(0, own - (face_lo ? kc : 0) - (face_hi ? kc : 0));
+    int64_t res = 0;
+    if (!want_mse && !periodic && interior > 0 && a->stream_resident != 0 && n_total > 0) {
+        DeviceRestore restore;
+        TVDN_HIP(hipSetDevice(a->device));
+        size_t free_b = 0, total_b = 0, per_row = 0;
+        TVDN_HIP(hipMemGetInfo(&free_b, &total_b));
+        free_b += state_kept_bytes(a->device);
+        if (const size_t cap_b = env_bytes("TVDN_HBM_LIMIT")) free_b = std::min(free_b, cap_b);
+        const size_t fixed = stream_device_bytes(nd, n_state, want_mse, R, kc, row_bytes, &per_row);
+        const size_t lim = (size_t)(0.85 * (double)free_b);
+        res = lim > fixed ? std::min<int64_t>(interior, (int64_t)((lim - fixed) / per_row)) : 0;
+        if (a->stream_resident > 0) res = std::min<int64_t>(res, a->stream_resident);
+        if (const char *e = getenv("TVDN_STREAM_RESIDENT")) res = std::max<int64_t>(0, std::min<int64_t>(res, (int64_t)atoll(e)));
+    }
+    *kc_out = kc;
+    *res_out = res;
+    *local_rows_out = own + 2 * kc - res;  // packed: halo, the own rows that live on the host, halo
+    return TVDN_OK;
+}
+
 // ---- one slab of a multi-process streamed run (tvdn_slab_io) ---------------------------------------------------------------
 // The process-per-GPU form of run_streamed_slabs: this process holds ITS slab's state in page-locked arrays of halo + own +
 // halo rows (halo = the depth of a pass), streams it through its device with the same drained passes, and between passes the
@@ -2173,16 +2273,20 @@ int run_streamed_rank(const tvdn_run_args *a, int64_t R, int64_t K)
         if (a->phase_iters) a->phase_iters[0] = a->phase_iters[1] = 0;
         return TVDN_OK;
     }
-    // the depth run_streamed will settle on (its own arithmetic: clamp, number of passes, equal depths) = the halo rows kept
-    int64_t kc = a->use_stop ? 1 : std::min<int64_t>({K, (int64_t)n_total, N0});
-    if (!a->use_stop) {
-        const int64_t n_pass = (n_total + kc - 1) / kc;
-        kc = n_total / n_pass + (n_total % n_pass ? 1 : 0);
+    int64_t kc = 0, res = 0, local_rows = 0;
+    {
+        const int rcs = slab_shape(a, R, K, &kc, &res, &local_rows);
+        if (rcs) return rcs;
     }
     TVDN_REQUIRE(kc <= own, "a pass of %lld levels needs %lld rows of the neighbour's state, this slab owns %lld: stream_k must not exceed the "
                  "smallest slab's rows", (long long)kc, (long long)kc, (long long)own);
-    const int64_t local_rows = own + 2 * kc;
-    const size_t local_bytes = (size_t)local_rows * row_bytes, own_off = (size_t)kc * row_bytes, own_bytes = (size_t)own * row_bytes;
+    const bool face_lo = periodic || io->row0 > 0, face_hi = periodic || io->row0 + own < N0;  // faces shared with a neighbour
+    RowMap rm;  // the same map run_streamed will build: which own rows are resident
+    rm.n0 = N0;
+    rm.e0 = io->row0 + (face_lo ? kc : 0);
+    rm.e1 = std::max(rm.e0, io->row0 + own - (face_hi ? kc : 0));
+    rm.res = res;
+    const size_t local_bytes = (size_t)local_rows * row_bytes;
     {
         const double need = (double)(2 + nd * n_state + (want_mse ? 1 : 0)) * (double)local_bytes;
         const size_t avail = host_available_bytes();
@@ -2198,14 +2302,29 @@ int run_streamed_rank(const tvdn_run_args *a, int64_t R, int64_t K)
     if ((rc = orig.alloc(local_bytes)) || (rc = recon.alloc(local_bytes))) return rc;
     for (int i = 0; i < nd * n_state; ++i)
         if ((rc = state[(size_t)i].alloc(local_bytes))) return rc;
-    parallel_copy(orig.p + own_off, a->data, own_bytes);
+    // the own rows that live on the host <-> the caller's own-row array, run by run (local slot of own row g: kc + host rows below it)
+    auto own_rows_between = [&](char *local, char *user, bool to_local) {
+        for (int64_t g = io->row0; g < io->row0 + own;) {
+            if (rm.resident(g)) {
+                ++g;
+                continue;
+            }
+            int64_t e = g + 1;
+            while (e < io->row0 + own && !rm.resident(e)) ++e;
+            char *l = local + (size_t)(kc + (g - io->row0) - rm.res_below(g)) * row_bytes, *u = user + (size_t)(g - io->row0) * row_bytes;
+            parallel_copy(to_local ? l : u, to_local ? u : l, (size_t)(e - g) * row_bytes);
+            g = e;
+        }
+    };
+    own_rows_between(orig.p, (char *)const_cast<void *>(a->data), true);
     if (want_mse) {
         if ((rc = ref.alloc(local_bytes))) return rc;
-        parallel_copy(ref.p + own_off, a->reference, own_bytes);
+        own_rows_between(ref.p, (char *)const_cast<void *>(a->reference), true);
     }
+    const int64_t own_hi = kc + own - res;  // local slots [kc, own_hi): the own rows on the host; the kc outermost at either end are never resident
     {   // the data term's halo rows: once
         void *arr[1] = {orig.p};
-        if (io->exchange(io->user, 1, arr, local_rows, kc, kc + own, (int32_t)kc, (int64_t)row_bytes)) {
+        if (io->exchange(io->user, 1, arr, local_rows, kc, own_hi, (int32_t)kc, (int64_t)row_bytes)) {
             set_error("the exchange hook of a slab run failed (data term)");
             return TVDN_ERR_INVALID;
         }
@@ -2222,12 +2341,15 @@ int run_streamed_rank(const tvdn_run_args *a, int64_t R, int64_t K)
     sh.first_new = 0;
     sh.local_rows = true;
     sh.local_v0 = io->row0;  // virtual row = K + global row, the local arrays start K rows below the first own row
+    sh.resident_rows = res;
+    sh.own_data = (const char *)a->data;
+    sh.own_recon = (char *)a->recon_out;
     sh.exact_wrap = !periodic && io->first_row_nonfinite != 0;
     std::vector<void *> swap_arrays;
     swap_arrays.push_back(recon.p);
     for (int i = 0; i < nd * n_state; ++i) swap_arrays.push_back(state[(size_t)i].p);
     sh.before_pass = [&]() -> int {
-        if (io->exchange(io->user, (int32_t)swap_arrays.size(), swap_arrays.data(), local_rows, kc, kc + own, (int32_t)kc, (int64_t)row_bytes)) {
+        if (io->exchange(io->user, (int32_t)swap_arrays.size(), swap_arrays.data(), local_rows, kc, own_hi, (int32_t)kc, (int64_t)row_bytes)) {
             set_error("the exchange hook of a slab run failed");
             return TVDN_ERR_INVALID;
         }
@@ -2242,8 +2364,29 @@ int run_streamed_rank(const tvdn_run_args *a, int64_t R, int64_t K)
     x.slab = nullptr;
     rc = run_streamed(&x, R, K, 0, &sh);
     if (rc) return rc;
-    parallel_copy(a->recon_out, recon.p + own_off, own_bytes);
+    if (a->stats) a->stats->resident_rows = res;
+    own_rows_between(recon.p, (char *)a->recon_out, false);  // (the resident rows went home from the device: sh.own_recon)
     return TVDN_OK;
 }
 
 }  // namespace tvdn
+
+// One slab of a multi-process streamed run (args->slab set, stream_rows / stream_k > 0): the bytes of host memory this slab
+// will page-lock and the rows it will keep resident in HBM instead.  A rank's own guard knows nothing of the other ranks on its
+// host: the caller adds these up per host and refuses, on every rank alike, before any rank page-locks anything
+// (cytvdn_amd/distributed.py does).
+extern "C" int tvdn_slab_host_need(const tvdn_run_args *a, int64_t *need_bytes, int64_t *resident_rows)
+{
+    using namespace tvdn;
+    TVDN_REQUIRE(a != nullptr, "args is NULL");
+    int64_t kc = 0, res = 0, local_rows = 0;
+    const int rc = slab_shape(a, a->stream_rows, a->stream_k, &kc, &res, &local_rows);
+    if (rc) return rc;
+    size_t row_bytes = a->dtype == TVDN_F32 ? 4 : 8;
+    for (int i = 1; i < a->ndim; ++i) row_bytes *= (size_t)a->shape[i];
+    const int n_state = a->n_fista > 0 ? 2 : 1;
+    const bool want_mse = a->mse_out != nullptr && a->reference != nullptr;
+    if (need_bytes) *need_bytes = (int64_t)((size_t)(2 + a->ndim * n_state + (want_mse ? 1 : 0)) * (size_t)local_rows * row_bytes);
+    if (resident_rows) *resident_rows = res;
+    return TVDN_OK;
+}

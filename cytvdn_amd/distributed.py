@@ -33,7 +33,8 @@ def denoise_slabs(my_rows, global_shape, mu, iterations=10, FISTA=True, stopping
     `staged=(rows, k)` keeps each rank's slab in pinned host memory and streams it through the GPU, k iterations
     per PCIe round trip -- the library's streamed loop (tvdn_run with a tvdn_slab_io, csrc/tvdn_stream.hip), which
     calls back here for the k rows of state it swaps with its neighbours per pass, the sums and the wrap row; with a
-    stopping rule one iteration per pass.  For cubes whose state exceeds the HBM of the GPUs at hand (BASELINE
+    stopping rule one iteration per pass.  Interior rows of the slab stay resident in HBM as far as they fit
+    (`staged=(rows, k, n)` caps them at n): they never cross PCIe and take no page-locked host memory.  For cubes whose state exceeds the HBM of the GPUs at hand (BASELINE
     config 5).  Without it the slab must fit in HBM."""
     import torch.distributed as dist
     if not dist.is_initialized():
@@ -242,6 +243,9 @@ def _denoise_slabs_staged(my_rows, lay, dtype, mu, lam, FISTA, unacc, n_f, n_p, 
     import torch.distributed as dist
     from . import _lib
     rows, k = max(1, int(staged[0])), max(1, int(staged[1]))
+    # rows of the slab that keep their state in HBM between the passes: staged = (rows, k, n) caps them, (rows, k) = as many
+    # interior rows as fit beside the rings (none of the k a neighbour reads at a shared face; planner.plan_run says how many)
+    resident = int(staged[2]) if len(staged) > 2 and not isinstance(staged[2], str) else -1
     n = n_f + n_p
     own = my_rows.cpu().numpy() if isinstance(my_rows, torch.Tensor) else np.ascontiguousarray(my_rows)
     nd = own.ndim
@@ -257,7 +261,7 @@ def _denoise_slabs_staged(my_rows, lay, dtype, mu, lam, FISTA, unacc, n_f, n_p, 
     io.exchange, io.allreduce, io.relay_row0 = cb
     a = _lib.RunArgs(dtype=_lib.dtype_code(dtype), ndim=nd, bc_mode=int(lay.bc_mode), device=int(device),
                      n_fista=n_f if FISTA else 0, n_plain=n_p if unacc else 0, use_stop=int(stop is not None),
-                     stop=float(stop or 0.0), stream_rows=rows, stream_k=k)
+                     stop=float(stop or 0.0), stream_rows=rows, stream_k=k, stream_resident=resident)
     for i, v in enumerate(own.shape):
         a.shape[i] = int(v)
     lam_inv, lam_mu = 1.0 / lam, (lam / mu).astype(dtype)
@@ -269,6 +273,12 @@ def _denoise_slabs_staged(my_rows, lay, dtype, mu, lam, FISTA, unacc, n_f, n_p, 
     a.data, a.recon_out, a.sums_out = own.ctypes.data, recon.ctypes.data, sums.ctypes.data
     a.phase_iters = C.addressof(phases)
     a.slab = C.pointer(io)
+    # Before any rank page-locks anything: what will the ranks of each HOST page-lock together?  (The guard inside the library
+    # sees one rank; two ranks that each pass it can exhaust the memory their host -- or their control group -- allows.)
+    need, kept = C.c_int64(0), C.c_int64(0)
+    rc_need = _lib.lib().tvdn_slab_host_need(C.byref(a), C.byref(need), C.byref(kept))
+    _check_hosts_hold_the_slabs(dist, group, world, int(need.value) if rc_need == 0 else -1,
+                                None if rc_need == 0 else _lib.lib().tvdn_last_error().decode())
     rc = _lib.lib().tvdn_run(C.byref(a))
     hooks.finish()
     if hooks.error is not None:
@@ -289,6 +299,34 @@ def _denoise_slabs_staged(my_rows, lay, dtype, mu, lam, FISTA, unacc, n_f, n_p, 
     with np.errstate(divide="ignore", invalid="ignore"):
         delta = np.where(done, sums[:, 1].astype(dtype) / sums[:, 2].astype(dtype), dt(0)).astype(dtype)
     return recon, b_norm, delta
+
+
+def _check_hosts_hold_the_slabs(dist, group, world, need_bytes, error=None, host=None, available=None):
+    """Collective: every rank contributes what it will page-lock (or its error); the sums per host are held against 80 % of
+    what that host has available, and every rank raises the same MemoryError (RuntimeError for a rank's own error) if any
+    host would be overdrawn -- nobody is left waiting in a collective for a rank that has bailed out."""
+    import socket
+    from .planner import HOST_FRACTION, host_available
+    mine = {"host": host or socket.gethostname(), "need": int(need_bytes), "error": error,
+            "available": available if available is not None else host_available()}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine, group=group)
+    errors = [f"rank {r}: {e['error']}" for r, e in enumerate(everyone) if e["error"]]
+    if errors:
+        raise RuntimeError("a rank cannot size its slab: " + "; ".join(errors))
+    per_host = {}
+    for e in everyone:
+        h = per_host.setdefault(e["host"], {"need": 0, "ranks": 0, "available": e["available"]})
+        h["need"] += e["need"]
+        h["ranks"] += 1
+        if e["available"] is not None:
+            h["available"] = e["available"] if h["available"] is None else min(h["available"], e["available"])
+    over = [f"{name}: {h['ranks']} ranks x their slabs = {h['need'] / 2 ** 30:.1f} GiB of page-locked host memory, "
+            f"{HOST_FRACTION:.0%} of the {h['available'] / 2 ** 30:.1f} GiB available is {HOST_FRACTION * h['available'] / 2 ** 30:.1f} GiB"
+            for name, h in sorted(per_host.items()) if h["available"] is not None and h["need"] > HOST_FRACTION * h["available"]]
+    if over:
+        raise MemoryError("the slabs do not fit the host memory of " + "; ".join(over) + ": fewer ranks per host, a shallower k "
+                          "(2 k halo rows per array and rank), or more rows resident in HBM (planner.plan_run(..., host_bytes=...))")
 
 
 _VERIFIED = {}

@@ -173,29 +173,73 @@ def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int =
     # streamed from pinned host memory: deepest temporal blocking whose windows fit
     s = max_slabs
     rows_own = -(-n0 // s)
-    # Depth first: PCIe traffic per iteration falls as 1/k, and a streamed run is PCIe-bound until k ~ 100 (measured on
-    # config-2 planes: k 32 -> 36, k 64 -> 55-58, k 128 -> 60 Gvoxel-iters/s).  For every chunk height the deepest k
-    # whose level windows fit is taken (the need is linear in k); among those the deepest wins, taller chunks on ties.
-    budget = int(STAGING_FRACTION * avail // plane)            # planes of HBM the windows may take
-    best = None
-    for rows in (32, 16, 8, 4, 2):
-        rows = min(rows, max(2, rows_own))
-        slope = wavefront_windows(nd, rows, 2) - wavefront_windows(nd, rows, 1)
-        k = (budget - wavefront_windows(nd, rows, 0)) // slope if slope > 0 else 0
-        k = int(min(k, 1 if stop else MAX_DEPTH, max(1, rows_own)))     # a stopping rule decides after every iteration
-        if k >= 1 and wavefront_windows(nd, rows, k) <= budget and (best is None or k > best[0]):
-            best = (k, rows)
-    if best is not None:
-        k, rows = best
-        need = wavefront_windows(nd, rows, k) * plane
-        out.update(mode="wavefront" if s == 1 else "slabs+wavefront", n_slabs=s, chunk_rows=rows, k=k,
-                   bytes_per_gpu=need,
-                   host_bytes_per_rank=(2 + nd * (2 if FISTA else 1)) * (rows_own + 2 * k) * plane,   # in-place host state
-                   why=f"state of {out['state_bytes'] / 2 ** 30:.1f} GiB exceeds "
-                       f"{s} x {avail / 2 ** 30:.1f} GiB of HBM: streamed from pinned host memory")
-        if host_bytes is not None and out["host_bytes_per_rank"] > host_bytes:
-            out["why"] += " (WARNING: the pinned host state does not fit in the host memory given)"
-        return out
+    budget = int(STAGING_FRACTION * avail // plane)            # planes of HBM the rings, boxes and resident rows may take
+    n_state = 2 if FISTA else 1
+    n_in, n_out, moved = 2 + nd * n_state, 1 + nd * n_state, 3 + nd * (n_state + 1)
+    host_arrays = 2 + nd * n_state                             # data term, recon, accumulator state: updated in place
+    if s == 1:
+        # One GPU: depth first.  PCIe traffic per iteration falls as 1/k, and a streamed run is PCIe-bound until k ~ 100 (measured
+        # on config-2 planes: k 32 -> 36, k 64 -> 55-58, k 128 -> 60 Gvoxel-iters/s).  For every chunk height the deepest k whose
+        # level windows fit is taken (the need is linear in k); among those the deepest wins, taller chunks on ties.  (This
+        # decides resident against streamed; the streamed run's own shape is then the library's: tvdn_stream_plan.)
+        best = None
+        for rows in (32, 16, 8, 4, 2):
+            rows = min(rows, max(2, rows_own))
+            slope = wavefront_windows(nd, rows, 2) - wavefront_windows(nd, rows, 1)
+            k = (budget - wavefront_windows(nd, rows, 0)) // slope if slope > 0 else 0
+            k = int(min(k, 1 if stop else MAX_DEPTH, max(1, rows_own)))     # a stopping rule decides after every iteration
+            if k >= 1 and wavefront_windows(nd, rows, k) <= budget and (best is None or k > best[0]):
+                best = (k, rows)
+        if best is not None:
+            k, rows = best
+            out.update(mode="wavefront", n_slabs=1, chunk_rows=rows, k=k, resident_rows_per_rank=0,
+                       bytes_per_gpu=wavefront_windows(nd, rows, k) * plane,
+                       host_bytes_per_rank=host_arrays * (rows_own + 2 * k) * plane,   # in-place host state
+                       why=f"state of {out['state_bytes'] / 2 ** 30:.1f} GiB exceeds {avail / 2 ** 30:.1f} GiB of HBM: "
+                           f"streamed from pinned host memory")
+            if host_bytes is not None and out["host_bytes_per_rank"] > host_bytes:
+                out["why"] += " (WARNING: the pinned host state does not fit in the host memory given)"
+            return out
+    else:
+        # One slab per GPU, every rank streaming its own (denoise_slabs(staged=(rows, k)) = tvdn_run with a tvdn_slab_io).  A rank
+        # page-locks host_arrays x (own rows + 2 k halo rows - rows it keeps resident in HBM); interior rows -- none of the k
+        # at a face shared with a neighbour -- stay resident as far as the HBM beside the rings allows.  The fastest (rows, k)
+        # by the library's model (csrc/tvdn_stream.hip choose_stream_shape: a row crosses the busy link in max(up / 55,
+        # down / 42.5 GB/s), 60 GB/s both ways when rows are kept; ring sweeps at 0.82 x 5.6 TB/s, 0.77 x in one-row chunks;
+        # device copies at 4.8 TB/s) AMONG those whose page-locked state fits 80 % of the host memory n_gpus ranks share.
+        host = host_bytes if host_bytes is not None else host_available()
+        host_cap = None if host is None else HOST_FRACTION * host / s
+        rb = float(plane)
+        row_step = max(n_in * rb / 55e9, n_out * rb / 42.5e9)
+        best = fallback = None
+        for rows in (2, 1) if not stop else (2,):
+            for k in range(1, (1 if stop else min(MAX_DEPTH, rows_own)) + 1):
+                planes = wavefront_windows(nd, rows, k)
+                if planes > budget:
+                    break
+                interior = max(0, rows_own - 2 * k)
+                for res in ({0, min(interior, (budget - planes) // n_in)} if rows > 1 else {0}):
+                    streamed = rows_own - res
+                    t_pcie = streamed * (n_in + n_out) * rb / 60e9 if res else (streamed + 0.5 * min(k, streamed)) * row_step
+                    t_gpu = rows_own * k * moved * rb / (5.6e12 * (0.77 if rows == 1 else 0.82)) + res * (n_in + n_out) * 2 * rb / 4.8e12
+                    cand = (max(t_pcie, t_gpu) / k, k, rows, res, host_arrays * (rows_own + 2 * k - res) * plane)
+                    if fallback is None or cand[4] < fallback[4]:
+                        fallback = cand                                  # the plan that page-locks least, should none fit
+                    if (host_cap is None or cand[4] <= host_cap) and (best is None or cand[0] < best[0]):
+                        best = cand
+        fits_host = best is not None
+        if best is None:
+            best = fallback
+        if best is not None:
+            t, k, rows, res, host_need = best
+            out.update(mode="slabs+wavefront", n_slabs=s, chunk_rows=rows, k=k, resident_rows_per_rank=int(res),
+                       bytes_per_gpu=(wavefront_windows(nd, rows, k) + res * n_in) * plane, host_bytes_per_rank=int(host_need),
+                       seconds_per_iteration_model=t,
+                       why=f"state of {out['state_bytes'] / 2 ** 30:.1f} GiB exceeds {s} x {avail / 2 ** 30:.1f} GiB of HBM: every "
+                           f"rank streams its slab from pinned host memory, {res} of its {rows_own} rows resident in HBM")
+            if not fits_host:
+                out["why"] += " (WARNING: not even the plan that page-locks least fits the host memory these ranks share)"
+            return out
     out.update(mode="does-not-fit", bytes_per_gpu=wavefront_windows(nd, 2, 1) * plane,
                why="not even a 2-row chunk window fits in HBM")
     return out

@@ -380,6 +380,13 @@ int tvdn_run(const tvdn_run_args *args);
  * release it first. */
 int tvdn_release_cache(void);
 
+/* ABI 6.  One slab of a multi-process streamed run (args->slab set, stream_rows / stream_k > 0, stream_resident as for the run):
+ * the bytes of host memory this slab will page-lock, and the interior rows it will keep resident in HBM instead (none of the
+ * stream_k rows a neighbour reads at a shared face; as many as fit beside the rings in 85 % of the device's free memory).  The
+ * guard inside tvdn_run knows nothing of the other ranks on its host: a launcher adds these figures up per host and refuses on
+ * every rank alike BEFORE any rank page-locks anything (cytvdn_amd.distributed.denoise_slabs does).  Queries the device. */
+int tvdn_slab_host_need(const tvdn_run_args *args, int64_t *need_bytes, int64_t *resident_rows);
+
 /* ABI 6.  A streamed tvdn_run hands the page-locked host memory it allocated back in the BACKGROUND (unpinning 144 GiB takes
  * about 7 s; the call returns without waiting for it, and the process's exit handlers do wait).  tvdn_wait_background() returns
  * once every such release has finished -- for a caller that wants the memory back before it goes on, or that times a second

@@ -22,8 +22,9 @@ def _view(ptr, n, row_bytes):
     return raw.reshape(int(n), int(row_bytes))
 
 
-def run_ranks_in_threads(x, mu, n_f, n_p, world, rows, k, bc=2, stop=None, cuts=None):
-    """Returns (recon of the whole cube, sums added over the ranks, iterations run)."""
+def run_ranks_in_threads(x, mu, n_f, n_p, world, rows, k, bc=2, stop=None, cuts=None, resident=-1):
+    """Returns (recon of the whole cube, sums added over the ranks, iterations run, rows each rank kept resident in HBM).
+    `resident`: tvdn_run_args.stream_resident of every rank (-1: as many interior rows as fit, 0: none, n: at most n)."""
     from cytvdn_amd import _lib
     N0, nd, dt = x.shape[0], x.ndim, x.dtype
     cuts = cuts or [r * N0 // world for r in range(world + 1)]
@@ -95,21 +96,22 @@ def run_ranks_in_threads(x, mu, n_f, n_p, world, rows, k, bc=2, stop=None, cuts=
             cbs = (_lib.SLAB_EXCHANGE(exchange), _lib.SLAB_ALLREDUCE(allreduce), _lib.SLAB_RELAY(relay))
             io.exchange, io.allreduce, io.relay_row0 = cbs
             a = _lib.RunArgs(dtype=_lib.dtype_code(dt), ndim=nd, bc_mode=bc, device=0, n_fista=n_f, n_plain=n_p,
-                             use_stop=int(stop is not None), stop=float(stop or 0.0), stream_rows=rows, stream_k=k)
+                             use_stop=int(stop is not None), stop=float(stop or 0.0), stream_rows=rows, stream_k=k,
+                             stream_resident=resident)
             for i, v in enumerate(own.shape):
                 a.shape[i] = int(v)
             for q in range(nd):
                 a.clip[q] = float((1.0 / lam)[q])
                 a.lambda_mu[q] = float((lam / mu).astype(dt)[q])
-            recon, sums, ran = np.empty_like(own), np.zeros((max(n, 1), 3)), C.c_int32(0)
-            a.data, a.recon_out, a.sums_out = own.ctypes.data, recon.ctypes.data, sums.ctypes.data
+            recon, sums, ran, st = np.empty_like(own), np.zeros((max(n, 1), 3)), C.c_int32(0), _lib.RunStats()
+            a.data, a.recon_out, a.sums_out, a.stats = own.ctypes.data, recon.ctypes.data, sums.ctypes.data, C.addressof(st)
             a.iters_run = C.addressof(ran)
             a.slab = C.pointer(io)
             rc = _lib.lib().tvdn_run(C.byref(a))
             if rc:
                 errors.append(RuntimeError(f"rank {rank}: {_lib.lib().tvdn_last_error().decode()}"))
                 bar.abort()
-            out[rank] = (recon, sums[:n], ran.value)
+            out[rank] = (recon, sums[:n], ran.value, int(st.resident_rows))
         except Exception as e:                          # noqa: BLE001
             errors.append(e)
             bar.abort()
@@ -122,7 +124,7 @@ def run_ranks_in_threads(x, mu, n_f, n_p, world, rows, k, bc=2, stop=None, cuts=
     real = [e for e in errors if not isinstance(e, threading.BrokenBarrierError)]
     if real or errors:
         raise (real or errors)[0]
-    return np.concatenate([o[0] for o in out], axis=0), sum(o[1] for o in out), out[0][2]
+    return np.concatenate([o[0] for o in out], axis=0), sum(o[1] for o in out), out[0][2], [o[3] for o in out]
 
 
 def _cube(shape, dt, seed, bad):
@@ -133,24 +135,36 @@ def _cube(shape, dt, seed, bad):
     return x
 
 
-@pytest.mark.parametrize("world,shape,dtype,n_f,n_p,rows,k,bc,stop,bad", [
-    (2, (20, 3, 4, 8), np.float32, 9, 0, 4, 3, 2, None, False),
-    (3, (19, 6, 16), np.float64, 5, 4, 3, 4, 2, None, False),     # hybrid, uneven slabs
-    (3, (9, 3, 4, 8), np.float32, 7, 0, 2, 3, 2, None, True),      # the middle rank's halo reaches the top face: it needs row 0 too
-    (3, (18, 3, 4, 8), np.float32, 6, 0, 2, 4, 0, None, False),    # periodic: a ring of slabs
-    (2, (12, 5, 12), np.float64, 0, 8, 5, 2, 0, 0.02, False),      # periodic with a stopping rule
-    (4, (13, 2, 3, 4), np.float32, 8, 0, 1, 3, 2, 0.02, True),     # stopping rule + non-finite first row, one-row chunks
+@pytest.mark.parametrize("world,shape,dtype,n_f,n_p,rows,k,bc,stop,bad,resident", [
+    (2, (20, 3, 4, 8), np.float32, 9, 0, 4, 3, 2, None, False, -1),   # every interior row resident: rank 0 keeps 10 - 3, rank 1 too
+    (2, (20, 3, 4, 8), np.float32, 9, 0, 4, 3, 2, None, False, 0),    # none
+    (2, (20, 3, 4, 8), np.float32, 9, 0, 4, 3, 2, None, False, 4),    # some, spread over the interior
+    (3, (19, 6, 16), np.float64, 5, 4, 3, 4, 2, None, False, -1),     # hybrid, uneven slabs (the middle one has 7 - 8 < 0 interior rows)
+    (3, (30, 6, 16), np.float64, 5, 4, 3, 4, 2, None, False, 3),
+    (3, (9, 3, 4, 8), np.float32, 7, 0, 2, 3, 2, None, True, -1),     # the middle rank's halo reaches the top face: it needs row 0 too
+    (2, (16, 3, 4, 8), np.float32, 6, 0, 2, 2, 2, None, True, -1),    # non-finite first row AND row 0 itself resident on rank 0
+    (3, (18, 3, 4, 8), np.float32, 6, 0, 2, 4, 0, None, False, -1),   # periodic: a ring of slabs (keeps none)
+    (2, (12, 5, 12), np.float64, 0, 8, 5, 2, 0, 0.02, False, -1),     # periodic with a stopping rule
+    (4, (13, 2, 3, 4), np.float32, 8, 0, 1, 3, 2, 0.02, True, -1),    # stopping rule + non-finite first row, one-row chunks
+    (2, (22, 2, 3, 4), np.float32, 8, 0, 3, 1, 2, 0.02, False, 5),    # stopping rule (one level per pass) with resident rows
 ])
-def test_ranks_as_threads(oracle, world, shape, dtype, n_f, n_p, rows, k, bc, stop, bad):
+def test_ranks_as_threads(oracle, world, shape, dtype, n_f, n_p, rows, k, bc, stop, bad, resident):
     dt = np.dtype(dtype)
     nd = len(shape)
     x = _cube(shape, dt, 7, bad)
     mu = np.array([1.0, 0.7, 0.5, 1.3][:nd], dt)
     k = min(k, shape[0] // world)                      # what distributed.denoise_slabs does: a pass reads k rows of the neighbour's
-    recon, sums, ran = run_ranks_in_threads(x, mu, n_f, n_p, world, rows, k, bc, stop)
+    recon, sums, ran, kept = run_ranks_in_threads(x, mu, n_f, n_p, world, rows, k, bc, stop, resident=resident)
     its = [n_f, n_p] if (n_f and n_p) else (n_f or n_p)
     ref = oracle.denoise(x, mu, its, n_f > 0, BC_mode=bc, stopping_relative_change=stop)
     assert bits_equal(recon, ref["recon"])
+    # what each rank may keep: its own rows but the k at every face it shares with a neighbour (periodic runs keep none)
+    cuts = [r * shape[0] // world for r in range(world + 1)]
+    n_total = n_f + n_p
+    kk = 1 if stop is not None else -(-n_total // -(-n_total // min(k, n_total)))    # passes of (almost) equal depth: the deepest one
+    interior = [max(0, cuts[r + 1] - cuts[r] - (kk if r > 0 else 0) - (kk if r < world - 1 else 0)) for r in range(world)]
+    want = [0] * world if bc == 0 or resident == 0 else [i if resident < 0 else min(i, resident) for i in interior]
+    assert kept == want, (kept, want)
     if stop is None:
         assert ran == n_f + n_p
         if not bad:
@@ -164,8 +178,8 @@ def test_ranks_as_threads(oracle, world, shape, dtype, n_f, n_p, rows, k, bc, st
 @given(world=st.integers(2, 4), per=st.integers(1, 7), extra=st.integers(0, 3),
        plane=st.one_of(st.tuples(st.integers(1, 3), st.integers(2, 4), st.sampled_from([4, 8, 12])), st.tuples(st.integers(2, 5), st.sampled_from([4, 7, 16]))),
        f64=st.booleans(), bc=st.sampled_from([0, 2]), n_f=st.integers(0, 6), n_p=st.integers(0, 4), seed=st.integers(0, 2 ** 31 - 1),
-       chunk=st.integers(1, 5), k=st.integers(1, 7), bad=st.booleans(), stop=st.booleans())
-def test_ranks_as_threads_random(oracle, world, per, extra, plane, f64, bc, n_f, n_p, seed, chunk, k, bad, stop):
+       chunk=st.integers(1, 5), k=st.integers(1, 7), bad=st.booleans(), stop=st.booleans(), resident=st.sampled_from([-1, -1, 0, 1, 2, 5]))
+def test_ranks_as_threads_random(oracle, world, per, extra, plane, f64, bc, n_f, n_p, seed, chunk, k, bad, stop, resident):
     if n_f + n_p == 0:
         n_f = 2
     rows = world * per + extra
@@ -178,8 +192,9 @@ def test_ranks_as_threads_random(oracle, world, per, extra, plane, f64, bc, n_f,
     mu = np.array([1.0, 0.7, 0.5, 1.3][:nd], dt)
     stop_v = 0.02 if stop else None
     k = max(1, min(k, rows // world))
-    recon, sums, ran = run_ranks_in_threads(x, mu, n_f, n_p, world, chunk, k, bc, stop_v)
+    recon, sums, ran, kept = run_ranks_in_threads(x, mu, n_f, n_p, world, chunk, k, bc, stop_v, resident=resident)
     its = [n_f, n_p] if (n_f and n_p) else (n_f or n_p)
     ref = oracle.denoise(x, mu, its, n_f > 0, BC_mode=bc, stopping_relative_change=stop_v)
     assert bits_equal(recon, ref["recon"])
     assert ran == (ref["iters_done"] if stop_v is not None else n_f + n_p)
+    assert all(kk >= 0 for kk in kept) and (bc == 2 or not any(kept))

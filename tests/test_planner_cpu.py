@@ -28,10 +28,21 @@ def test_baseline_configs():
     one = plan_run((512, 512, 256, 256), "float32", True, 1, hbm_bytes=HBM)
     assert one["mode"] == "wavefront" and one["k"] >= 2 and one["bytes_per_gpu"] <= 0.85 * HBM
     assert one["bytes_per_gpu"] == wavefront_windows(4, one["chunk_rows"], one["k"]) * 128 * 2 ** 20
-    c5 = plan_run((1024, 1024, 256, 256), "float32", True, 8, hbm_bytes=HBM)
+    # BASELINE config 5 on the 8 GPUs of ONE node with 3 TB of host memory: every rank streams its 128-row slab, keeps the
+    # interior rows that fit beside the rings resident in HBM, and page-locks 10 arrays of (own + 2 k halo - resident) rows
+    c5 = plan_run((1024, 1024, 256, 256), "float32", True, 8, hbm_bytes=HBM, host_bytes=3 * 10 ** 12)
     assert c5["mode"] == "slabs+wavefront" and c5["n_slabs"] == 8 and c5["min_slabs_in_core"] > 8
     assert c5["state_bytes"] == 15 * 256 * GIB
-    assert c5["host_bytes_per_rank"] == 10 * (128 + 2 * c5["k"]) * 256 * 2 ** 20     # in-place host state: 10 arrays
+    res = c5["resident_rows_per_rank"]
+    assert 0 < res <= 128 - 2 * c5["k"] and c5["bytes_per_gpu"] <= 0.85 * HBM
+    assert c5["host_bytes_per_rank"] == 10 * (128 + 2 * c5["k"] - res) * 256 * 2 ** 20
+    assert 8 * c5["host_bytes_per_rank"] <= 0.8 * 3 * 10 ** 12 and "WARNING" not in c5["why"]
+    # with host memory to spare the same cube streams every row at the deepest k the rings allow (faster by the model)
+    big = plan_run((1024, 1024, 256, 256), "float32", True, 8, hbm_bytes=HBM, host_bytes=8 * 10 ** 12)
+    assert big["resident_rows_per_rank"] == 0 and big["k"] > c5["k"] and big["seconds_per_iteration_model"] < c5["seconds_per_iteration_model"]
+    assert big["host_bytes_per_rank"] == 10 * (128 + 2 * big["k"]) * 256 * 2 ** 20
+    # ... and on a host that cannot hold even the plan that page-locks least, the plan says so
+    assert "WARNING" in plan_run((1024, 1024, 256, 256), "float32", True, 8, hbm_bytes=HBM, host_bytes=2 ** 38)["why"]
 
 
 def test_stop_rule_selects_per_iteration_engine():
@@ -72,11 +83,15 @@ def test_host_available_and_the_streamed_run_guard(monkeypatch):
     if real > 8 * 2 ** 30:
         planner.check_host_fits(plan)                                  # 2.5-3.5 GiB of state: fine
     planner.check_host_fits(planner.plan_run((8, 8, 16, 16), "float32", True, 1, hbm_bytes=2 ** 30))   # in-core: nothing to check
-    # eight ranks of BASELINE config 5 on one 3 TB node do not fit with k = 30 halos (3.7 TiB); the check says so
+    # eight ranks of BASELINE config 5 planned for a host with memory to spare (every row streamed, deep halos: 4.3 TiB) do not
+    # fit one 3 TB node, and the check says so; planned for that node (rows resident in HBM, shallower halos) they do
     monkeypatch.delenv("TVDN_HOST_LIMIT")
-    c5 = planner.plan_run((1024, 1024, 256, 256), "float32", True, 8, hbm_bytes=288 * 10 ** 9)
-    assert c5["mode"] == "slabs+wavefront"
+    roomy = planner.plan_run((1024, 1024, 256, 256), "float32", True, 8, hbm_bytes=288 * 2 ** 30, host_bytes=8 * 10 ** 12)
+    assert roomy["mode"] == "slabs+wavefront"
     monkeypatch.setattr(planner, "host_available", lambda: 3 * 10 ** 12)
     with pytest.raises(MemoryError):
-        planner.check_host_fits(c5, ranks_on_host=8)
-    planner.check_host_fits(c5, ranks_on_host=4)                       # two such nodes hold it
+        planner.check_host_fits(roomy, ranks_on_host=8)
+    planner.check_host_fits(roomy, ranks_on_host=2)                    # four such nodes hold it
+    c5 = planner.plan_run((1024, 1024, 256, 256), "float32", True, 8, hbm_bytes=288 * 2 ** 30)     # (host_available() = 3 TB here)
+    assert c5["resident_rows_per_rank"] > 0
+    planner.check_host_fits(c5, ranks_on_host=8)

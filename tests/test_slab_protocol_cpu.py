@@ -267,3 +267,45 @@ def test_streamed_slab_hooks_over_gloo(world, periodic):
             assert (a[i, d:d + own] // 16 == r).all()                # own rows never written
         assert np.allclose(out[r]["sums"], [sum(1.0 + q for q in range(world)), 10.0 * world, sum(0.5 * q for q in range(world))])
     assert all((out[r]["planes"] == 7).all() for r in range(world))     # rank 0's planes, on every rank
+
+
+def _host_check_worker(rank, world, port, needs, hosts, available, outdir):
+    import torch.distributed as dist
+    from cytvdn_amd.distributed import _check_hosts_hold_the_slabs
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        try:
+            _check_hosts_hold_the_slabs(dist, None, world, needs[rank], "no device" if needs[rank] < 0 else None,
+                                        host=hosts[rank], available=available)
+            verdict = "ok"
+        except MemoryError as e:
+            verdict = "memory: " + str(e)
+        except RuntimeError as e:
+            verdict = "error: " + str(e)
+        with open(os.path.join(outdir, f"v{rank}.txt"), "w") as f:
+            f.write(verdict)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("needs,hosts,want", [
+    ((30, 30, 30), ("a", "a", "b"), "ok"),               # 60 on host a, 30 on host b, 80 of 100 allowed each
+    ((50, 50, 30), ("a", "a", "b"), "memory"),           # two ranks that would each pass overdraw host a together
+    ((50, 50, 50), ("a", "b", "c"), "ok"),               # ... and do not when every rank has a host of its own
+    ((30, -1, 30), ("a", "a", "b"), "error"),            # a rank that cannot size its slab: every rank hears of it
+])
+def test_the_ranks_of_a_host_add_up_what_they_will_page_lock(needs, hosts, want):
+    """denoise_slabs(staged=...): before any rank page-locks its slab the ranks gather what each will take
+    (tvdn_slab_host_need) and every rank reaches the SAME verdict per host -- nobody waits in a collective for a rank that has
+    bailed out, and no host (or control group) is driven out of memory by ranks that each looked at their own share only."""
+    world = len(needs)
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.start_processes(_host_check_worker, args=(world, _free_port(), needs, hosts, 100, tmp), nprocs=world, join=True,
+                           start_method="spawn")
+        verdicts = [open(os.path.join(tmp, f"v{r}.txt")).read() for r in range(world)]
+    assert all(v.startswith(want) for v in verdicts), verdicts
+    assert len(set(verdicts)) == 1                                   # the same text on every rank
+    if want == "memory":
+        assert "a: 2 ranks" in verdicts[0]

@@ -63,7 +63,10 @@ def worker(rank, world, port, a, q):
     t0 = time.perf_counter()
     # the whole call of every rank: page-locking its slab, the passes of the library's streamed loop (tvdn_run with a
     # tvdn_slab_io, csrc/tvdn_stream.hip run_streamed_rank) with the k-row state swaps between them, the release
-    recon, b_norm, _ = denoise_slabs(own, shape, mu, a.iters, FISTA=True, lam=lam, device=dev, staged=(a.rows, a.k))
+    # rows kept resident in HBM: as many as fit when every rank has its own GPU; none when the ranks share one (each would
+    # count the same free memory as its own) unless --resident says how many
+    res = a.resident if a.resident is not None else (-1 if a.gpu_per_rank else 0)
+    recon, b_norm, _ = denoise_slabs(own, shape, mu, a.iters, FISTA=True, lam=lam, device=dev, staged=(a.rows, a.k, res))
     dist.barrier()
     dt_run = time.perf_counter() - t0
     if rank == 0:
@@ -79,6 +82,7 @@ def main():
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--iters", type=int, default=64)
     ap.add_argument("--gpu-per-rank", action="store_true", help="rank r on GPU r (a multi-GPU node) instead of all ranks on GPU 0")
+    ap.add_argument("--resident", type=int, default=None, help="rows of every slab kept in HBM (-1: as many interior rows as fit)")
     a = ap.parse_args()
     import numpy as np
     import torch.multiprocessing as mp
@@ -96,7 +100,7 @@ def main():
     vox = float(np.prod(shape))
     res.update({"metric": "Gvoxel-iters/s (4D aniso FISTA, staged slabs, %d ranks %s over gloo)" % (a.ranks, "one GPU each" if a.gpu_per_rank else "on ONE GPU"),
                 "value": round(vox * a.iters / res["seconds"] / 1e9, 2), "unit": "Gvoxel-iters/s", "shape": list(shape),
-                "ranks": a.ranks, "chunk_rows": a.rows, "k": a.k, "iters": a.iters,
+                "ranks": a.ranks, "chunk_rows": a.rows, "k": a.k, "iters": a.iters, "resident_rows_asked": a.resident,
                 "state_GiB_compact": round(15 * vox * 4 / 2 ** 30, 1), "wall_s": round(time.perf_counter() - t0, 1)})
     print(json.dumps(res))
 
