@@ -273,6 +273,9 @@ typedef struct tvdn_run_stats {
  * tvdn_run_args.slab set, shape[0] / data / recon_out / reference describe this slab's OWN rows only, stream_rows / stream_k
  * must be positive and the same on every slab (stream_k at most the own rows of the smallest slab), and what crosses process
  * boundaries goes through the hooks below, all called on the calling thread, at the same points of the schedule on every slab.
+ * stream_resident: interior rows of the slab (none of the stream_k a neighbour reads at a shared face) that keep their state
+ * in HBM between the passes: -1 as many as fit, 0 none, n at most n (Jia-Zhao, no MSE trace); tvdn_slab_host_need says
+ * beforehand how many that will be and what the slab page-locks on the host.
  * sums_out / mse_out receive this slab's share (the caller adds the slabs up); bit-identical to the one-process run. */
 typedef struct tvdn_slab_io {
     int64_t global_rows;  /* rows of the WHOLE cube along axis 0                                                       */
@@ -280,10 +283,12 @@ typedef struct tvdn_slab_io {
     int32_t rank, world;  /* position in the chain (Jia-Zhao) / ring (periodic) of slabs; world >= 2                    */
     int32_t first_row_nonfinite; /* Jia-Zhao: the cube's first row holds Inf / NaN (the same value on every slab)       */
     int32_t reserved;
-    /* arrays[i]: a page-locked array of rows_per_array = depth + own + depth rows, own rows at [own_lo, own_hi).  Fill the
-     * `depth` halo rows next to every face this slab shares with a neighbour with that neighbour's outermost `depth` own rows
-     * (and give it mine).  Called once for the data term before the first pass, then before every later pass for recon and
-     * the accumulator state.  Non-zero return aborts the run. */
+    /* arrays[i]: a page-locked array of rows_per_array = depth + (own rows that live on the host) + depth rows, those own
+     * rows at [own_lo, own_hi) -- the slab's interior rows that stay resident in HBM (stream_resident) have no slot, the
+     * `depth` outermost own rows at either end always do.  Fill the `depth` halo rows next to every face this slab shares
+     * with a neighbour with that neighbour's outermost `depth` own rows (rows [own_hi - depth, own_hi) of the neighbour below,
+     * [own_lo, own_lo + depth) of the one above) and give it mine.  Called once for the data term before the first pass, then
+     * before every later pass for recon and the accumulator state.  Non-zero return aborts the run. */
     int (*exchange)(void *user, int32_t n_arrays, void *const *arrays, int64_t rows_per_array, int64_t own_lo, int64_t own_hi,
                     int32_t depth, int64_t row_bytes);
     /* sums3: one iteration's three sums over this slab -> over all slabs, in place.  Only with use_stop, once per iteration. */
