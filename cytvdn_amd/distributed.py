@@ -34,7 +34,9 @@ def denoise_slabs(my_rows, global_shape, mu, iterations=10, FISTA=True, stopping
     per PCIe round trip -- the library's streamed loop (tvdn_run with a tvdn_slab_io, csrc/tvdn_stream.hip), which
     calls back here for the k rows of state it swaps with its neighbours per pass, the sums and the wrap row; with a
     stopping rule one iteration per pass.  Interior rows of the slab stay resident in HBM as far as they fit
-    (`staged=(rows, k, n)` caps them at n): they never cross PCIe and take no page-locked host memory.  For cubes whose state exceeds the HBM of the GPUs at hand (BASELINE
+    (`staged=(rows, k, n)` caps them at n): they never cross PCIe and take no page-locked host memory.  `staged="auto"`
+    leaves the choice to `planner.plan_run` (rank 0 plans for all): resident slabs when they fit their GPUs, else the fastest
+    streamed plan the host memory holds.  For cubes whose state exceeds the HBM of the GPUs at hand (BASELINE
     config 5).  Without it the slab must fit in HBM."""
     import torch.distributed as dist
     if not dist.is_initialized():
@@ -78,6 +80,26 @@ def denoise_slabs(my_rows, global_shape, mu, iterations=10, FISTA=True, stopping
     n = n_f + n_p
     if device is None:
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if isinstance(staged, str) or staged is True:
+        # staged="auto": the planner decides -- slabs resident in HBM when they fit, else every rank streams its slab with the
+        # (rows, k, resident rows) that are fastest by the library's model AMONG those whose page-locked state fits the host
+        # these ranks share (planner.plan_run).  Rank 0 plans, everybody follows: k must be the same on every rank.
+        if staged is not True and staged != "auto":
+            raise ValueError(f"staged must be (rows, k[, resident rows]), 'auto' or None, got {staged!r}")
+        from .planner import plan_run
+        plan = [None]
+        if rank == 0:
+            p = plan_run(tuple(int(v) for v in global_shape), dtype, FISTA, world, stop=stopping_relative_change is not None,
+                         device=device)
+            plan[0] = None if p["mode"] in ("slabs", "in-core") else (p["mode"], p.get("chunk_rows"), p.get("k"),
+                                                                       p.get("resident_rows_per_rank", -1), p["why"])
+        dist.broadcast_object_list(plan, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+        if plan[0] is None:
+            staged = None
+        elif plan[0][0] not in ("slabs+wavefront", "wavefront"):
+            raise MemoryError(f"no plan for this cube on {world} ranks: {plan[0][4]}")
+        else:
+            staged = (int(plan[0][1]), int(plan[0][2]), int(plan[0][3]))
     if staged is not None:
         exact_wrap = False
         if world > 1 and int(BC_mode) == 2:       # a non-finite first row: every rank must know (see engine.py)

@@ -146,3 +146,30 @@ def test_staged_slabs_match_single_process(oracle, world, shape, dtype, its, fis
         assert np.array_equal(p["dl"] == 0, ref["delta_recon"] == 0)
         np.testing.assert_allclose(p["dl"], ref["delta_recon"], rtol=1e-4 if dt == np.float32 else 1e-12)
         np.testing.assert_allclose(p["bn"], ref["b_norm"], rtol=1e-4 if dt == np.float32 else 1e-12)
+
+
+@pytest.mark.parametrize("world,shape,dtype,its,fista,stop,hbm", [
+    (2, (40, 8, 32, 64), "float32", 9, True, None, "12M"),      # a slab's state (22 MB) exceeds what a rank may count on: streamed
+    (3, (45, 8, 32, 64), "float32", [5, 3], True, None, "12M"),  # ... three ranks, hybrid schedule
+    (2, (40, 8, 32, 64), "float32", 30, True, 0.05, "12M"),      # ... with a stopping rule: one iteration per pass
+    (2, (40, 8, 32, 64), "float32", 9, True, None, "1G"),        # room to spare: the slabs stay resident, halo rows over the wire
+], ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_staged_auto_lets_the_planner_decide(oracle, monkeypatch, world, shape, dtype, its, fista, stop, hbm):
+    """denoise_slabs(staged="auto"): rank 0 plans for everybody (planner.plan_run with the HBM each rank may count on and the
+    host memory the ranks share) -- resident slabs when they fit, else every rank streams its slab with the planned chunk
+    height, depth and resident rows.  The oracle's bits either way."""
+    import torch.multiprocessing as mp
+    from cytvdn_amd import synth
+    monkeypatch.setenv("TVDN_HBM_LIMIT", hbm)                   # (the spawned ranks inherit it)
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.start_processes(_worker_api, args=(world, _free_port(), shape, dtype, its, fista, stop, tmp, "auto"),
+                           nprocs=world, join=True, start_method="spawn")
+        parts = [np.load(os.path.join(tmp, f"r{r}.npz")) for r in range(world)]
+    x = synth.cube(shape, seed=14, dtype=dt)
+    mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
+    ref = oracle.denoise(x, mu, its, fista, stopping_relative_change=stop)
+    assert bits_equal(np.concatenate([p["own"] for p in parts]), ref["recon"])
+    for p in parts:
+        assert np.array_equal(p["dl"] == 0, ref["delta_recon"] == 0)
