@@ -29,7 +29,7 @@ EXPORTS = (
     "tvdn_ctx_timing_enable", "tvdn_ctx_timing_read", "tvdn_ctx_timing_read_each",
     "tvdn_accumulator_update", "tvdn_datacube_update", "tvdn_sum_square_error", "tvdn_iterate_fused",
     "tvdn_synth_fill", "tvdn_run", "tvdn_pipeline_plan", "tvdn_run_workspace_bytes", "tvdn_release_cache", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many", "tvdn_plan", "tvdn_copy_many", "tvdn_stream_mix", "tvdn_stream_mix_march",
-    "tvdn_stream_host_need", "tvdn_stream_plan", "tvdn_wait_background", "tvdn_slab_host_need", "tvdn_fista_ratios", "tvdn_iter_mode", "tvdn_roles_bind", "tvdn_roles_advance",
+    "tvdn_stream_host_need", "tvdn_stream_plan", "tvdn_wait_background", "tvdn_slab_host_need", "tvdn_slab_row_map", "tvdn_fista_ratios", "tvdn_iter_mode", "tvdn_roles_bind", "tvdn_roles_advance",
 )
 
 

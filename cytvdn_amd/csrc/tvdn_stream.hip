@@ -609,6 +609,12 @@ struct RowMap {
     bool resident(int64_t g) const { return res_below(g + 1) > res_below(g); }
     int64_t host_below(int64_t g) const { return g - res_below(g); }  // host rows among [0, g)
     int64_t host_rows() const { return n0 - res; }
+    // the window of a slab [g0, g1) whose passes are `depth` levels deep: everything but the `depth` rows at a shared face
+    void slab_window(int64_t g0, int64_t g1, bool shared_lo, bool shared_hi, int64_t depth)
+    {
+        e0 = g0 + (shared_lo ? depth : 0);
+        e1 = std::max(e0, g1 - (shared_hi ? depth : 0));
+    }
 };
 
 // Accumulator-state rows that live on the host, in pinned memory allocated BLOCK BY BLOCK (in row order) by a helper thread
@@ -813,8 +819,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
     RowMap rm;
     rm.n0 = N0;
     if (sh) {  // a slab keeps none of the rows its neighbours read
-        rm.e0 = sh->g0 + (art_lo ? K : 0);
-        rm.e1 = std::max(rm.e0, sh->g1 - (art_hi ? K : 0));
+        rm.slab_window(sh->g0, sh->g1, art_lo, art_hi, K);
     }
     if (sh && res_req > 0) {  // a slab of a multi-process run: its coordinator has sized the packed local arrays for exactly this
         TVDN_REQUIRE(!want_mse && res_req <= rm.e1 - rm.e0, "a slab cannot keep %lld rows resident (%lld interior rows; none with an MSE trace)",
@@ -2283,8 +2288,7 @@ int run_streamed_rank(const tvdn_run_args *a, int64_t R, int64_t K)
     const bool face_lo = periodic || io->row0 > 0, face_hi = periodic || io->row0 + own < N0;  // faces shared with a neighbour
     RowMap rm;  // the same map run_streamed will build: which own rows are resident
     rm.n0 = N0;
-    rm.e0 = io->row0 + (face_lo ? kc : 0);
-    rm.e1 = std::max(rm.e0, io->row0 + own - (face_hi ? kc : 0));
+    rm.slab_window(io->row0, io->row0 + own, face_lo, face_hi, kc);
     rm.res = res;
     const size_t local_bytes = (size_t)local_rows * row_bytes;
     {
@@ -2388,5 +2392,30 @@ extern "C" int tvdn_slab_host_need(const tvdn_run_args *a, int64_t *need_bytes, 
     const bool want_mse = a->mse_out != nullptr && a->reference != nullptr;
     if (need_bytes) *need_bytes = (int64_t)((size_t)(2 + a->ndim * n_state + (want_mse ? 1 : 0)) * (size_t)local_rows * row_bytes);
     if (resident_rows) *resident_rows = res;
+    return TVDN_OK;
+}
+
+// Which own rows of a slab stay resident and where the others sit in its packed local arrays, as arithmetic only (no device):
+// local_slot[i] for own row i = its row index in the arrays the exchange hook sees (depth halo rows first), or -1 when the row
+// is one of the `resident_rows` kept in HBM.  The very map the run uses (RowMap::slab_window); exported so that the host logic
+// can be checked without a GPU (tests/test_host_guard_cpu.py).
+extern "C" int tvdn_slab_row_map(const tvdn_run_args *a, int64_t depth, int64_t resident_rows, int64_t *local_slot)
+{
+    using namespace tvdn;
+    TVDN_REQUIRE(a != nullptr && a->slab != nullptr && local_slot != nullptr, "NULL argument");
+    const tvdn_slab_io *io = a->slab;
+    const int64_t own = a->shape[0], N0 = io->global_rows;
+    TVDN_REQUIRE(own >= 1 && io->row0 >= 0 && io->row0 + own <= N0 && depth >= 1 && resident_rows >= 0, "bad slab / depth / count");
+    const bool periodic = a->bc_mode == TVDN_BC_PERIODIC;
+    RowMap rm;
+    rm.n0 = N0;
+    rm.slab_window(io->row0, io->row0 + own, periodic || io->row0 > 0, periodic || io->row0 + own < N0, depth);
+    TVDN_REQUIRE(resident_rows <= rm.e1 - rm.e0, "%lld rows cannot be resident: the slab has %lld interior rows", (long long)resident_rows,
+                 (long long)(rm.e1 - rm.e0));
+    rm.res = resident_rows;
+    for (int64_t i = 0; i < own; ++i) {
+        const int64_t g = io->row0 + i;
+        local_slot[i] = rm.resident(g) ? -1 : depth + i - rm.res_below(g);
+    }
     return TVDN_OK;
 }

@@ -392,6 +392,11 @@ int tvdn_release_cache(void);
  * every rank alike BEFORE any rank page-locks anything (cytvdn_amd.distributed.denoise_slabs does).  Queries the device. */
 int tvdn_slab_host_need(const tvdn_run_args *args, int64_t *need_bytes, int64_t *resident_rows);
 
+/* ABI 6.  Pure arithmetic (no device): for a slab (args->slab, shape[0] = own rows, bc_mode) whose passes are `depth` levels
+ * deep and which keeps `resident_rows` interior rows in HBM, local_slot[i] of own row i = its row in the packed local arrays the
+ * exchange hook sees (depth halo rows come first), or -1 when the row is resident.  The map the run itself uses. */
+int tvdn_slab_row_map(const tvdn_run_args *args, int64_t depth, int64_t resident_rows, int64_t *local_slot);
+
 /* ABI 6.  A streamed tvdn_run hands the page-locked host memory it allocated back in the BACKGROUND (unpinning 144 GiB takes
  * about 7 s; the call returns without waiting for it, and the process's exit handlers do wait).  tvdn_wait_background() returns
  * once every such release has finished -- for a caller that wants the memory back before it goes on, or that times a second

@@ -206,3 +206,45 @@ def test_workspace_bytes_is_the_layout_of_the_resident_state():
         assert need.value == want_arrays * (-(-cube // 256) * 256 + 4096)
     a = _lib.RunArgs(dtype=0, ndim=5)
     assert _lib.lib().tvdn_run_workspace_bytes(C.byref(a), C.byref(need)) == -1
+
+
+def test_which_rows_of_a_slab_stay_resident_and_where_the_others_sit():
+    """tvdn_slab_row_map: the library's own map of a slab's rows (csrc/tvdn_stream.hip RowMap::slab_window), no GPU needed.  For
+    every cut, depth and resident count: exactly that many rows are resident, none of them among the `depth` rows at a face
+    shared with a neighbour (those are what the exchange hook sends), the host rows fill the packed local arrays without a gap
+    behind the `depth` halo rows, and the resident rows are spread evenly over the interior."""
+    import ctypes as C
+    import itertools
+    from cytvdn_amd import _lib
+    L = _lib.lib()
+    for n0, world, depth, bc in itertools.product((9, 20, 64, 128), (2, 3, 8), (1, 3, 16), (0, 2)):
+        cuts = [r * n0 // world for r in range(world + 1)]
+        for rank in range(world):
+            g0, g1 = cuts[rank], cuts[rank + 1]
+            own = g1 - g0
+            if own < depth or own < 1:
+                continue
+            shared_lo, shared_hi = bc == 0 or rank > 0, bc == 0 or rank < world - 1
+            interior = max(0, own - depth * (int(shared_lo) + int(shared_hi)))
+            io = _lib.SlabIO(global_rows=n0, row0=g0, rank=rank, world=world)
+            a = _lib.RunArgs(dtype=0, ndim=4, bc_mode=bc)
+            for i, v in enumerate((own, 2, 3, 4)):
+                a.shape[i] = v
+            a.slab = C.pointer(io)
+            slots = (C.c_int64 * own)()
+            for res in sorted({0, 1, interior // 2, interior}):
+                if res > interior:
+                    continue
+                assert L.tvdn_slab_row_map(C.byref(a), depth, res, slots) == 0, L.tvdn_last_error()
+                s = list(slots)
+                assert s.count(-1) == res
+                if shared_lo:
+                    assert all(v >= 0 for v in s[:depth])
+                if shared_hi:
+                    assert all(v >= 0 for v in s[own - depth:])
+                assert [v for v in s if v >= 0] == list(range(depth, depth + own - res))       # packed, in order, behind the halo
+                if res > 1:                                                                     # evenly spread over the interior
+                    idx = [i for i, v in enumerate(s) if v < 0]
+                    gaps = [b - a_ for a_, b in zip(idx, idx[1:])]
+                    assert max(gaps) - min(gaps) <= 1
+            assert L.tvdn_slab_row_map(C.byref(a), depth, interior + 1, slots) != 0                # more than the interior holds
