@@ -248,3 +248,46 @@ def test_which_rows_of_a_slab_stay_resident_and_where_the_others_sit():
                     gaps = [b - a_ for a_, b in zip(idx, idx[1:])]
                     assert max(gaps) - min(gaps) <= 1
             assert L.tvdn_slab_row_map(C.byref(a), depth, interior + 1, slots) != 0                # more than the interior holds
+
+
+def _stream_plan(shape, hbm, n_f=200, n_p=0, resident=-1, stop=False, bc=2, dtype=0):
+    import ctypes as C
+    from cytvdn_amd import _lib
+    a = _lib.RunArgs(dtype=dtype, ndim=len(shape), bc_mode=bc, n_fista=n_f, n_plain=n_p, use_stop=int(stop), stop=0.01,
+                     stream_rows=-1, stream_k=-1, stream_resident=resident)
+    for i, v in enumerate(shape):
+        a.shape[i] = v
+    po = _lib.StreamPlanOut()
+    rc = _lib.lib().tvdn_stream_plan(C.byref(a), int(hbm), C.byref(po))
+    return rc, po
+
+
+def test_the_streamed_plan_as_arithmetic():
+    """tvdn_stream_plan with the free HBM given is pure arithmetic (csrc/tvdn_stream.hip choose_stream_shape), checked here on
+    BASELINE's planes: what it plans fits 85 % of the HBM it was given; a rank slab of config 5 keeps nothing and takes
+    one-row chunks at the deepest k (a level costs R + 2 rows per array); half of it keeps most rows and takes two-row
+    chunks; a stopping rule means one level per pass; more HBM never plans a shallower run; a periodic cube keeps nothing."""
+    gib = 2 ** 30
+    plane = 1024 * 256 * 256 * 4
+    for hbm in (200 * gib, 268 * gib, 288 * gib):
+        rc, full = _stream_plan((128, 1024, 256, 256), hbm)
+        assert rc == 0 and full.hbm_bytes <= 0.85 * hbm
+        assert (full.rows, full.resident_rows) == (1, 0) and full.k >= 30          # PCIe-bound: depth is speed
+        assert full.host_bytes == 10 * 128 * plane                                   # data term, recon, 8 accumulator arrays
+        rc, half = _stream_plan((64, 1024, 256, 256), hbm)
+        assert rc == 0 and half.hbm_bytes <= 0.85 * hbm
+        if hbm >= 268 * gib:
+            assert half.rows == 2 and half.resident_rows >= 48 and 8 <= half.k <= 16  # most rows fit: keep them, shallow rings
+            assert half.host_bytes == 10 * (64 - half.resident_rows) * plane
+        rc, none = _stream_plan((64, 1024, 256, 256), hbm, resident=0)
+        assert rc == 0 and none.resident_rows == 0 and none.rows == 1 and none.k >= half.k and (none.k > half.k or half.resident_rows == 0)
+        rc, st = _stream_plan((64, 1024, 256, 256), hbm, stop=True)
+        assert rc == 0 and st.k == 1
+        rc, per = _stream_plan((64, 1024, 256, 256), hbm, bc=0)
+        assert rc == 0 and per.resident_rows == 0 and per.host_bytes == (2 * 9 + 1) * 64 * plane     # old and new state apart
+    ks = [_stream_plan((128, 1024, 256, 256), g * gib)[1].k for g in (80, 120, 160, 200, 240, 280)]
+    assert ks == sorted(ks) and ks[0] >= 1
+    rc, _ = _stream_plan((128, 1024, 256, 256), 8 * gib)                             # not even one level of one-row... two-row chunks
+    assert rc != 0
+    # f64 planes are twice as heavy: shallower at the same HBM
+    assert _stream_plan((128, 1024, 256, 256), 268 * gib, dtype=1)[1].k < _stream_plan((128, 1024, 256, 256), 268 * gib)[1].k
