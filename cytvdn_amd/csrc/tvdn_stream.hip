@@ -5,6 +5,24 @@
 // k iterations.  Every level keeps a ring of R+2 rows per array in HBM (tvdn_iter_args.ring_rows); the sweeps are
 // tvdn_iterate_fused launches, so the bits are those of the resident engine.  Upstream has no counterpart: its
 // arrays never leave the host (cyTVDN/cyTVDN.py:148-242 is the loop this replaces for cubes beyond HBM).
+//
+// Map of this file (it is long; every part is host code around tvdn_iterate_fused launches and copies):
+//   host memory        PinnedBuf (huge-page anonymous memory + one registration; background release), HostArr (a caller's array
+//                      page-locked in place or a packed pinned copy), StateBlocks (accumulator state pinned block by block under
+//                      the first pass), host_available_bytes / stream_host_need (the guard), tvdn_wait_background
+//   planning           stream_planes / stream_device_bytes (what a shape costs in HBM), choose_stream_shape (R, K, rows kept),
+//                      tvdn_stream_plan / tvdn_stream_host_need (the same as arithmetic for callers)
+//   who keeps what     RowMap (which rows stay resident; a slab's window), SlabShare / SlabBarrier (a slab of a device list or of a
+//                      multi-process run), slab_shape / tvdn_slab_host_need / tvdn_slab_row_map (a rank's packed local arrays)
+//   run_streamed       set-up (helper threads: `pinner` page-locks, `stager` uploads resident rows' data term; rings, boxes and
+//                      store carved from one kept device block), then one of two schedules over the same rings:
+//                        `pass`   one drained pass (periodic cubes, slabs): upload chunk c + 1, scatter into level 0, K sweeps
+//                                 trailing each other by a row, gather level K, download; exchange / all-reduce / row-0 hooks
+//                        `chain`  Jia-Zhao on one device: several passes stacked into one running row index, downloads by a
+//                                 copy kernel, the last pass sending resident rows' results home itself
+//                      then results home, stats, teardown in an order that does not stall
+//   run_streamed_slabs a device list: shared host arrays (two sets), one thread per slab, a barrier per pass, the row-0 mailbox
+//   run_streamed_rank  one process per GPU: packed local arrays of halo + host rows + halo, the caller's hooks between passes
 #include <algorithm>
 #include <atomic>
 #include <chrono>
