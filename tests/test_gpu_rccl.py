@@ -167,3 +167,75 @@ def test_rccl_data_group_beside_gloo_control_group():
     want = float(sum(range(1, world + 1)))
     for ok, t, c in res:
         assert ok == "True" and float(t) == want and float(c) == want
+
+
+def _staged_worker(rank, world, port, shape, dtype_name, bc, its, staged, stop, bad, hbm, outdir):
+    import torch
+    import torch.distributed as dist
+    from cytvdn_amd import synth
+    from cytvdn_amd.distributed import denoise_slabs, slab_rows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if hbm:
+        os.environ["TVDN_HBM_LIMIT"] = hbm
+    backend = os.environ.get("TVDN_TEST_BACKEND", "nccl")        # "gloo": the same cases with every rank on GPU 0 (a rehearsal of
+    dev = rank if backend == "nccl" else 0                       # this file's code on a one-GPU box; nothing of RCCL runs then)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        dt = np.dtype(dtype_name)
+        nd = len(shape)
+        full = synth.cube(shape, seed=91, dtype=dt) + dt.type(0.25)
+        if bad:
+            full[0, ..., 1] = np.inf
+        g0, g1 = slab_rows(shape, rank, world, bc)
+        mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+        own, bn, dl = denoise_slabs(full[g0:g1], shape, mu, its, FISTA=True, stopping_relative_change=stop, BC_mode=bc,
+                                    device=dev, staged=staged)
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), own=own, bn=bn, dl=dl)
+    finally:
+        dist.destroy_process_group()
+
+
+STAGED_CASES = [
+    # world, shape, dtype, bc, iterations, staged, stop, non-finite first row, TVDN_HBM_LIMIT
+    (2, (20, 3, 4, 8), "float32", 2, 9, (4, 3), None, False, None),            # k-row swaps over RCCL (rows staged through HBM)
+    (2, (20, 3, 4, 8), "float32", 2, 9, (4, 3, 0), None, False, None),         # ... with no row resident
+    (3, (19, 6, 16), "float64", 2, [5, 4], (3, 4), None, False, None),         # uneven slabs, hybrid schedule
+    (3, (9, 3, 4, 8), "float32", 2, 7, (2, 3), None, True, None),              # row-0 broadcast: the middle rank needs it too
+    (2, (18, 3, 4, 8), "float32", 0, 6, (2, 4), None, False, None),            # periodic: a ring of two
+    (2, (12, 5, 8, 12), "float32", 2, [30, 6], (5, 8), 0.03, False, None),     # stopping rule: an all-reduce per iteration
+    (2, (40, 8, 32, 64), "float32", 2, 9, "auto", None, False, "12M"),         # the planner decides: streamed
+    (2, (40, 8, 32, 64), "float32", 2, 9, "auto", None, False, "1G"),          # ... resident slabs
+]
+
+
+@pytest.mark.parametrize("world,shape,dtype,bc,its,staged,stop,bad,hbm", STAGED_CASES,
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_rccl_staged_slabs_match_oracle(oracle, world, shape, dtype, bc, its, staged, stop, bad, hbm):
+    """BASELINE configs[4] in structure over RCCL: every rank streams its slab through ITS GPU (tvdn_run with a tvdn_slab_io), the
+    hooks moving the k halo rows, the sums and the wrap planes device to device.  The gloo form of the same runs on one GPU in
+    tests/test_gpu_two_ranks.py; this is the one that needs the GPUs (TVDN_TEST_BACKEND=gloo rehearses this file's own code with
+    every rank on GPU 0)."""
+    if os.environ.get("TVDN_TEST_BACKEND", "nccl") == "nccl" and _ngpu() < world:
+        pytest.skip(f"needs {world} GPUs for an RCCL run (one rank per GPU); this box has {_ngpu()}")
+    import torch.multiprocessing as mp
+    from cytvdn_amd import synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.start_processes(_staged_worker, args=(world, _free_port(), shape, dtype, bc, its, staged, stop, bad, hbm, tmp),
+                           nprocs=world, join=True, start_method="spawn")
+        parts = [np.load(os.path.join(tmp, f"r{r}.npz")) for r in range(world)]
+    x = synth.cube(shape, seed=91, dtype=dt) + dt.type(0.25)
+    if bad:
+        x[0, ..., 1] = np.inf
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    ref = oracle.denoise(x, mu, its, True, BC_mode=bc, stopping_relative_change=stop)
+    assert bits_equal(np.concatenate([p["own"] for p in parts], axis=0), ref["recon"])
+    for p in parts:
+        assert np.array_equal(p["dl"] == 0, ref["delta_recon"] == 0)
