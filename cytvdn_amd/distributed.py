@@ -299,7 +299,11 @@ def _denoise_slabs_staged(my_rows, lay, dtype, mu, lam, FISTA, unacc, n_f, n_p, 
     # sees one rank; two ranks that each pass it can exhaust the memory their host -- or their control group -- allows.)
     need, kept = C.c_int64(0), C.c_int64(0)
     rc_need = _lib.lib().tvdn_slab_host_need(C.byref(a), C.byref(need), C.byref(kept))
-    _check_hosts_hold_the_slabs(dist, group, world, int(need.value) if rc_need == 0 else -1,
+    # ... plus what is not page-locked but lives in the same memory: the slab and its result as this rank holds them, and the rows
+    # of one swap in flight (gloo moves them through host memory: k rows of every swapped array, sent and received)
+    row_bytes = int(np.prod(own.shape[1:])) * own.dtype.itemsize
+    beside = own.nbytes + recon.nbytes + (0 if hooks.via_dev else 2 * k * row_bytes * (1 + nd * (2 if n_f and FISTA else 1)))
+    _check_hosts_hold_the_slabs(dist, group, world, int(need.value) + beside if rc_need == 0 else -1,
                                 None if rc_need == 0 else _lib.lib().tvdn_last_error().decode())
     rc = _lib.lib().tvdn_run(C.byref(a))
     hooks.finish()
