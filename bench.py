@@ -19,14 +19,15 @@ sweep kernel, from HIP events recorded around that kernel on its own stream duri
 The compact state of this engine moves fewer bytes than that yardstick (15 passes = 60 B per voxel); what the
 kernel really streams is reported next to it as roofline.moved_GBps / roofline.moved_frac.
 
-The headline runs on the FIRST allocation of the state: the sweep's speed depends on which physical pages that allocation got
-(same clocks, same virtual address, 11.0 ... 12.6 ms for config 2: profiles/r03_placement_audition_*.jsonl), denoise3D/4D take
-the first one below 400 iterations and audition 3-4 from there on, so a single draw is what a typical call gets.
+The state lives where the product puts it: on a virtual range composed from 1 GiB physical granules (csrc/tvdn_devmem.hip;
+`config.state_mem`).  On a plain hipMalloc block of that size the sweep's speed is a draw (11.0 ... 12.6 ms for config 2 by the
+placement, stable for as long as the block is held: profiles/r03_placement_audition_*.jsonl, r05_placement_*.jsonl); on granules
+it is 11.1 ... 11.45 ms whichever granules the block got, so there is nothing to audition and the first block is the only one.
 
 At N = 1 the line also carries
-  best_placement  the headline workload once more on the fastest of --audition-extra (4) placements, candidates' probe times
-                  listed (kept one first): the spread of the box is in the line
-  sustained     config 2 again for >= 400 steps under the product's own audition rule (3 candidates): what a long run sees
+  hipmalloc_placements  the headline workload once more on plain hipMalloc blocks (TVDN_VMM=0), the best of --audition-extra (4)
+                  placements with every candidate's probe time listed: what rounds 1-4 ran on, and the lottery of THIS box
+  sustained     config 2 again for >= 400 steps: what a long run sees
   also          the other single-GPU configurations on the same clock: BASELINE configs[2] (float64, unaccelerated), the
                 configs[0] shape on the GPU (3-D FISTA 128x128x512), ONE slab of configs[3] (66x512x256x256 local block, halo
                 edges, edge rows first, halo rows refreshed by device copies of the size of the RCCL messages) = the per-GPU term
@@ -72,11 +73,12 @@ def parse():
                     help="single GPU: run ONE interior slab of an N-slab job (halo edges, edge rows first, halo rows "
                          "refreshed by device copies) instead of the whole cube; --shape is then the GLOBAL shape")
     ap.add_argument("--audition", type=int, default=1, metavar="N",
-                    help="placements of the state tried before the HEADLINE run, the fastest kept (engine.HipBackend.best_of: "
-                         "the sweep's speed depends on which physical pages the allocation got); 1 = take the first "
-                         "allocation, which is what denoise3D/4D do below 400 iterations and therefore the default")
+                    help="placements of the state tried before the HEADLINE run, the fastest kept (engine.HipBackend.best_of); "
+                         "1 = the first, which is what the product does: a state on granules sweeps at the same speed wherever "
+                         "it lies (only with TVDN_VMM=0, on plain hipMalloc blocks, is there anything to choose)")
     ap.add_argument("--audition-extra", type=int, default=4, metavar="N",
-                    help="the headline workload once more as the best of N placements (reported as `best_placement`; 0 = skip)")
+                    help="the headline workload once more on plain hipMalloc blocks, the best of N placements (reported as "
+                         "`hipmalloc_placements`; 0 = skip)")
     ap.add_argument("--no-api", action="store_true", help="skip the API-level entries (denoise4D from NumPy, streamed runs)")
     ap.add_argument("--no-also", action="store_true", help="skip the extra single-GPU configurations")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 300-step repeat of the headline workload")
@@ -338,7 +340,7 @@ def measure(shape, dtype_name, fista, state, steps, warmup, device, rank=0, worl
         "value": round(total_vox * steps / elapsed / 1e9, 3), "unit": "Gvoxel-iters/s",
         "ms_per_step": round(elapsed / steps * 1e3, 4), "dtype": dtype_name,
         "config": {"workload": name, "global_shape": list(shape), "local_block": list(lay.local_shape), "bc_mode": 2,
-                   "state_arrays": be.n_arrays(), "state": state,
+                   "state_arrays": be.n_arrays(), "state": state, "state_mem": be.state_mem,
                    "placement_audition_ms": getattr(be, "audition", []),
                    "parallelism": f"slab{world}" if world > 1 else ("one slab of %d" % slab_of if slab_of else "single")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -619,15 +621,23 @@ def main():
 
     best_placement = None
     if headline and a.audition_extra > 1:
-        try:   # the same steps on the fastest of N placements: what denoise4D gets from 400 iterations on (driver._audition_candidates)
+        prev_vmm = os.environ.get("TVDN_VMM")
+        try:   # the same steps on plain hipMalloc blocks, the fastest of N placements: what rounds 1-4 measured, and this box's lottery
+            os.environ["TVDN_VMM"] = "0"
             r = measure(shape, dtype_name, fista, a.state, a.steps, a.warmup, local_rank, traffic_table=traffic_table,
                         audition=a.audition_extra)
             best_placement = {"value": r["value"], "ms_per_step": r["ms_per_step"], "candidates": a.audition_extra,
+                              "state_mem": r["config"]["state_mem"],
                               "placement_audition_ms": r["config"]["placement_audition_ms"],
                               "kernel_ms": r["roofline"]["kernel_ms"], "frac": r["roofline"]["frac"],
                               "moved_frac": r["roofline"]["moved_frac"]}
         except Exception as e:
             best_placement = {"error": repr(e)}
+        finally:
+            if prev_vmm is None:
+                os.environ.pop("TVDN_VMM", None)
+            else:
+                os.environ["TVDN_VMM"] = prev_vmm
 
     sustained = None
     if headline and not a.no_sustained:
@@ -710,11 +720,11 @@ def main():
             out["config"]["overlap"] = bool(overlap)
             out["transport_fallback"] = bool(fallback)
             out["preflight"] = preflight
-        out["config"]["audition_rule"] = ("headline = the FIRST allocation of the state (a single draw of the placement lottery, "
-                                          "what denoise3D/4D get below 400 iterations); the product tries 3 placements from "
-                                          "400 iterations and 4 from 800 (driver._audition_candidates)")
+        out["config"]["audition_rule"] = ("none: the state is composed from 1 GiB physical granules (state_mem), on which the sweep's time "
+                                          "does not depend on the draw; hipmalloc_placements shows plain blocks on the same box "
+                                          "(the product auditions those: 3 placements from 400 iterations, 4 from 800)")
         if best_placement is not None:
-            out["best_placement"] = best_placement
+            out["hipmalloc_placements"] = best_placement
         if sustained is not None:
             out["sustained"] = sustained
         if also is not None:

@@ -17,7 +17,7 @@ from .kernels import (accumulator_update_3D, accumulator_update_3D_FISTA, accumu
                       iso_accumulator_update_4D, iso_accumulator_update_4D_FISTA, sum_square_error_3D,
                       sum_square_error_4D)
 
-__version__ = "0.1.0"
+__version__ = "0.5.0"
 
 __all__ = [
     "denoise4D", "denoise3D", "check_memory",

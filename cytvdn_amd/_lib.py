@@ -30,7 +30,9 @@ EXPORTS = (
     "tvdn_accumulator_update", "tvdn_datacube_update", "tvdn_sum_square_error", "tvdn_iterate_fused",
     "tvdn_synth_fill", "tvdn_run", "tvdn_pipeline_plan", "tvdn_run_workspace_bytes", "tvdn_release_cache", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many", "tvdn_plan", "tvdn_copy_many", "tvdn_stream_mix", "tvdn_stream_mix_march",
     "tvdn_stream_host_need", "tvdn_stream_plan", "tvdn_wait_background", "tvdn_slab_host_need", "tvdn_slab_row_map", "tvdn_fista_ratios", "tvdn_iter_mode", "tvdn_roles_bind", "tvdn_roles_advance",
+    "tvdn_mem_alloc", "tvdn_mem_free", "tvdn_state_kept_bytes",
 )
+MEM_PLAIN, MEM_GRANULES, MEM_CALLER = 0, 1, 2
 
 
 class TvdnError(RuntimeError):
@@ -69,13 +71,14 @@ class PlanOut(C.Structure):
 
 
 class RunStats(C.Structure):
-    """struct tvdn_run_stats (include/tvdn.h, ABI 6)."""
+    """struct tvdn_run_stats (include/tvdn.h, ABI 7)."""
     _fields_ = [
         ("engine", C.c_int32), ("pipelined", C.c_int32), ("stream_rows", C.c_int32), ("stream_k", C.c_int32),
         ("resident_rows", C.c_int64), ("n_passes", C.c_int64), ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64),
         ("setup_s", C.c_double), ("loop_s", C.c_double), ("total_s", C.c_double),
         ("audition_n", C.c_int32), ("audition_kept", C.c_int32), ("audition_ms", C.c_double * 8),
         ("first_pass_s", C.c_double), ("first_pass_iters", C.c_int32), ("results_under_last_pass", C.c_int32),
+        ("state_mem", C.c_int32), ("reserved", C.c_int32),
     ]
 
     def as_dict(self):
@@ -183,9 +186,13 @@ def lib():
     L.tvdn_roles_advance.argtypes = [C.POINTER(ManyArgs), C.c_int32, C.c_double]
     L.tvdn_run_workspace_bytes.argtypes = [C.POINTER(RunArgs), C.POINTER(C.c_int64)]
     L.tvdn_pipeline_plan.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.POINTER(C.c_int32)]
+    L.tvdn_mem_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int, C.POINTER(C.c_int32)]
+    L.tvdn_mem_free.argtypes = [C.c_void_p]
+    L.tvdn_state_kept_bytes.argtypes = [C.c_int]
+    L.tvdn_state_kept_bytes.restype = C.c_int64
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header and library out of step
-    if L.tvdn_abi_version() != 6:
+    if L.tvdn_abi_version() != 7:
         raise TvdnError("libtvdn_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -264,6 +271,47 @@ def new_ctx(device: int) -> C.c_void_p:
     with torch.cuda.device(device):
         check(lib().tvdn_ctx_create(C.byref(h), int(device)))
     return h
+
+
+class DeviceBlock:
+    """`nbytes` of device memory from the library's own allocator (tvdn_mem_alloc: composed from physical granules when it
+    is big, because a hipMalloc block of tens of GiB decides by its placement how fast the sweep runs on it and such a block
+    does not -- csrc/tvdn_devmem.hip).  `tensor(dtype)` views it as a 1-D torch tensor (no copy, no
+    ownership: the block lives as long as this object, which the tensor's users must keep)."""
+
+    def __init__(self, nbytes: int, device: int):
+        p, k = C.c_void_p(), C.c_int32()
+        check(lib().tvdn_mem_alloc(C.byref(p), int(nbytes), int(device), C.byref(k)))
+        self.ptr, self.nbytes, self.device, self.kind = int(p.value), int(nbytes), int(device), int(k.value)
+
+    def tensor(self, dtype: "torch.dtype"):
+        item = torch.empty(0, dtype=dtype).element_size()
+        n = self.nbytes // item
+        typestr = {torch.float32: "<f4", torch.float64: "<f8", torch.uint8: "|u1"}[dtype]
+
+        class _View:   # the CUDA array interface (v2): what torch.as_tensor reads a raw device pointer through
+            __cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (self.ptr, False), "version": 2, "strides": None}
+        t = torch.as_tensor(_View(), device=torch.device("cuda", self.device))
+        if t.data_ptr() != self.ptr:
+            raise TvdnError("torch copied the device block instead of viewing it")
+        return t
+
+    def free(self):
+        if self.ptr:
+            p, self.ptr = self.ptr, 0
+            check(lib().tvdn_mem_free(C.c_void_p(p)))
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def state_kept_bytes(device: int) -> int:
+    """Bytes of the device block the last tvdn_run on `device` kept for the next one: used as far as the driver reports,
+    free as far as planning goes."""
+    return int(lib().tvdn_state_kept_bytes(int(device)))
 
 
 def copy_to_device(src: np.ndarray, dst) -> None:

@@ -229,9 +229,18 @@ void host_unpin_result(void *user);
 int run_streamed_rank(const tvdn_run_args *a, int64_t rows, int64_t k);  // one slab of a multi-process run (tvdn_slab_io)
 // tvdn_run.hip: the big device block of a run is KEPT when the run ends (one per device) and handed to the next run it fits
 // (releasing and re-allocating tens of GiB in quick succession costs seconds); tvdn_release_cache() returns it
-hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, bool *reused, bool any_larger);
+hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, bool *reused, bool any_larger, double spread_budget_s = 0.25);
 void state_release(void *p, size_t bytes, int device);
 size_t state_kept_bytes(int device);  // counts as free: the next run takes it over or releases it
+// tvdn_devmem.hip: device memory composed from physical granules (big blocks) or plain hipMalloc; dev_free takes either
+struct DevAllocInfo {  // what a block of granules was made from (all zero for a plain block)
+    int64_t granule_bytes;
+    int32_t granules, pool;  // granules mapped / created to choose them from
+    double seconds;
+};
+hipError_t dev_alloc(void **p, size_t bytes, int device, int *kind, double spread_budget_s = 0.25, DevAllocInfo *info = nullptr);
+hipError_t dev_free(void *p);
+int dev_kind(const void *p);
 // Entry points that select a device put the calling thread's current device back before they return: a library that leaves
 // hipSetDevice(3) behind changes where the caller's next allocation (torch's, say) lands.
 struct DeviceRestore {

@@ -37,20 +37,28 @@ static bool keep_state()
     return !(e && atoi(e) == 0) && getenv("TVDN_MALLOC") == nullptr;
 }
 
-// The state's allocation.  TVDN_MALLOC=contiguous | uncached | finegrained asks the runtime for another kind of device memory
-// (measurement: does a physically contiguous state take the placement lottery out of the sweep's speed?  DESIGN.md section 3).
-static hipError_t state_malloc(void **p, size_t bytes)
+// The state's allocation: composed from physical granules (tvdn_devmem.hip: the placement of such a block does not decide how
+// fast the sweep runs on it, that of a hipMalloc block does).  `granules` false: a plain hipMalloc block
+// (slabs on several devices, whose neighbours copy rows out of it peer to peer).  TVDN_MALLOC=contiguous | uncached |
+// finegrained asks the runtime for another kind of device memory (measurement, round 3: they draw from the same lottery).
+static hipError_t state_malloc(void **p, size_t bytes, int device, bool granules = true, double spread_budget_s = 0.25)
 {
     const char *e = getenv("TVDN_MALLOC");
     if (e && !strcmp(e, "contiguous")) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous);
     if (e && !strcmp(e, "uncached")) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached);
     if (e && !strcmp(e, "finegrained")) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
-    return hipMalloc(p, bytes);
+    if (!granules) return hipMalloc(p, bytes);
+    DevAllocInfo info;
+    const hipError_t rc = dev_alloc(p, bytes, device, nullptr, spread_budget_s, &info);
+    if (rc == hipSuccess && getenv("TVDN_RUN_TIMING") && info.granules)
+        fprintf(stderr, "tvdn_run:   state on %d granules of %lld MiB, a random subset of %d created, in %.3f s (budget for the extra ones %.2f s)\n", info.granules,
+                (long long)(info.granule_bytes >> 20), info.pool, info.seconds, spread_budget_s);
+    return rc;
 }
 
 // the kept block of `device` if it holds `bytes` without being more than a quarter larger (`any_larger`: however much larger -- a
 // streamed run carves rings out of it and is indifferent to where they lie), else a fresh allocation
-hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, bool *reused, bool any_larger)
+hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, bool *reused, bool any_larger, double spread_budget_s)
 {
     *reused = false;
     if (keep_state() && device >= 0 && device < TVDN_MAX_DEVICES) {
@@ -66,13 +74,13 @@ hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, 
             return hipSuccess;
         }
         if (c) {  // the wrong size: make room before asking for the right one
-            (void)hipFree(c);
+            (void)dev_free(c);
             c = nullptr;
             cb = 0;
         }
     }
     *got_bytes = bytes;
-    return state_malloc(p, bytes);
+    return state_malloc(p, bytes, device, true, spread_budget_s);
 }
 
 size_t state_kept_bytes(int device)
@@ -94,7 +102,7 @@ void state_release(void *p, size_t bytes, int device)
             return;
         }
     }
-    (void)hipFree(p);
+    (void)dev_free(p);
 }
 
 struct DevBuf {
@@ -110,7 +118,7 @@ struct DevBuf {
             if (keep && bytes)
                 state_release(p, bytes, device);
             else
-                (void)hipFree(p);
+                (void)dev_free(p);
         }
     }
 };
@@ -282,10 +290,16 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
         } else {
             // one slab: the block the last run of this device left behind, if it fits (StateCache above)
             if (world == 1) {
-                TVDN_HIP(state_acquire(&s.state.p, stride * (size_t)n_arr, &s.state.bytes, s.device, &state_reused, false));
+                // what a well-placed state is worth: 5 % of the time the run's sweeps will take (at 5.5 TB/s), at least 0.25 s
+                const double sweeps_s = (double)n_total * (double)(stride * (size_t)n_arr) / 5.5e12;
+                TVDN_HIP(state_acquire(&s.state.p, stride * (size_t)n_arr, &s.state.bytes, s.device, &state_reused, false, std::max(0.25, 0.05 * sweeps_s)));
                 s.state.keep = true;
             } else {
-                TVDN_HIP(state_malloc(&s.state.p, stride * (size_t)n_arr));
+                // several slabs: granules when they all share one device (logical slabs), a plain block when neighbours on
+                // other devices pull rows out of it peer to peer
+                bool one_device = true;
+                for (int q = 0; q < world; ++q) one_device = one_device && (a->n_devices == 0 || a->devices[q] == a->devices[0]);
+                TVDN_HIP(state_malloc(&s.state.p, stride * (size_t)n_arr, s.device, one_device));
             }
         }
         TVDN_HIP(hipMemsetAsync(s.state.p, 0, stride * (size_t)(n_arr - 2), s.main));
@@ -354,7 +368,12 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
         // a caller that brings the state's memory has chosen its placement: no audition then.  Nor when the block is the one
         // the last run kept (if that run auditioned, this IS its winner; allocating and freeing three more blocks of tens of
         // GiB per call is what the kept block exists to avoid) -- unless TVDN_AUDITION insists.
-        const int want = !s.state.owned ? 1 : (e ? atoi(e) : (state_reused ? 1 : (n_total >= 800 ? 4 : (n_total >= 400 ? 3 : 1))));
+        // Nor on a block made of granules: its sweep time does not depend on which granules it got (tvdn_devmem.hip), so a second
+        // candidate would cost an allocation and tell nothing; the audition remains for plain blocks (TVDN_VMM=0, a runtime
+        // without virtual-memory management).
+        const bool granules = s.state.owned && dev_kind(s.state.p) == TVDN_MEM_GRANULES;
+        stats.state_mem = !s.state.owned ? TVDN_MEM_CALLER : (granules ? TVDN_MEM_GRANULES : TVDN_MEM_PLAIN);
+        const int want = !s.state.owned ? 1 : (e ? atoi(e) : ((state_reused || granules) ? 1 : (n_total >= 800 ? 4 : (n_total >= 400 ? 3 : 1))));
         const size_t bytes = (size_t)s.rows() * row_bytes;
         const size_t stride = (bytes + 255) / 256 * 256 + 4096;
         const size_t total = stride * (size_t)(3 + nd * per_axis);
@@ -398,7 +417,7 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
                 std::unique_ptr<DevBuf> b(new DevBuf);
                 b->device = s.device;
                 b->bytes = total;
-                if (state_malloc(&b->p, total) != hipSuccess) {
+                if (state_malloc(&b->p, total, s.device) != hipSuccess) {
                     (void)hipGetLastError();
                     break;
                 }
@@ -948,6 +967,8 @@ extern "C" int tvdn_plan(int dtype, int ndim, const int64_t *shape, int fista, i
     return TVDN_OK;
 }
 
+extern "C" int64_t tvdn_state_kept_bytes(int device) { return (int64_t)tvdn::state_kept_bytes(device); }
+
 extern "C" int tvdn_release_cache(void)
 {
     tvdn::DeviceRestore restore;
@@ -955,7 +976,7 @@ extern "C" int tvdn_release_cache(void)
     for (int d = 0; d < TVDN_MAX_DEVICES; ++d)
         if (tvdn::g_state_cache.p[d]) {
             (void)hipSetDevice(d);
-            (void)hipFree(tvdn::g_state_cache.p[d]);
+            (void)tvdn::dev_free(tvdn::g_state_cache.p[d]);
             tvdn::g_state_cache.p[d] = nullptr;
             tvdn::g_state_cache.bytes[d] = 0;
         }

@@ -1014,7 +1014,10 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
     mem.device = device;
     const double t_before_block = since(t_start);
     bool block_reused = false;
-    TVDN_HIP(state_acquire(&mem.p, dev_bytes, &mem.bytes, device, &block_reused, true));
+    // (the rings of the levels are swept like a resident state, many streams at once: the same allocator, tvdn_devmem.hip)
+    TVDN_HIP(state_acquire(&mem.p, dev_bytes, &mem.bytes, device, &block_reused, true,
+                           std::max(0.25, 0.05 * (double)n_total * (double)N0 * (double)row_bytes * (double)(3 + 3 * nd) / 5.5e12)));
+    const int block_kind = dev_kind(mem.p);  // granules or a plain block (tvdn_devmem.hip)
     const double t_block = since(t_start);
     TVDN_HIP(hipMemsetAsync(mem.p, 0, ring_bytes, st.main));
     char *cursor = (char *)mem.p;
@@ -2012,6 +2015,7 @@ int run_streamed(const tvdn_run_args *a, int64_t R, int64_t K, int64_t res_req, 
         s.first_pass_s = first_pass_s;
         s.first_pass_iters = (int32_t)depth_of_pass(0);
         s.results_under_last_pass = recon_direct ? 1 : 0;
+        s.state_mem = block_kind;
     }
     return TVDN_OK;
 }

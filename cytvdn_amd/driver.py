@@ -282,6 +282,24 @@ def _library_stream_plan(datacube, n_fista, n_plain, use_stop, mse, BC_mode, dev
     return int(po.rows), int(po.k)
 
 
+def _wants_torch_workspace(args) -> bool:
+    """Small states (under 2 GiB) come from torch's caching allocator -- allocation in microseconds, and no placement to speak
+    of at that size; big ones are left to the library, which composes them from physical granules: the sweep's speed on a
+    hipMalloc block of tens of GiB (which is what torch would hand over) is a draw, on granules it is not.
+    TVDN_WORKSPACE=torch / library forces either."""
+    import ctypes as C
+    from . import _lib
+    e = os.environ.get("TVDN_WORKSPACE")
+    if e in ("torch", "library"):
+        return e == "torch"
+    if os.environ.get("TVDN_VMM", "1") == "0":
+        return True
+    need = C.c_int64(0)
+    _lib.check(_lib.lib().tvdn_run_workspace_bytes(C.byref(args), C.byref(need)))
+    from .engine import vmm_min_bytes
+    return need.value < vmm_min_bytes()
+
+
 def _state_workspace(args, shape, dtype, fista, n_total, device, BC_mode):
     """Device memory for the state of a resident tvdn_run, from torch's caching allocator: `hipMalloc` of tens of GiB
     takes 11 ms most times and 3-5 s some times, and a process that denoises cube after cube should pay that once
@@ -354,9 +372,14 @@ def _run_device_list(devices, datacube, lambdaInv, lam_mu, n_fista, n_plain, sto
     if stream is not None or len(devices) > 1 or reference_data is not None:   # (the reference cube of an MSE trace too)
         if torch.cuda.is_available():
             torch.cuda.empty_cache()       # the library allocates these runs' device memory itself: hand it what torch's cache holds
-    if len(devices) == 1 and stream is None:
+    if len(devices) == 1 and stream is None and _wants_torch_workspace(a):
         workspace = _state_workspace(a, datacube.shape, dtype, n_fista > 0, n, devices[0], BC_mode)
         a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    elif len(devices) == 1 and stream is None and torch.cuda.is_available():
+        # a big state: the library composes it from physical granules and keeps the block for the next call (csrc/tvdn_devmem.hip,
+        # tvdn_release_cache) -- what torch's cache holds from other work goes back to the driver first, so that it can
+        if torch.cuda.memory_reserved(int(devices[0])) > (1 << 30):
+            torch.cuda.empty_cache()
     if progress is not None:
         hook = C.CFUNCTYPE(None, C.c_int32, C.c_void_p)(lambda slots_done, _user: progress(int(slots_done)))
         a.progress = C.cast(hook, C.c_void_p)

@@ -44,6 +44,12 @@ DEFAULT_STATE = os.environ.get("TVDN_STATE", "compact")
 ARRAY_SKEW = 4096   # bytes by which consecutive state arrays are staggered inside the state allocation
 
 
+def vmm_min_bytes() -> int:
+    """States from this size on are composed from physical granules: csrc/tvdn_devmem.hip's own threshold (2 GiB;
+    TVDN_VMM_MIN_MIB overrides both, tests use it to put small cubes on granules)."""
+    return int(os.environ.get("TVDN_VMM_MIN_MIB", "2048")) << 20
+
+
 def fista_ratios(n: int) -> np.ndarray:
     """(tk-1)/tk_new for iterations 0..n-1, float64 on the host (reference cyTVDN.py:153-156): the library's own
     recurrence (_lib.fista_ratios), so that this schedule is defined once for every engine."""
@@ -227,6 +233,11 @@ class HipBackend:
                 if slab.dtype != tdt or slab.numel() < n_arr * stride_el:
                     raise ValueError(f"slab must hold {n_arr * stride_el} elements of {tdt}")
                 self._slab = slab[:n_arr * stride_el]
+            elif n_arr * stride_el * item >= vmm_min_bytes() and os.environ.get("TVDN_VMM", "1") != "0":
+                # a big state: the library's allocator (granules; how fast the sweep runs on a hipMalloc block of this size
+                # is decided by where it landed -- csrc/tvdn_devmem.hip).  The block outlives the tensor views below.
+                self._block = _lib.DeviceBlock(n_arr * stride_el * item, self.device)
+                self._slab = self._block.tensor(tdt)
             else:
                 self._slab = torch.empty(n_arr * stride_el, dtype=tdt, device=dev)
             self._slab[:(n_arr - 2) * stride_el].zero_()
@@ -267,11 +278,35 @@ class HipBackend:
         a.lo_mode, a.hi_mode, a.bc_mode = layout.lo_mode, layout.hi_mode, layout.bc_mode
         a.orig = self.orig.data_ptr()
 
+    @property
+    def state_mem(self) -> str:
+        """What the state's block is made of: "granules" (tvdn_mem_alloc composed it), "plain" (one hipMalloc block: torch's
+        allocator, or the library's below its threshold / without virtual-memory management) or "caller" (`slab=`)."""
+        b = getattr(self, "_block", None)
+        if b is not None:
+            return "granules" if b.kind == _lib.MEM_GRANULES else "plain"
+        return "plain"
+
+    def release(self):
+        """Give the state's device memory back now (the views into it must not be used afterwards)."""
+        for name in ("S", "b", "d", "recon", "orig", "_slab", "_parts"):
+            if hasattr(self, name):
+                setattr(self, name, None)
+        b = getattr(self, "_block", None)
+        if b is not None:
+            torch.cuda.current_stream(self.device).synchronize()
+            b.free()
+            self._block = None
+
     def __del__(self):
         try:
             if getattr(self, "_private_ctx", False) and self.ctx:
                 _lib.lib().tvdn_ctx_destroy(self.ctx)
                 self.ctx = None
+        except Exception:
+            pass
+        try:
+            self.release()
         except Exception:
             pass
 
@@ -400,7 +435,10 @@ class HipBackend:
     @classmethod
     def best_of(cls, candidates: int, layout, dtype, fista, device: int = 0, hbm_fraction: float = 0.8,
                 release_losers: bool = True, **kw):
-        """The sweep's speed depends on WHERE in HBM its state landed: with identical clocks, the same 60 GiB state of
+        """(Round 5: states of 2 GiB and more are composed from physical granules, csrc/tvdn_devmem.hip, whose sweep time does not
+        depend on the draw -- for them this returns the first candidate, unless TVDN_AUDITION insists.  What follows is the
+        story of plain hipMalloc blocks, which remains true of them.)
+        The sweep's speed depends on WHERE in HBM its state landed: with identical clocks, the same 60 GiB state of
         BASELINE config 2 sweeps in 11.2, 12.1 or 12.6 ms depending on the physical pages one hipMalloc happened to get
         (three states held at once in one process, timed in turn, each reproducible: profiles/r03_placement_audition_*.jsonl;
         plain per-array streaming is equally fast on all of them, so it is the relation BETWEEN the 15 streams -- DRAM
@@ -423,6 +461,8 @@ class HipBackend:
                     break
             be = cls(layout, dtype, fista, device=device, **kw)
             held.append(be)
+            if be.state_mem == "granules" and os.environ.get("TVDN_AUDITION") is None:
+                break     # a state on granules sweeps at the same speed whichever granules it got: nothing to audition
             if candidates > 1:
                 times.append(be.probe_ms())
         if len(held) == 1:

@@ -52,6 +52,11 @@ def hbm_available(device: int = 0, hbm_bytes: int = None):
         if torch.cuda.is_available():
             free = int(torch.cuda.mem_get_info(device)[0])
             free += max(0, int(torch.cuda.memory_reserved(device)) - int(torch.cuda.memory_allocated(device)))
+            # ... and the block the library's last run on this device kept for the next one (tvdn_release_cache): a streamed
+            # run keeps its rings and resident rows, ~85 % of the HBM -- counted as used, the next plan saw 15 % free, sent
+            # a cube that fits to the streamed engine or refused one that streams (planner.py:53)
+            from . import _lib
+            free += _lib.state_kept_bytes(device)
     except Exception:
         free = None
     cap = os.environ.get("TVDN_HBM_LIMIT")

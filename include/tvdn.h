@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TVDN_ABI_VERSION 6
+#define TVDN_ABI_VERSION 7
 
 typedef enum tvdn_dtype { TVDN_F32 = 0, TVDN_F64 = 1 } tvdn_dtype;
 
@@ -265,6 +265,9 @@ typedef struct tvdn_run_stats {
     int32_t first_pass_iters; /* ... and the iterations it held                                                     */
     int32_t results_under_last_pass; /* streamed with resident rows: 1 when their results crossed PCIe during the last pass
                               (result array page-locked in place, no stopping rule) instead of in one piece after it   */
+    int32_t state_mem;     /* ABI 7.  TVDN_MEM_*: what the run's big device block (the state, or the rings and kept rows
+                              of a streamed run) is made of; TVDN_MEM_CALLER for a caller's workspace                  */
+    int32_t reserved;
 } tvdn_run_stats;
 
 /* ABI 6.  One slab of a cube that several PROCESSES denoise together, each streaming ITS slab through its GPU from its own
@@ -373,6 +376,26 @@ typedef struct tvdn_run_args {
 } tvdn_run_args;
 
 int tvdn_run(const tvdn_run_args *args);
+
+/* ABI 7.  Device memory for a state, composed from physical granules.  The sweep's speed on a state of tens of GiB depends
+ * on the allocation it lives in: hipMalloc states of BASELINE configs[1] sweep in 11.0 ... 12.6 ms by the draw, each
+ * reproducibly for as long as it is held, while the same state on a virtual range mapped from separately created 1 GiB
+ * granules (hipMemCreate / hipMemMap) stays within 11.07 ... 11.45 ms whichever granules it gets and in whatever order
+ * (csrc/tvdn_devmem.hip).  tvdn_run takes its own device memory from here; a caller that keeps a state
+ * of its own (cytvdn_amd/engine.py does, for one slab of a multi-process run) should too.  Blocks under 2 GiB, and every
+ * block when the runtime has no virtual-memory management (or TVDN_VMM=0 is set), are plain hipMalloc blocks: *kind says
+ * which it was.  The reference has no counterpart (NumPy allocates its state, cyTVDN/cyTVDN.py:131-145).
+ * tvdn_mem_free takes pointers of either kind (it synchronises the device, as hipFree does). */
+#define TVDN_MEM_PLAIN 0
+#define TVDN_MEM_GRANULES 1
+#define TVDN_MEM_CALLER 2
+int tvdn_mem_alloc(void **ptr, int64_t bytes, int device, int32_t *kind);
+int tvdn_mem_free(void *ptr);
+
+/* ABI 7.  Bytes of the block the last one-device tvdn_run on `device` kept for the next one (0: none): device memory that
+ * hipMemGetInfo reports as used but that the next tvdn_run takes over or releases, i.e. free for planning purposes
+ * (cytvdn_amd/planner.py adds it to what the device has free; tvdn_plan and tvdn_stream_plan do so themselves). */
+int64_t tvdn_state_kept_bytes(int device);
 
 /* A one-device tvdn_run that allocates its own device memory -- the state of a resident run, or the rings, boxes and
  * resident rows of a streamed one -- KEEPS that block when it returns (one per device) and hands it to the next run it fits
