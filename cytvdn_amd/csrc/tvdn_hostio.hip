@@ -47,12 +47,18 @@ static std::atomic<int> g_cap_users{0};
 // set/reset pair let the first run to finish lift it for the others mid-flight).  n > 0 takes a hold, n == 0 drops one.
 void io_cap_lanes(int n)
 {
+    // one lock for count and cap together: a release that sees "last user" and another thread's fresh hold must not interleave
+    // (the drop of a cap that had just been taken again)
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     if (n > 0) {
         g_lanes_cap.store(n);
         g_cap_users.fetch_add(1);
-    } else if (g_cap_users.fetch_sub(1) <= 1) {
+    } else if (g_cap_users.load() <= 1) {
         g_cap_users.store(0);
         g_lanes_cap.store(0);
+    } else {
+        g_cap_users.fetch_sub(1);
     }
 }
 

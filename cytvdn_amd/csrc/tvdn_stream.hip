@@ -204,10 +204,18 @@ struct HostArr {
             return TVDN_OK;
         }
         (void)hipGetLastError();
-        if (e == hipErrorHostMemoryAlreadyRegistered) {  // already page-locked by the caller
-            p = (char *)user;
-            cube_rows = true;
-            return TVDN_OK;
+        if (e == hipErrorHostMemoryAlreadyRegistered) {
+            // The runtime says so for ANY overlap with an existing registration, a partial one too -- and the copy kernels
+            // write these addresses straight from the GPU: an unregistered page among them is a fault that kills the process
+            // (no XNACK).  Page-locked by the caller only if the device can address its first AND last byte; else a pinned
+            // copy of our own.
+            void *d0 = nullptr, *d1 = nullptr;
+            if (hipHostGetDevicePointer(&d0, user, 0) == hipSuccess && hipHostGetDevicePointer(&d1, (char *)user + bytes - 1, 0) == hipSuccess) {
+                p = (char *)user;
+                cube_rows = true;
+                return TVDN_OK;
+            }
+            (void)hipGetLastError();
         }
         return alloc(packed_bytes);
     }
@@ -2313,21 +2321,40 @@ int run_streamed_rank(const tvdn_run_args *a, int64_t R, int64_t K)
     rm.slab_window(io->row0, io->row0 + own, face_lo, face_hi, kc);
     rm.res = res;
     const size_t local_bytes = (size_t)local_rows * row_bytes;
+    // What can fail on ONE rank only -- its host's memory, a page-locked allocation -- fails before the first exchange, and the
+    // ranks agree on it through the all-reduce hook: a rank that returned alone would leave its peers waiting inside the
+    // exchange until the communicator's timeout instead of every rank raising the same error.
+    int rc_local = TVDN_OK;
     {
         const double need = (double)(2 + nd * n_state + (want_mse ? 1 : 0)) * (double)local_bytes;
         const size_t avail = host_available_bytes();
         if (avail == 0 || need > 0.8 * (double)avail) {
             set_error("this slab's state needs %.0f bytes of page-locked host memory, which exceeds what the host has available (%zu bytes, "
                       "of which 80 %% are used at most; every rank on this host asks for its own)", need, avail);
-            return TVDN_ERR_UNSUPPORTED;
+            rc_local = TVDN_ERR_UNSUPPORTED;
         }
     }
     PinnedBuf orig, recon, ref;
     std::unique_ptr<PinnedBuf[]> state(new PinnedBuf[(size_t)nd * n_state]);
-    int rc;
-    if ((rc = orig.alloc(local_bytes)) || (rc = recon.alloc(local_bytes))) return rc;
-    for (int i = 0; i < nd * n_state; ++i)
-        if ((rc = state[(size_t)i].alloc(local_bytes))) return rc;
+    int rc = TVDN_OK;
+    if (!rc_local) rc_local = orig.alloc(local_bytes);
+    if (!rc_local) rc_local = recon.alloc(local_bytes);
+    for (int i = 0; i < nd * n_state && !rc_local; ++i) rc_local = state[(size_t)i].alloc(local_bytes);
+    if (!rc_local && want_mse) rc_local = ref.alloc(local_bytes);
+    if (io->allreduce) {
+        double s3[3] = {rc_local ? 1.0 : 0.0, 0.0, 0.0};
+        const std::string mine = rc_local ? tvdn_last_error() : "";
+        if (io->allreduce(io->user, s3)) {
+            set_error("the all-reduce hook of a slab run failed (set-up status)");
+            return TVDN_ERR_INVALID;
+        }
+        if (s3[0] > 0.0 && !rc_local) {
+            set_error("%d rank(s) of this run could not set up their slab (host memory or a page-locked allocation): every rank stops", (int)s3[0]);
+            return TVDN_ERR_UNSUPPORTED;
+        }
+        if (rc_local) set_error("%s", mine.c_str());
+    }
+    if (rc_local) return rc_local;
     // the own rows that live on the host <-> the caller's own-row array, run by run (local slot of own row g: kc + host rows below it)
     auto own_rows_between = [&](char *local, char *user, bool to_local) {
         for (int64_t g = io->row0; g < io->row0 + own;) {
@@ -2343,10 +2370,7 @@ int run_streamed_rank(const tvdn_run_args *a, int64_t R, int64_t K)
         }
     };
     own_rows_between(orig.p, (char *)const_cast<void *>(a->data), true);
-    if (want_mse) {
-        if ((rc = ref.alloc(local_bytes))) return rc;
-        own_rows_between(ref.p, (char *)const_cast<void *>(a->reference), true);
-    }
+    if (want_mse) own_rows_between(ref.p, (char *)const_cast<void *>(a->reference), true);
     const int64_t own_hi = kc + own - res;  // local slots [kc, own_hi): the own rows on the host; the kc outermost at either end are never resident
     {   // the data term's halo rows: once
         void *arr[1] = {orig.p};

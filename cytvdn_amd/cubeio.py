@@ -174,7 +174,11 @@ def denoise_file(input_path, output_path, mu, iterations=10, FISTA=True, stoppin
         # The engines see arrays: a stored cube of the compute dtype IS one (its memory map, read in place), any other is
         # converted block by block (mpi.py:217-239 converts per tile); the result lands in the output file's own memory map
         # where the format has one (.npy / raw), else it is written block by block (HDF5 / EMD).
-        if isinstance(src.src, np.ndarray) and src.src.dtype == dt and src.src.flags["C_CONTIGUOUS"]:
+        in_place = isinstance(src.src, np.ndarray) and src.src.dtype == dt and src.src.flags["C_CONTIGUOUS"]
+        out_mapped = os.path.splitext(str(output_path))[1].lower() not in _H5_EXT
+        _check_host_holds_the_copies(src.shape, dt, nd, FISTA, stopping_relative_change is not None, device,
+                                     converted=not in_place, result_in_ram=not out_mapped)
+        if in_place:
             x = src.src
         else:
             x = np.empty(src.shape, dt)
@@ -195,6 +199,36 @@ def denoise_file(input_path, output_path, mu, iterations=10, FISTA=True, stoppin
     finally:
         src.close()
     return res[1], res[2]
+
+
+def _check_host_holds_the_copies(shape, dt, nd, fista, stop, device, converted: bool, result_in_ram: bool) -> None:
+    """A stored cube of another dtype (uint16 detector counts, say) is converted into ONE host array of the compute dtype, and a
+    result bound for HDF5 / EMD is held in RAM until it is written block by block: up to two more cubes of pageable memory that
+    the streamed engine's own guard (tvdn_stream_host_need) knows nothing of -- it could pass, and the kernel then kill the
+    process.  Add them to what the run page-locks and refuse BEFORE anything is allocated."""
+    from . import planner
+    cube = int(np.prod(shape)) * np.dtype(dt).itemsize
+    extra = cube * (int(bool(converted)) + int(bool(result_in_ram)))
+    if not extra:
+        return
+    avail = planner.host_available()
+    if avail is None:
+        return
+    pinned = 0
+    try:
+        dev = int(device[0]) if isinstance(device, (list, tuple)) and len(device) else (0 if device is None else int(device))
+        plan = planner.plan_run(tuple(shape), dt, bool(fista), 1, stop=bool(stop), device=dev)
+        pinned = int(plan.get("host_bytes_per_rank") or 0)
+    except Exception:
+        pinned = 0                      # no GPU to ask (the run itself will say so): judge the copies alone
+    if extra + pinned > planner.HOST_FRACTION * avail:
+        what = " + ".join(w for w, on in (("the cube converted to %s" % np.dtype(dt).name, converted),
+                                          ("the result held for the HDF5 writer", result_in_ram)) if on)
+        raise MemoryError(f"denoise_file would hold {extra / 2 ** 30:.1f} GiB of host memory for {what}"
+                          + (f" beside {pinned / 2 ** 30:.1f} GiB of page-locked state of the streamed run" if pinned else "")
+                          + f", more than {planner.HOST_FRACTION:.0%} of the {avail / 2 ** 30:.1f} GiB this host has available: store the "
+                          "cube in the compute dtype (it is then read in place through its memory map) and write .npy / raw "
+                          "output (written in place), or use more nodes")
 
 
 __all__ = ["open_cube", "CubeWriter", "LazyCube", "denoise_file", "EMD_DATA"]

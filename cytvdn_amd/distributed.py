@@ -185,23 +185,48 @@ class _RankHooks:
     def _snd(self, t):
         return t.to(self.cuda) if self.via_dev else t.contiguous()
 
+    STAGE_BYTES = 512 << 20      # RCCL: device memory per direction that a shift may stage rows through
+
     def _shift(self, views, take, put, to, frm, tag0):
-        """Everybody sends rows `take` of every array to `to` and receives rows `put` from `frm` (either may be None)."""
-        dist, ops, post = self.dist, [], []
+        """Everybody sends rows `take` of every array to `to` and receives rows `put` from `frm` (either may be None).
+        Over gloo the page-locked host rows travel as they are, all arrays in one batch.  Over RCCL they are staged through HBM,
+        and at the moment of a swap the library holds its rings and as many resident rows as fit 85 % of the free HBM: the rows
+        go array by array in chunks of at most STAGE_BYTES through TWO reusable device buffers (BASELINE configs[4]: k = 16
+        rows of 256 MiB x 9 arrays would otherwise ask torch for 72 GiB that are no longer there).  Both sides cut
+        the same chunks -- the counts follow from (rows, row bytes) alone -- so the messages pair up."""
+        dist = self.dist
+        if not self.via_dev:
+            ops = []
+            for i, t in enumerate(views):
+                if to is not None:
+                    ops.append(dist.P2POp(dist.isend, t[take].contiguous(), self.peer(to), self.group, tag=tag0 + 4 * i))
+                if frm is not None:
+                    ops.append(dist.P2POp(dist.irecv, t[put], self.peer(frm), self.group, tag=tag0 + 4 * i))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            return
+        n_rows = (take.stop - take.start)
+        row_bytes = int(views[0].shape[1]) if views else 0
+        if not views or n_rows <= 0 or (to is None and frm is None):
+            return
+        chunk = max(1, min(n_rows, self.STAGE_BYTES // max(1, row_bytes)))
+        if getattr(self, "_stage", None) is None or self._stage[0].shape != (chunk, row_bytes):
+            self._stage = [torch.empty((chunk, row_bytes), dtype=torch.uint8, device=self.cuda) for _ in range(2)]
+        snd, rcv = self._stage
         for i, t in enumerate(views):
-            if to is not None:
-                ops.append(dist.P2POp(dist.isend, self._snd(t[take]), self.peer(to), self.group, tag=tag0 + 4 * i))
-            if frm is not None:
-                dst = t[put]
-                buf = torch.empty(dst.shape, dtype=dst.dtype, device=self.cuda) if self.via_dev else dst
-                if self.via_dev:
-                    post.append((dst, buf))
-                ops.append(dist.P2POp(dist.irecv, buf, self.peer(frm), self.group, tag=tag0 + 4 * i))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        for dst, buf in post:
-            dst.copy_(buf)
+            for c0 in range(0, n_rows, chunk):
+                c = min(chunk, n_rows - c0)
+                ops = []
+                if to is not None:
+                    snd[:c].copy_(t[take.start + c0:take.start + c0 + c])
+                    ops.append(dist.P2POp(dist.isend, snd[:c], self.peer(to), self.group, tag=tag0 + 4 * i))
+                if frm is not None:
+                    ops.append(dist.P2POp(dist.irecv, rcv[:c], self.peer(frm), self.group, tag=tag0 + 4 * i))
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                if frm is not None:
+                    t[put.start + c0:put.start + c0 + c].copy_(rcv[:c])
 
     def exchange(self, _user, n, arrays, rows_per, lo, hi, depth, row_bytes):
         try:

@@ -294,7 +294,10 @@ typedef struct tvdn_slab_io {
      * before every later pass for recon and the accumulator state.  Non-zero return aborts the run. */
     int (*exchange)(void *user, int32_t n_arrays, void *const *arrays, int64_t rows_per_array, int64_t own_lo, int64_t own_hi,
                     int32_t depth, int64_t row_bytes);
-    /* sums3: one iteration's three sums over this slab -> over all slabs, in place.  Only with use_stop, once per iteration. */
+    /* sums3: three doubles over this slab -> summed over all slabs, in place.  With use_stop once per iteration (the three sums);
+     * and, when the hook is set, ONCE before the first exchange with {1 if this slab's set-up failed else 0, 0, 0}: what can
+     * fail on one rank only (its host's memory, a page-locked allocation) makes every rank return the same error instead of
+     * leaving the others inside the exchange until the communicator times out (ABI 7). */
     int (*allreduce)(void *user, double *sums3);
     /* Only with first_row_nonfinite: a BROADCAST, once per pass, of row 0 of every level of the pass (n_planes contiguous
      * row-planes, page-locked) from the slab that owns row 0 to every other slab.  The owner calls it with send = 1 early in

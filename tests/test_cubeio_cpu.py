@@ -199,3 +199,19 @@ def test_denoise_file_refuses_to_overwrite_its_input(tmp_path):
         with pytest.raises(ValueError, match="input file itself"):
             cubeio.denoise_file(str(p), str(out), mu=[1, 1, 0.5, 0.5], iterations=2)
     assert np.array_equal(np.load(p), x)               # untouched
+
+
+def test_denoise_file_counts_the_copies_it_will_hold(tmp_path, monkeypatch):
+    """A stored cube of another dtype is converted into one host array, a result bound for HDF5 is held in RAM: both are added to
+    what the run page-locks and refused BEFORE anything is allocated when the host cannot hold them."""
+    x = (np.arange(4 * 3 * 4 * 8) % 7).astype(np.uint16).reshape(4, 3, 4, 8)
+    p = tmp_path / "counts.npy"
+    np.save(p, x)
+    monkeypatch.setenv("TVDN_HOST_LIMIT", "1K")                         # a host with (next to) no memory
+    with pytest.raises(MemoryError, match="converted to float32"):
+        cubeio.denoise_file(str(p), str(tmp_path / "out.npy"), mu=[1, 1, 0.5, 0.5], iterations=2)
+    assert not (tmp_path / "out.npy").exists()                          # refused before the output was created
+    # same dtype in, memory-mapped out: nothing is copied, nothing to refuse (the run itself then needs the GPU)
+    cubeio._check_host_holds_the_copies(x.shape, np.dtype(np.float32), 4, True, False, None, converted=False, result_in_ram=False)
+    with pytest.raises(MemoryError, match="HDF5 writer"):
+        cubeio._check_host_holds_the_copies(x.shape, np.dtype(np.float32), 4, True, False, None, converted=False, result_in_ram=True)
