@@ -35,11 +35,12 @@ At N = 1 the line also carries
                 at 50 and 200 iterations, and tvdn_run streamed from page-locked host memory (tvdn_run_stats: passes-only rate,
                 h2d / d2h GB/s, set-up and whole-call seconds) -- half a rank slab of BASELINE configs[4] with the library's
                 plan (rows resident in HBM) and with every row streamed, and the config-2 cube from host-resident state
-  cpu_baseline  the reference-structured CPU restatement (oracle/libtvdn_oracle_timed.so, kind "port": the reference's five
-                passes per iteration, its visiting order, dtype-width sums and serial boundary hyperslab) on the host cores of
-                the same box, on config 2 itself when the host has the memory for it, in a CHILD process (the thread binding
-                SURVEY 8d asks of it must not leak into the library's host threads).  Nothing built from the reference's
-                sources runs (or travels) here: port / reference = 0.94, profiles/r03_port_vs_reference.json.
+  cpu_baseline  the reference's OWN compiled kernels (oracle/_ref: its shipped C built by oracle/Makefile in the build container,
+                travelling as binaries; kind "reference") called in the reference's order on the host cores of the same box, on
+                config 2 itself when the host has the memory for it, in a CHILD process (the thread binding SURVEY 8d asks of
+                it must not leak into the library's host threads); `port` beside it = the repo's reference-structured restatement
+                (oracle/libtvdn_oracle_timed.so) on a third of the budget.  Without oracle/_ref (a checkout that never saw
+                /root/reference) the port alone, kind "port".
 Every roofline object carries the per-step sweep-kernel time as mean, minimum, median and maximum (HIP events per launch).
 """
 import argparse
@@ -166,11 +167,29 @@ def cpu_baseline(target_s, x_host=None):
         dt = time.perf_counter() - t0
         return vox * n / dt / 1e9, n, dt
 
-    v, n, dt = leg(oracle.timed_kernels(), target_s)
-    out = dict(value=v, unit="Gvoxel-iters/s", cores=cores, kind="port",
+    what_k = ("the reference's own compiled kernels (oracle/_ref: cyTVDN/anisotropic.c and utils.c as shipped, gcc -O2 -fopenmp) "
+              "called in the reference's order")
+    port = None
+    if oracle.have_reference_kernels():
+        # the real thing: the reference's kernels, built in the build container from the C the reference ships, travelled
+        # here as binaries; the port beside it on a third of the budget (how faithful the stand-in of rounds 1-4 was)
+        try:
+            v, n, dt = leg(oracle.load_reference_kernels(), target_s)
+            pv, pn, pdt = leg(oracle.timed_kernels(), target_s / 3.0)
+            port = {"value": pv, "iterations": pn, "seconds": round(pdt, 1), "port_over_reference": round(pv / v, 3)}
+            kind = "reference"
+        except Exception as e:       # e.g. another Python ABI on this box: say so and time the port
+            port = {"reference_kernels_failed": repr(e)}
+            v, n, dt = leg(oracle.timed_kernels(), target_s)
+            kind, what_k = "port", "oracle/libtvdn_oracle_timed.so = the reference's five passes, visiting order, dtype-width sums and serial boundary hyperslab"
+    else:
+        v, n, dt = leg(oracle.timed_kernels(), target_s)
+        kind, what_k = "port", "oracle/libtvdn_oracle_timed.so = the reference's five passes, visiting order, dtype-width sums and serial boundary hyperslab"
+    out = dict(value=v, unit="Gvoxel-iters/s", cores=cores, kind=kind,
                sample=f"denoise4D FISTA f32 {'x'.join(map(str, shape))} synthetic 4D-STEM ({what}), {n} iterations, "
-                      f"{dt:.1f} s, OMP_NUM_THREADS={cores}; oracle/libtvdn_oracle_timed.so = the reference's five "
-                      f"passes, visiting order, dtype-width sums and serial boundary hyperslab")
+                      f"{dt:.1f} s, OMP_NUM_THREADS={cores}; {what_k}")
+    if port is not None:
+        out["port"] = port
     return out
 
 
