@@ -232,6 +232,9 @@ int run_streamed_rank(const tvdn_run_args *a, int64_t rows, int64_t k);  // one 
 hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, bool *reused, bool any_larger, double spread_budget_s = 0.25);
 void state_release(void *p, size_t bytes, int device);
 size_t state_kept_bytes(int device);  // counts as free: the next run takes it over or releases it
+// the state's allocation itself (granules unless told otherwise: tvdn_devmem.hip), and the shape of a resident run's pipelined transfers
+hipError_t state_malloc(void **p, size_t bytes, int device, bool granules = true, double spread_budget_s = 0.25);
+void pipeline_plan(int64_t n0, int64_t n_total, int64_t cube_bytes, int32_t out[3]);
 // tvdn_devmem.hip: device memory composed from physical granules (big blocks) or plain hipMalloc; dev_free takes either
 struct DevAllocInfo {  // what a block of granules was made from (all zero for a plain block)
     int64_t granule_bytes;

@@ -1,0 +1,200 @@
+// What a tvdn_run keeps and what it costs: the state block kept between runs (one per device), the arithmetic of check_memory for
+// HBM (tvdn_plan), the shape of a resident run's pipelined transfers, and the small C entries around them (include/tvdn.h).
+// Split from tvdn_run.hip in round 5 (no file of csrc/ above 1000 lines).
+#include <cstdlib>
+#include <mutex>
+
+#include "tvdn_common.hpp"
+
+namespace tvdn {
+
+// The state block of the last resident run of each device is KEPT when the run ends and handed to the next run that it
+// fits: releasing and re-allocating tens of GiB in quick succession costs 0.7 s per hipMalloc plus 1.1 s per hipFree, with
+// single stalls of 4-6 s (profiles/r03_malloc_stall_probe.jsonl), so a program that calls tvdn_run cube after cube would
+// spend more time in the allocator than in the sweeps.  One block per device at most, only while no caller-provided
+// workspace is in use; tvdn_release_cache() hands it back, TVDN_KEEP_STATE=0 never keeps one.
+struct StateCache {
+    std::mutex mu;
+    void *p[TVDN_MAX_DEVICES] = {};
+    size_t bytes[TVDN_MAX_DEVICES] = {};
+};
+static StateCache g_state_cache;
+
+static bool keep_state()
+{
+    const char *e = getenv("TVDN_KEEP_STATE");
+    return !(e && atoi(e) == 0) && getenv("TVDN_MALLOC") == nullptr;
+}
+
+// The state's allocation: composed from physical granules (tvdn_devmem.hip: the placement of such a block does not decide how
+// fast the sweep runs on it, that of a hipMalloc block does).  `granules` false: a plain hipMalloc block
+// (slabs on several devices, whose neighbours copy rows out of it peer to peer).  TVDN_MALLOC=contiguous | uncached |
+// finegrained asks the runtime for another kind of device memory (measurement, round 3: they draw from the same lottery).
+hipError_t state_malloc(void **p, size_t bytes, int device, bool granules, double spread_budget_s)
+{
+    const char *e = getenv("TVDN_MALLOC");
+    if (e && !strcmp(e, "contiguous")) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous);
+    if (e && !strcmp(e, "uncached")) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached);
+    if (e && !strcmp(e, "finegrained")) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
+    if (!granules) return hipMalloc(p, bytes);
+    DevAllocInfo info;
+    const hipError_t rc = dev_alloc(p, bytes, device, nullptr, spread_budget_s, &info);
+    if (rc == hipSuccess && getenv("TVDN_RUN_TIMING") && info.granules)
+        fprintf(stderr, "tvdn_run:   state on %d granules of %lld MiB, a random subset of %d created, in %.3f s (budget for the extra ones %.2f s)\n", info.granules,
+                (long long)(info.granule_bytes >> 20), info.pool, info.seconds, spread_budget_s);
+    return rc;
+}
+
+// the kept block of `device` if it holds `bytes` without being more than a quarter larger (`any_larger`: however much larger -- a
+// streamed run carves rings out of it and is indifferent to where they lie), else a fresh allocation
+hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, bool *reused, bool any_larger, double spread_budget_s)
+{
+    *reused = false;
+    if (keep_state() && device >= 0 && device < TVDN_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lk(g_state_cache.mu);
+        void *&c = g_state_cache.p[device];
+        size_t &cb = g_state_cache.bytes[device];
+        if (c && cb >= bytes && (any_larger || cb - bytes <= bytes / 4)) {
+            *p = c;
+            *got_bytes = cb;
+            c = nullptr;
+            cb = 0;
+            *reused = true;
+            return hipSuccess;
+        }
+        if (c) {  // the wrong size: make room before asking for the right one
+            (void)dev_free(c);
+            c = nullptr;
+            cb = 0;
+        }
+    }
+    *got_bytes = bytes;
+    return state_malloc(p, bytes, device, true, spread_budget_s);
+}
+
+size_t state_kept_bytes(int device)
+{
+    if (device < 0 || device >= TVDN_MAX_DEVICES) return 0;
+    std::lock_guard<std::mutex> lk(g_state_cache.mu);
+    return g_state_cache.bytes[device];
+}
+
+void state_release(void *p, size_t bytes, int device)
+{
+    if (!p) return;
+    if (keep_state() && device >= 0 && device < TVDN_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lk(g_state_cache.mu);
+        void *&c = g_state_cache.p[device];
+        if (!c) {
+            c = p;
+            g_state_cache.bytes[device] = bytes;
+            return;
+        }
+    }
+    (void)dev_free(p);
+}
+
+// Shape of a resident run's pipelined transfers (see run_impl): out = {rows per chunk, iterations that follow the upload,
+// iterations that run over the download}, {0, 0, 0} = plain order.  Eight chunks (~12 ms of PCIe each for a 4 GiB cube), as
+// many iterations at either end as a chunk's transfer pays for; cubes under 256 MiB move in milliseconds and runs under four
+// iterations have nothing to hide a transfer under.  TVDN_PIPELINE=0 keeps the plain order, "R,k0,k1" forces a shape (tests).
+void pipeline_plan(int64_t n0, int64_t n_total, int64_t cube_bytes, int32_t out[3])
+{
+    out[0] = out[1] = out[2] = 0;
+    if (n_total <= 0 || n0 <= 0) return;
+    const char *e = getenv("TVDN_PIPELINE");
+    if (e && strchr(e, ',')) {
+        int r_ = 0, k0_ = 0, k1_ = 0;
+        if (sscanf(e, "%d,%d,%d", &r_, &k0_, &k1_) == 3 && r_ >= 1 && k0_ >= 0 && k1_ >= 0) {
+            out[0] = r_;
+            out[1] = (int32_t)std::min<int64_t>(k0_, n_total);
+            out[2] = (int32_t)std::min<int64_t>(k1_, n_total - out[1]);
+        }
+        return;
+    }
+    if ((e && atoi(e) == 0) || n_total < 4 || n0 < 32 || cube_bytes < (int64_t(256) << 20)) return;
+    out[0] = (int32_t)std::max<int64_t>(8, (n0 + 7) / 8);
+    out[1] = (int32_t)std::min<int64_t>(8, n_total / 2);
+    out[2] = (int32_t)std::min<int64_t>(8, n_total - out[1]);
+}
+
+}  // namespace tvdn
+
+// The HBM arithmetic of check_memory (cyTVDN.py:438-467) for this engine: arrays of the compact state, bytes of the
+// tallest slab of an n-way split with its halo rows, what the device has free, and the fewest slabs that would fit.
+extern "C" int tvdn_plan(int dtype, int ndim, const int64_t *shape, int fista, int n_slabs, int device, tvdn_plan_out *out)
+{
+    tvdn::DeviceRestore restore;
+    size_t kept = 0;  // the state block the last run of this device left for the next one counts as free
+    if (device >= 0 && device < TVDN_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lk(tvdn::g_state_cache.mu);
+        kept = tvdn::g_state_cache.bytes[device];
+    }
+    TVDN_REQUIRE(out != nullptr && shape != nullptr, "NULL argument");
+    TVDN_REQUIRE(dtype == TVDN_F32 || dtype == TVDN_F64, "bad dtype %d", dtype);
+    TVDN_REQUIRE(ndim == 3 || ndim == 4, "ndim must be 3 or 4, got %d", ndim);
+    for (int i = 0; i < ndim; ++i) TVDN_REQUIRE(shape[i] >= 1, "shape[%d] must be >= 1", i);
+    TVDN_REQUIRE(n_slabs >= 1 && n_slabs <= shape[0], "n_slabs must be 1..shape[0]");
+    const int64_t item = dtype == TVDN_F32 ? 4 : 8;
+    int64_t plane = item;
+    for (int i = 1; i < ndim; ++i) plane *= shape[i];
+    const int64_t arrays = 3 + (int64_t)ndim * (fista ? 3 : 2);
+    auto slab_bytes = [&](int64_t s) {
+        const int64_t rows = (shape[0] + s - 1) / s + (s > 1 ? 2 : 0);
+        return arrays * (rows * plane + 4096 + 255);
+    };
+    size_t free_b = 0, total_b = 0;
+    TVDN_HIP(hipSetDevice(device));
+    TVDN_HIP(hipMemGetInfo(&free_b, &total_b));
+    free_b += kept;
+    out->arrays = arrays;
+    out->bytes_per_slab = slab_bytes(n_slabs);
+    out->free_bytes = (int64_t)free_b;
+    out->fits = out->bytes_per_slab <= (int64_t)(0.9 * (double)free_b) ? 1 : 0;
+    out->min_slabs = 0;
+    for (int64_t s = 1; s <= shape[0]; ++s)
+        if (slab_bytes(s) <= (int64_t)(0.9 * (double)free_b)) {
+            out->min_slabs = (int32_t)s;
+            break;
+        }
+    return TVDN_OK;
+}
+
+extern "C" int64_t tvdn_state_kept_bytes(int device) { return (int64_t)tvdn::state_kept_bytes(device); }
+
+extern "C" int tvdn_release_cache(void)
+{
+    tvdn::DeviceRestore restore;
+    std::lock_guard<std::mutex> lk(tvdn::g_state_cache.mu);
+    for (int d = 0; d < TVDN_MAX_DEVICES; ++d)
+        if (tvdn::g_state_cache.p[d]) {
+            (void)hipSetDevice(d);
+            (void)tvdn::dev_free(tvdn::g_state_cache.p[d]);
+            tvdn::g_state_cache.p[d] = nullptr;
+            tvdn::g_state_cache.bytes[d] = 0;
+        }
+    return TVDN_OK;
+}
+
+extern "C" int tvdn_run_workspace_bytes(const tvdn_run_args *a, int64_t *bytes)
+{
+    TVDN_REQUIRE(a != nullptr && bytes != nullptr, "NULL argument");
+    TVDN_REQUIRE(a->dtype == TVDN_F32 || a->dtype == TVDN_F64, "bad dtype %d", a->dtype);
+    TVDN_REQUIRE(a->ndim == 3 || a->ndim == 4, "ndim must be 3 or 4, got %d", a->ndim);
+    size_t b = a->dtype == TVDN_F32 ? 4 : 8;
+    for (int i = 0; i < a->ndim; ++i) {
+        TVDN_REQUIRE(a->shape[i] >= 1, "shape[%d] must be >= 1", i);
+        b *= (size_t)a->shape[i];
+    }
+    const size_t stride = (b + 255) / 256 * 256 + 4096;  // as run_impl lays the state out
+    *bytes = (int64_t)(stride * (size_t)(3 + a->ndim * (a->n_fista > 0 ? 3 : 2)));
+    return TVDN_OK;
+}
+
+extern "C" int tvdn_pipeline_plan(int64_t n0, int32_t n_iters, int64_t cube_bytes, int32_t *out)
+{
+    TVDN_REQUIRE(out != nullptr, "NULL argument");
+    TVDN_REQUIRE(n0 >= 1 && n_iters >= 0 && cube_bytes >= 0, "bad argument");
+    tvdn::pipeline_plan(n0, n_iters, cube_bytes, out);
+    return TVDN_OK;
+}

@@ -1,0 +1,360 @@
+// StreamRun::chain -- the streamed engine's schedule for Jia-Zhao runs on one device: one pass, or several CHAINED into one
+// running row index so that the link is busy both ways all the time.  tvdn_stream.hip has the map of the engine.
+#include "tvdn_stream_run.hpp"
+
+namespace tvdn {
+
+int StreamRun::describe(int it0, int kk, const double *rat, PassDesc &pd)
+{
+    pd.it0 = it0;
+    pd.kk = kk;
+    pd.modes.resize((size_t)kk);
+    pd.tk.resize((size_t)kk);
+    pd.tkp.resize((size_t)kk);
+    pd.first = n_passes == 0 && it0 == 0;
+    pd.last = !a->use_stop && it0 + kk == n_total;
+    bool form = d_form;
+    pd.n_in_state = form ? 2 : 1;
+    double prev = tk_prev;
+    for (int j = 0; j < kk; ++j) {
+        const bool acc = !std::isnan(rat[j]);
+        TVDN_REQUIRE(!acc || form, "a FISTA iteration cannot follow an unaccelerated one");
+        pd.modes[(size_t)j] = iter_mode(acc, form);
+        pd.tk[(size_t)j] = acc ? rat[j] : 0.0;
+        pd.tkp[(size_t)j] = prev;
+        form = acc;
+        if (acc) prev = rat[j];
+    }
+    pd.n_out_state = form ? 2 : 1;
+    d_form = form;  // the trackers move on: the next description continues from here
+    tk_prev = prev;
+    return TVDN_OK;
+}
+
+// ---- chained passes (Jia-Zhao) ---------------------------------------------------------------------------------------------
+// A pass of K levels over N0 rows fills and drains its pipeline: uploads happen in its first N0 / R chunks, downloads in
+// its last N0 / R, and only the chunks in between use the link both ways -- at K = 38 on 64 rows that is 12 chunks of 52,
+// although the link carries 56 GB/s up AND 49 GB/s down at once (tools/ubench/pcie_duplex.hip, profiles/r04_pcie_duplex.jsonl).
+// Chained, pass p + 1 starts uploading in the chunk after pass p's last upload, while p's upper levels are still climbing:
+// the passes are stacked into one running row index v = p N0 + g, level j + 1 trails level j by one row of THAT index, a
+// ring slot is v mod ring, and a launch that straddles the seam between two passes is cut there (the last row of p ends
+// at the cube's top face, row 0 of p + 1 starts at its bottom one; each piece with its own iteration numbers).  What pass
+// p + 1 uploads must be home: row g comes down (p N0 + g + K) / R chunks in and goes up again ((p + 1) N0 + g) / R - 1
+// chunks in, so K <= N0 - 3 R is asked for, and the upload stream waits for the download event of that chunk.
+// One pass at a time (`chain` of one) is the drained schedule: runs with a stopping rule, and passes deeper than that.
+// How rows come down.  The runtime's hipMemcpyAsync moves a download with a DMA engine when its stream is idle and with a
+// blit kernel otherwise; two DMA transfers in opposite directions at once take 4 x as long (512 MiB down: 10.5 ms alone,
+// 42 ms beside an upload; profiles/r04_chained_trace_summary.txt -- what made chained passes LOSE in round 3), while an
+// upload by DMA beside a download by a small copy kernel runs at 54 + 42 GB/s and leaves the sweeps alone (8 workgroups;
+// with 16 or more the sweeps lose a third: tools/ubench/pcie_duplex.hip, profiles/r04_pcie_duplex.jsonl).  Chained passes
+// keep both directions busy all the time, so their downloads are a copy kernel of 8 workgroups writing the page-locked
+// host arrays directly; drained passes keep the runtime's copies.  TVDN_STREAM_DOWN_BLOCKS=n overrides (0: runtime copies).
+int StreamRun::chain(std::vector<PassDesc> &ps)
+{
+    const int P = (int)ps.size();
+    const int64_t V1 = (int64_t)P * N0;  // running rows that are uploaded
+    int64_t kmax = 0;
+    for (const PassDesc &pd : ps) kmax = std::max<int64_t>(kmax, pd.kk);
+    const int64_t n_chunks = (V1 + ps[(size_t)P - 1].kk + R - 1) / R;
+    std::vector<hipEvent_t> down_done((size_t)n_chunks, nullptr);
+    const int bx_recon = 1, bx_ref = 2 + nd * n_state;  // fixed box numbers: 0 data term, 1 recon, 2 + q n_state + s state
+    auto bx_state = [&](int q, int s) { return 2 + q * n_state + s; };
+    auto ox_state = [&](int q, int s) { return 1 + q * n_state + s; };  // out boxes: 0 recon, then the state
+    it.shape[0] = V1;
+    // the pieces of the running rows [v0, v1) by pass: fn(pass, v_lo, v_hi)
+    auto pieces = [&](int64_t v0, int64_t v1, const std::function<int(int, int64_t, int64_t)> &fn) -> int {
+        v0 = std::max<int64_t>(v0, 0);
+        v1 = std::min<int64_t>(v1, V1);
+        for (int64_t v = v0; v < v1;) {
+            const int q = (int)(v / N0);
+            const int64_t e = std::min<int64_t>(v1, (int64_t)(q + 1) * N0);
+            const int rcp = fn(q, v, e);
+            if (rcp) return rcp;
+            v = e;
+        }
+        return TVDN_OK;
+    };
+    auto host_rows_in = [&](int64_t v0, int64_t v1) {
+        int64_t n = 0;
+        for (int64_t v = std::max<int64_t>(v0, 0); v < std::min(v1, V1); ++v) n += resident(v % N0) ? 0 : 1;
+        return n;
+    };
+    // host rows among cube rows [g0, g1) -> box rows from `slot` on, run by run
+    auto up_rows = [&](char *box, int64_t &slot, int64_t g0, int64_t g1, const std::function<char *(int64_t)> &src_row,
+                       const std::function<bool(int64_t)> &joins_next) -> int {
+        for (int64_t g = g0; g < g1;) {
+            if (resident(g)) {
+                ++g;
+                continue;
+            }
+            int64_t n = 1;
+            while (g + n < g1 && !resident(g + n) && joins_next(g + n - 1)) ++n;
+            TVDN_HIP(hipMemcpyAsync(box + (size_t)slot * row_bytes, src_row(g), (size_t)n * row_bytes, hipMemcpyHostToDevice, st.up));
+            bytes_up += n * (int64_t)row_bytes;
+            slot += n;
+            g += n;
+        }
+        return TVDN_OK;
+    };
+    const std::function<bool(int64_t)> always = [](int64_t) { return true; };
+    auto upload = [&](int64_t t, int64_t t_now) -> int {
+        const int64_t u0 = t * R, u1 = std::min((t + 1) * R, V1);
+        if (u0 >= u1 || host_rows_in(u0, u1) == 0) return TVDN_OK;
+        int rcu = orig_ready.wait();
+        if (rcu) return rcu;
+        const int h = (int)(t % 2);
+        if (in_free_set[h]) TVDN_HIP(hipStreamWaitEvent(st.up, in_free[h], 0));
+        int64_t s_orig = 0, s_recon = 0, s_ref = 0;
+        std::vector<int64_t> s_state((size_t)nd * 2, 0);
+        rcu = pieces(u0, u1, [&](int q, int64_t v_lo, int64_t v_hi) -> int {
+            const PassDesc &pd = ps[(size_t)q];
+            const int64_t g0 = v_lo - (int64_t)q * N0, g1 = v_hi - (int64_t)q * N0;
+            const int64_t before = s_orig;
+            int r3 = up_rows(inbox[h][0], s_orig, g0, g1, [&](int64_t g) { return host_row(orig_h, g); }, always);
+            if (r3) return r3;
+            const int64_t n_host = s_orig - before;
+            if (want_mse && (r3 = up_rows(inbox[h][bx_ref], s_ref, g0, g1, [&](int64_t g) { return host_row(ref_h, g); }, always))) return r3;
+            if (pd.first) {  // recon and state are formed on the device: their box rows stay unused
+                s_recon += n_host;
+                for (int64_t &x : s_state) x += n_host;
+                return TVDN_OK;
+            }
+            if (q > 0) {
+                // these rows came down at the end of pass q - 1: the upload stream waits for the chunk that sent the last of them
+                const int64_t t_out = ((int64_t)(q - 1) * N0 + (g1 - 1) + ps[(size_t)q - 1].kk) / R;
+                TVDN_REQUIRE(t_out < t_now && down_done[(size_t)t_out] != nullptr,
+                             "chained passes: row %lld of pass %d is uploaded before pass %d has sent it home (k too deep to chain)",
+                             (long long)(g1 - 1), q, q - 1);
+                TVDN_HIP(hipStreamWaitEvent(st.up, down_done[(size_t)t_out], 0));
+            }
+            if ((r3 = wait_recon(0))) return r3;
+            if ((r3 = up_rows(inbox[h][bx_recon], s_recon, g0, g1, [&](int64_t g) { return host_row(recon_h, g); }, always))) return r3;
+            for (int64_t g = g0; g < g1; ++g)
+                if (!resident(g) && (r3 = sb[0].wait_for(rm.host_below(g)))) return r3;
+            for (int qx = 0; qx < nd; ++qx)
+                for (int s = 0; s < n_state; ++s) {
+                    int64_t &sl = s_state[(size_t)qx * 2 + s];
+                    if (s >= pd.n_in_state) {
+                        sl += n_host;
+                        continue;
+                    }
+                    const int arr = qx * n_state + s;
+                    if ((r3 = up_rows(inbox[h][bx_state(qx, s)], sl, g0, g1, [&](int64_t g) { return sb[0].row(arr, rm.host_below(g)); },
+                                      [&](int64_t g) { return sb[0].block_of(rm.host_below(g)) == sb[0].block_of(rm.host_below(g + 1)); })))
+                        return r3;
+                }
+            return TVDN_OK;
+        });
+        if (rcu) return rcu;
+        TVDN_HIP(hipEventRecord(in_ready[h], st.up));
+        return TVDN_OK;
+    };
+
+    int rc2 = upload(0, 0);
+    if (rc2) return rc2;
+    for (int64_t t = 0; t < n_chunks; ++t) {
+        if ((rc2 = upload(t + 1, t))) return rc2;  // the next chunk crosses PCIe while this one is swept
+        const int h = (int)(t % 2);
+        const int64_t u0 = t * R, u1 = std::min((t + 1) * R, V1);
+        if (u0 < u1) {
+            const bool from_host = host_rows_in(u0, u1) > 0;
+            if (from_host) TVDN_HIP(hipStreamWaitEvent(st.main, in_ready[h], 0));
+            cdst.clear();
+            csrc.clear();
+            int64_t slot = 0;
+            for (int64_t v = u0; v < u1; ++v) {
+                const int q = (int)(v / N0);
+                const PassDesc &pd = ps[(size_t)q];
+                const int64_t g = v - (int64_t)q * N0;
+                const bool res_row = resident(g);
+                if (pd.first && res_row && (rc2 = wait_staged(g + 1))) return rc2;
+                auto put = [&](const Ring &rg, const char *src) {
+                    cdst.push_back(rg.row(v));
+                    csrc.push_back((void *)src);
+                };
+                auto boxed = [&](int bx) { return inbox[h][bx] + (size_t)slot * row_bytes; };
+                const char *o_src = res_row ? store_row(0, g) : boxed(0);
+                put(Ow, o_src);
+                put(Rw[0], pd.first ? o_src : (res_row ? store_row(1, g) : boxed(bx_recon)));
+                for (int qx = 0; qx < nd; ++qx) {
+                    put(A(0, qx), pd.first ? zero_plane : (res_row ? store_row(2 + qx * n_state, g) : boxed(bx_state(qx, 0))));
+                    if (pd.n_in_state == 2)
+                        put(A(-1, qx), pd.first ? zero_plane : (res_row ? store_row(2 + qx * n_state + 1, g) : boxed(bx_state(qx, 1))));
+                }
+                if (want_mse) put(Fw, boxed(bx_ref));
+                if (!res_row) ++slot;
+            }
+            rc2 = copy_rows(cdst, csrc, row_bytes, st.main);
+            if (rc2) return rc2;
+            for (int64_t v = u0; v < u1; ++v) {
+                const int q = (int)(v / N0);
+                const int64_t g = v - (int64_t)q * N0;
+                if (exact_wrap && g == 0)
+                    TVDN_HIP(hipMemcpyAsync(((q & 1) ? row0b : row0)[0], Rw[0].row(v), row_bytes, hipMemcpyDeviceToDevice, st.main));
+                if (want_mse && ps[(size_t)q].it0 == 0 && ps[(size_t)q].first)  // MSE[0]: the input against the reference (cyTVDN.py:124-125)
+                    if ((rc2 = sse_row(Rw[0].row(v), Fw.row(v), 0, g))) return rc2;
+            }
+            if (from_host) {
+                TVDN_HIP(hipEventRecord(in_free[h], st.main));
+                in_free_set[h] = true;
+            }
+        }
+        // the wavefront: level j+1 trails level j by one running row; a launch is cut at the seam between two passes
+        for (int64_t j = 0; j < kmax; ++j) {
+            rc2 = pieces(t * R - (j + 1), (t + 1) * R - (j + 1), [&](int q, int64_t v_lo, int64_t v_hi) -> int {
+                const PassDesc &pd = ps[(size_t)q];
+                if (j >= pd.kk) return TVDN_OK;
+                const int mode = pd.modes[(size_t)j];
+                it.row_lo = (int64_t)q * N0;
+                it.row_hi = (int64_t)(q + 1) * N0;
+                it.sweep_lo = v_lo;
+                it.sweep_hi = v_hi;
+                it.mode = mode;
+                it.tk = pd.tk[(size_t)j];
+                it.tk_prev = pd.tkp[(size_t)j];
+                it.recon_in = Rw[(size_t)j].base;
+                it.recon_out = Rw[(size_t)j + 1].base;
+                it.wrap_recon = exact_wrap ? ((q & 1) ? row0b : row0)[(size_t)j] : nullptr;
+                for (int qx = 0; qx < nd; ++qx) {
+                    char *cur = A(j, qx).base, *prv = A(j - 1, qx).base, *nxt = A(j + 1, qx).base;
+                    it.b_in[qx] = it.d_in[qx] = it.dprev_in[qx] = nullptr;
+                    it.b_out[qx] = it.d_out[qx] = nullptr;
+                    if (mode == TVDN_ITER_FISTA_D) {
+                        it.d_in[qx] = cur; it.dprev_in[qx] = prv; it.d_out[qx] = nxt;
+                    } else if (mode == TVDN_ITER_FISTA_D_TO_PLAIN) {
+                        it.d_in[qx] = cur; it.dprev_in[qx] = prv; it.b_out[qx] = nxt;
+                    } else {
+                        it.b_in[qx] = cur; it.b_out[qx] = nxt;
+                    }
+                }
+                int r3 = tvdn_iterate_fused(ctx.c, &it, (double *)sums_d.p + 3 * (size_t)(pd.it0 + (int)j), st.main);
+                if (r3) return r3;
+                if (want_mse)
+                    for (int64_t v = v_lo; v < v_hi; ++v)
+                        if ((r3 = sse_row(Fw.row(v), Rw[(size_t)j + 1].row(v), pd.it0 + (int)j + 1, v - (int64_t)q * N0))) return r3;
+                if (exact_wrap && v_lo == (int64_t)q * N0)
+                    TVDN_HIP(hipMemcpyAsync(((q & 1) ? row0b : row0)[(size_t)j + 1], Rw[(size_t)j + 1].row(v_lo), row_bytes, hipMemcpyDeviceToDevice, st.main));
+                return TVDN_OK;
+            });
+            if (rc2) return rc2;
+        }
+        // rows that have reached their pass's last level go home: resident rows into the store, the others across PCIe
+        cdst.clear();
+        csrc.clear();
+        struct Out {
+            int q;
+            int64_t g0, g1, slot0;
+        };
+        std::vector<Out> outs;
+        int64_t oslot = 0;
+        for (int q = 0; q < P; ++q) {
+            const PassDesc &pd = ps[(size_t)q];
+            const int64_t lo = std::max<int64_t>((int64_t)q * N0, t * R - pd.kk), hi = std::min<int64_t>((int64_t)(q + 1) * N0, (t + 1) * R - pd.kk);
+            if (lo >= hi) continue;
+            // The run's last pass: the state of a resident row is not needed again, and its result can cross PCIe under
+            // the pass (the link has room: a hybrid run uses half of it) instead of in one piece after it -- when the
+            // caller's result array is page-locked in place, i.e. has a place for every row.
+            if (pd.last && RES > 0 && !recon_direct_decided) {
+                if ((rc2 = wait_recon(0))) return rc2;
+                recon_direct = recon_h.cube_rows && getenv("TVDN_STREAM_HOME_AFTER") == nullptr;
+                recon_direct_decided = true;
+            }
+            const bool direct = pd.last && recon_direct;
+            outs.push_back(Out{q, lo - (int64_t)q * N0, hi - (int64_t)q * N0, oslot});
+            for (int64_t v = lo; v < hi; ++v) {
+                const int64_t g = v - (int64_t)q * N0;
+                const bool res_row = resident(g);
+                auto put = [&](int i_store, int ox, const Ring &rg) {
+                    cdst.push_back(res_row ? store_row(i_store, g) : outbox[h][ox] + (size_t)oslot * row_bytes);
+                    csrc.push_back(rg.row(v));
+                };
+                if (res_row && direct) {  // the result only, into the out box like a host row's
+                    cdst.push_back(outbox[h][0] + (size_t)oslot * row_bytes);
+                    csrc.push_back(Rw[(size_t)pd.kk].row(v));
+                    ++oslot;
+                    continue;
+                }
+                put(1, 0, Rw[(size_t)pd.kk]);
+                for (int qx = 0; qx < nd; ++qx) {
+                    put(2 + qx * n_state, ox_state(qx, 0), A(pd.kk, qx));
+                    if (pd.n_out_state == 2) put(2 + qx * n_state + 1, ox_state(qx, 1), A(pd.kk - 1, qx));
+                }
+                if (!res_row) ++oslot;
+            }
+        }
+        TVDN_REQUIRE(oslot <= R + 1, "chained passes: %lld rows come down in one chunk, the out boxes hold %lld (depths of consecutive passes differ by more than one)",
+                     (long long)oslot, (long long)(R + 1));
+        if (!cdst.empty()) {
+            if (oslot > 0 && out_free_set[h]) TVDN_HIP(hipStreamWaitEvent(st.main, out_free[h], 0));
+            rc2 = copy_rows(cdst, csrc, row_bytes, st.main);
+            if (rc2) return rc2;
+        }
+        if (oslot > 0) {
+            TVDN_HIP(hipEventRecord(out_ready[h], st.main));
+            TVDN_HIP(hipStreamWaitEvent(st.down, out_ready[h], 0));
+            if ((rc2 = wait_recon(0))) return rc2;  // the host arrays these rows land in exist (first pass: the helper may still be at it)
+            std::vector<void *> kd, ks;  // copies of whole rows for the copy kernel (down_blocks > 0)
+            for (const Out &o : outs) {
+                const PassDesc &pd = ps[(size_t)o.q];
+                const bool direct = pd.last && recon_direct;
+                int64_t slot = o.slot0;
+                for (int64_t g = o.g0; g < o.g1;) {
+                    if (resident(g)) {
+                        if (direct) {  // its result went into the out box: one row, straight into the caller's array
+                            char *dst = recon_h.p + (size_t)g * row_bytes;
+                            const char *src = outbox[h][0] + (size_t)slot * row_bytes;
+                            if (down_blocks > 0 && row_bytes % 16 == 0 && ((uintptr_t)dst & 15) == 0) {
+                                kd.push_back(dst);
+                                ks.push_back((void *)src);
+                            } else {
+                                TVDN_HIP(hipMemcpyAsync(dst, src, row_bytes, hipMemcpyDeviceToHost, st.down));
+                            }
+                            bytes_down += (int64_t)row_bytes;
+                            ++slot;
+                        }
+                        ++g;
+                        continue;
+                    }
+                    const int64_t hs = rm.host_below(g);
+                    if ((rc2 = sb[0].wait_for(hs))) return rc2;
+                    int64_t n = 1;
+                    while (g + n < o.g1 && !resident(g + n) && sb[0].block_of(hs + n) == sb[0].block_of(hs)) ++n;
+                    const size_t boff = (size_t)slot * row_bytes, len = (size_t)n * row_bytes;
+                    auto down = [&](char *dst, const char *src) -> int {
+                        if (down_blocks > 0 && row_bytes % 16 == 0 && ((uintptr_t)dst & 15) == 0) {
+                            for (int64_t r = 0; r < n; ++r) {
+                                kd.push_back(dst + (size_t)r * row_bytes);
+                                ks.push_back((void *)(src + (size_t)r * row_bytes));
+                            }
+                        } else {
+                            TVDN_HIP(hipMemcpyAsync(dst, src, len, hipMemcpyDeviceToHost, st.down));
+                        }
+                        return TVDN_OK;
+                    };
+                    if ((rc2 = down(host_row(recon_h, g), outbox[h][0] + boff))) return rc2;
+                    for (int qx = 0; qx < nd; ++qx)
+                        for (int s = 0; s < pd.n_out_state; ++s)
+                            if ((rc2 = down(sb[0].row(qx * n_state + s, hs), outbox[h][ox_state(qx, s)] + boff))) return rc2;
+                    bytes_down += (int64_t)len * (1 + (int64_t)pd.n_out_state * nd);
+                    slot += n;
+                    g += n;
+                }
+            }
+            // ONE launch of a few workgroups writes the chunk's rows into the page-locked host arrays (see down_blocks)
+            if (!kd.empty() && (rc2 = tvdn_copy_many((int32_t)kd.size(), kd.data(), ks.data(), (int64_t)row_bytes, down_blocks, st.down))) return rc2;
+            TVDN_HIP(hipEventRecord(out_free[h], st.down));
+            out_free_set[h] = true;
+        }
+        if (P > 1) {  // what a later pass's uploads wait for (also for chunks that sent nothing: the stream is in order)
+            if ((rc2 = evs.make(&down_done[(size_t)t]))) return rc2;
+            TVDN_HIP(hipEventRecord(down_done[(size_t)t], st.down));
+        }
+    }
+    TVDN_HIP(hipStreamSynchronize(st.down));
+    TVDN_HIP(hipStreamSynchronize(st.main));
+    TVDN_HIP(hipStreamSynchronize(st.up));
+    n_passes += P;
+    return TVDN_OK;
+}
+
+}  // namespace tvdn
