@@ -30,7 +30,7 @@ EXPORTS = (
     "tvdn_accumulator_update", "tvdn_datacube_update", "tvdn_sum_square_error", "tvdn_iterate_fused",
     "tvdn_synth_fill", "tvdn_run", "tvdn_pipeline_plan", "tvdn_run_workspace_bytes", "tvdn_release_cache", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many", "tvdn_plan", "tvdn_copy_many", "tvdn_stream_mix", "tvdn_stream_mix_march",
     "tvdn_stream_host_need", "tvdn_stream_plan", "tvdn_wait_background", "tvdn_slab_host_need", "tvdn_slab_row_map", "tvdn_fista_ratios", "tvdn_iter_mode", "tvdn_roles_bind", "tvdn_roles_advance",
-    "tvdn_mem_alloc", "tvdn_mem_free", "tvdn_state_kept_bytes",
+    "tvdn_mem_alloc", "tvdn_mem_free", "tvdn_state_kept_bytes", "tvdn_recon_from_state",
 )
 MEM_PLAIN, MEM_GRANULES, MEM_CALLER = 0, 1, 2
 
@@ -186,6 +186,8 @@ def lib():
     L.tvdn_roles_advance.argtypes = [C.POINTER(ManyArgs), C.c_int32, C.c_double]
     L.tvdn_run_workspace_bytes.argtypes = [C.POINTER(RunArgs), C.POINTER(C.c_int64)]
     L.tvdn_pipeline_plan.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.POINTER(C.c_int32)]
+    L.tvdn_recon_from_state.argtypes = [C.c_int, C.c_int, i64p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_double), C.c_double, C.c_int64, C.c_int64, C.c_void_p]
     L.tvdn_mem_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int, C.POINTER(C.c_int32)]
     L.tvdn_mem_free.argtypes = [C.c_void_p]
     L.tvdn_state_kept_bytes.argtypes = [C.c_int]

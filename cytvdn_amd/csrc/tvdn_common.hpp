@@ -262,6 +262,21 @@ struct DeviceRestore {
     DeviceRestore(const DeviceRestore &) = delete;
     DeviceRestore &operator=(const DeviceRestore &) = delete;
 };
+// tvdn_rebuild.hip: recon of ring rows [row0, row1) rebuilt from the accumulator state (the streamed engine's level 0)
+struct RebuildArgs {
+    int dtype, ndim;
+    int64_t plane_shape[3];  // shape[1:], ndim - 1 entries
+    const void *orig;        // ring of orig_ring_rows planes
+    void *recon;             // ring of ring_rows planes, as in1 / in2
+    const void *in1[4];      // b (b-form) or d_k-1 (d-form), per reference axis
+    const void *in2[4];      // d_k (d-form)
+    const void *next1, *next2;  // optional: axis 0's in1 / in2 of row `row1` as planes of their own (a row that is not in the rings yet)
+    double lambda_mu[4], tk_prev;
+    int d_form;
+    int64_t row0, row1, top; // rows rebuilt; the first row beyond the block (a Jia-Zhao top face: its axis-0 accumulator is zero)
+    int64_t ring_rows, orig_ring_rows;
+};
+int recon_rebuild(const RebuildArgs &a, hipStream_t s);
 void io_cap_lanes(int n);  // tvdn_hostio.hip: n > 0 holds a cap of n staging lanes per transfer, 0 drops that hold (counted)
 // A non-blocking stream in a hardware-queue class of its own.  The runtime multiplexes streams onto a few hardware queues
 // per PRIORITY level; two streams that share one execute in submission order, so a transfer's completion marker can sit

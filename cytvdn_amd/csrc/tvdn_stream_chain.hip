@@ -55,6 +55,14 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
     const int64_t V1 = (int64_t)P * N0;  // running rows that are uploaded
     int64_t kmax = 0;
     for (const PassDesc &pd : ps) kmax = std::max<int64_t>(kmax, pd.kk);
+    // Recon does not cross PCIe (tvdn_rebuild.hip): a pass that continues a run uploads the data term and the accumulator state,
+    // and the level-0 recon of its host rows is REBUILT from them on the rings; only the run's last pass brings recon down.  The
+    // last row of a chunk needs the axis-0 accumulator of the row after it, which is the first row of the NEXT chunk: that chunk
+    // is therefore already on the device when this one is scattered (uploads run two chunks ahead, three in-boxes), and the
+    // rebuild reads those two planes straight from its box.  Shipped as before when the cube's first row is not finite (the exact
+    // wrap keeps row 0's recon of every level, and its accumulator is not the constant zero the rebuild takes at the top face)
+    // and with a stopping rule (any pass may be the last).
+    const bool ship_recon = ships_recon();
     const int64_t n_chunks = (V1 + ps[(size_t)P - 1].kk + R - 1) / R;
     std::vector<hipEvent_t> down_done((size_t)n_chunks, nullptr);
     const int bx_recon = 1, bx_ref = 2 + nd * n_state;  // fixed box numbers: 0 data term, 1 recon, 2 + q n_state + s state
@@ -102,7 +110,7 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
         if (u0 >= u1 || host_rows_in(u0, u1) == 0) return TVDN_OK;
         int rcu = orig_ready.wait();
         if (rcu) return rcu;
-        const int h = (int)(t % 2);
+        const int h = (int)(t % 3);
         if (in_free_set[h]) TVDN_HIP(hipStreamWaitEvent(st.up, in_free[h], 0));
         int64_t s_orig = 0, s_recon = 0, s_ref = 0;
         std::vector<int64_t> s_state((size_t)nd * 2, 0);
@@ -127,8 +135,12 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                              (long long)(g1 - 1), q, q - 1);
                 TVDN_HIP(hipStreamWaitEvent(st.up, down_done[(size_t)t_out], 0));
             }
-            if ((r3 = wait_recon(0))) return r3;
-            if ((r3 = up_rows(inbox[h][bx_recon], s_recon, g0, g1, [&](int64_t g) { return host_row(recon_h, g); }, always))) return r3;
+            if (ship_recon) {
+                if ((r3 = wait_recon(0))) return r3;
+                if ((r3 = up_rows(inbox[h][bx_recon], s_recon, g0, g1, [&](int64_t g) { return host_row(recon_h, g); }, always))) return r3;
+            } else {
+                s_recon += n_host;  // rebuilt on the device: its box rows stay unused
+            }
             for (int64_t g = g0; g < g1; ++g)
                 if (!resident(g) && (r3 = sb[0].wait_for(rm.host_below(g)))) return r3;
             for (int qx = 0; qx < nd; ++qx)
@@ -151,14 +163,15 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
     };
 
     int rc2 = upload(0, 0);
+    if (!rc2) rc2 = upload(1, 0);
     if (rc2) return rc2;
     for (int64_t t = 0; t < n_chunks; ++t) {
-        if ((rc2 = upload(t + 1, t))) return rc2;  // the next chunk crosses PCIe while this one is swept
-        const int h = (int)(t % 2);
+        if ((rc2 = upload(t + 2, t))) return rc2;  // the chunk after the next crosses PCIe while this one is swept
+        const int h = (int)(t % 2), hi3 = (int)(t % 3);  // out boxes alternate, in boxes take turns by three
         const int64_t u0 = t * R, u1 = std::min((t + 1) * R, V1);
         if (u0 < u1) {
             const bool from_host = host_rows_in(u0, u1) > 0;
-            if (from_host) TVDN_HIP(hipStreamWaitEvent(st.main, in_ready[h], 0));
+            if (from_host) TVDN_HIP(hipStreamWaitEvent(st.main, in_ready[hi3], 0));
             cdst.clear();
             csrc.clear();
             int64_t slot = 0;
@@ -172,10 +185,11 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                     cdst.push_back(rg.row(v));
                     csrc.push_back((void *)src);
                 };
-                auto boxed = [&](int bx) { return inbox[h][bx] + (size_t)slot * row_bytes; };
+                auto boxed = [&](int bx) { return inbox[hi3][bx] + (size_t)slot * row_bytes; };
                 const char *o_src = res_row ? store_row(0, g) : boxed(0);
                 put(Ow, o_src);
-                put(Rw[0], pd.first ? o_src : (res_row ? store_row(1, g) : boxed(bx_recon)));
+                if (pd.first || res_row || ship_recon)  // (else: rebuilt from the state, below)
+                    put(Rw[0], pd.first ? o_src : (res_row ? store_row(1, g) : boxed(bx_recon)));
                 for (int qx = 0; qx < nd; ++qx) {
                     put(A(0, qx), pd.first ? zero_plane : (res_row ? store_row(2 + qx * n_state, g) : boxed(bx_state(qx, 0))));
                     if (pd.n_in_state == 2)
@@ -186,6 +200,64 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
             }
             rc2 = copy_rows(cdst, csrc, row_bytes, st.main);
             if (rc2) return rc2;
+            if (!ship_recon) {
+                // level-0 recon of this chunk's host rows, pass by pass (each with its own form and momentum ratio), run of host
+                // rows by run; the axis-0 accumulator of the row after a run: the next ring row, the store (a resident row), the
+                // first row of the next chunk's box (already uploaded: see above), or nothing at a pass's top face
+                bool next_box_waited = false;
+                rc2 = pieces(u0, u1, [&](int q, int64_t v_lo, int64_t v_hi) -> int {
+                    const PassDesc &pd = ps[(size_t)q];
+                    if (pd.first) return TVDN_OK;  // recon = data term: copied above
+                    RebuildArgs ra;
+                    std::memset(&ra, 0, sizeof ra);
+                    ra.dtype = a->dtype;
+                    ra.ndim = nd;
+                    for (int i = 1; i < nd; ++i) ra.plane_shape[i - 1] = a->shape[i];
+                    ra.orig = Ow.base;
+                    ra.recon = Rw[0].base;
+                    ra.d_form = pd.n_in_state == 2;
+                    for (int qx = 0; qx < nd; ++qx) {
+                        ra.in1[qx] = ra.d_form ? A(-1, qx).base : A(0, qx).base;
+                        ra.in2[qx] = ra.d_form ? A(0, qx).base : nullptr;
+                        ra.lambda_mu[qx] = a->lambda_mu[qx];
+                    }
+                    ra.tk_prev = pd.tkp.empty() ? 0.0 : pd.tkp[0];
+                    ra.top = (int64_t)(q + 1) * N0;
+                    ra.ring_rows = cap;
+                    ra.orig_ring_rows = ocap;
+                    for (int64_t v = v_lo; v < v_hi;) {
+                        if (resident(v - (int64_t)q * N0)) {  // its recon came from the store
+                            ++v;
+                            continue;
+                        }
+                        int64_t e = v + 1;
+                        while (e < v_hi && !resident(e - (int64_t)q * N0)) ++e;
+                        ra.row0 = v;
+                        ra.row1 = e;
+                        ra.next1 = ra.next2 = nullptr;
+                        if (e == u1 && e < ra.top) {  // the row after this run has not been scattered: it belongs to the next chunk
+                            const int64_t gn = e - (int64_t)q * N0;
+                            const char *n1, *n2 = nullptr;  // axis 0: state 0 = d_k (or b), state 1 = d_k-1
+                            if (resident(gn)) {
+                                n1 = store_row(2, gn);
+                                if (ra.d_form) n2 = store_row(3, gn);
+                            } else {
+                                if (!next_box_waited) TVDN_HIP(hipStreamWaitEvent(st.main, in_ready[(t + 1) % 3], 0));
+                                next_box_waited = true;
+                                n1 = inbox[(t + 1) % 3][bx_state(0, 0)];  // box row 0: the first host row of the next chunk is this very row
+                                if (ra.d_form) n2 = inbox[(t + 1) % 3][bx_state(0, 1)];
+                            }
+                            ra.next1 = ra.d_form ? n2 : n1;
+                            ra.next2 = ra.d_form ? n1 : nullptr;
+                        }
+                        const int r3 = recon_rebuild(ra, st.main);
+                        if (r3) return r3;
+                        v = e;
+                    }
+                    return TVDN_OK;
+                });
+                if (rc2) return rc2;
+            }
             for (int64_t v = u0; v < u1; ++v) {
                 const int q = (int)(v / N0);
                 const int64_t g = v - (int64_t)q * N0;
@@ -195,8 +267,8 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                     if ((rc2 = sse_row(Rw[0].row(v), Fw.row(v), 0, g))) return rc2;
             }
             if (from_host) {
-                TVDN_HIP(hipEventRecord(in_free[h], st.main));
-                in_free_set[h] = true;
+                TVDN_HIP(hipEventRecord(in_free[hi3], st.main));
+                in_free_set[hi3] = true;
             }
         }
         // the wavefront: level j+1 trails level j by one running row; a launch is cut at the seam between two passes
@@ -250,6 +322,7 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
         for (int q = 0; q < P; ++q) {
             const PassDesc &pd = ps[(size_t)q];
             const int64_t lo = std::max<int64_t>((int64_t)q * N0, t * R - pd.kk), hi = std::min<int64_t>((int64_t)(q + 1) * N0, (t + 1) * R - pd.kk);
+            const bool recon_down = ship_recon || pd.last;  // a host row's recon goes home only when somebody will read it there
             if (lo >= hi) continue;
             // The run's last pass: the state of a resident row is not needed again, and its result can cross PCIe under
             // the pass (the link has room: a hybrid run uses half of it) instead of in one piece after it -- when the
@@ -274,7 +347,7 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                     ++oslot;
                     continue;
                 }
-                put(1, 0, Rw[(size_t)pd.kk]);
+                if (res_row || recon_down) put(1, 0, Rw[(size_t)pd.kk]);
                 for (int qx = 0; qx < nd; ++qx) {
                     put(2 + qx * n_state, ox_state(qx, 0), A(pd.kk, qx));
                     if (pd.n_out_state == 2) put(2 + qx * n_state + 1, ox_state(qx, 1), A(pd.kk - 1, qx));
@@ -331,11 +404,12 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                         }
                         return TVDN_OK;
                     };
-                    if ((rc2 = down(host_row(recon_h, g), outbox[h][0] + boff))) return rc2;
+                    const bool recon_down_q = ship_recon || pd.last;
+                    if (recon_down_q && (rc2 = down(host_row(recon_h, g), outbox[h][0] + boff))) return rc2;
                     for (int qx = 0; qx < nd; ++qx)
                         for (int s = 0; s < pd.n_out_state; ++s)
                             if ((rc2 = down(sb[0].row(qx * n_state + s, hs), outbox[h][ox_state(qx, s)] + boff))) return rc2;
-                    bytes_down += (int64_t)len * (1 + (int64_t)pd.n_out_state * nd);
+                    bytes_down += (int64_t)len * ((recon_down_q ? 1 : 0) + (int64_t)pd.n_out_state * nd);
                     slot += n;
                     g += n;
                 }

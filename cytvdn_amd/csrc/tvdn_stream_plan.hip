@@ -34,7 +34,8 @@ void host_unpin_result(void *user) { (void)hipHostUnregister(user); }
 // Python side).
 int64_t stream_planes(int nd, int64_t rows, int64_t k, bool mse, bool wrap)
 {
-    return ((k + 1) + (k + 2) * nd) * (rows + 2) + (rows + k + 3) * (mse ? 2 : 1) + 2 * (3 + 4 * nd) * rows + 2 * (1 + 2 * nd) + (wrap ? 2 * (k + 1) : 0) + 1;
+    // (three in-boxes of 2 + 2 nd arrays -- uploads run two chunks ahead --, two out boxes of 1 + 2 nd arrays holding rows + 1)
+    return ((k + 1) + (k + 2) * nd) * (rows + 2) + (rows + k + 3) * (mse ? 2 : 1) + (3 * (2 + 2 * nd) + 2 * (1 + 2 * nd)) * rows + 2 * (1 + 2 * nd) + (wrap ? 2 * (k + 1) : 0) + 1;
 }
 
 // Chunk height R, depth K and the number of rows whose state STAYS in HBM between passes (the resident + streamed hybrid).
@@ -52,7 +53,10 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
 {
     const int64_t budget = (int64_t)(0.85 * (double)free_bytes / (double)row_bytes);
     const double rb = (double)row_bytes;
-    const int n_in = 2 + nd * n_state, n_out = 1 + nd * n_state, moved = 3 + nd * (n_state + 1);
+    // what a streamed row carries per pass: the data term and the state up, the state down (recon is rebuilt on the device and
+    // comes down with the last pass only, tvdn_rebuild.hip) -- with a stopping rule (k_cap == 1) recon both ways as well
+    const int ships = k_cap <= 1 ? 1 : 0;
+    const int n_in = 1 + ships + nd * n_state, n_out = ships + nd * n_state, moved = 3 + nd * (n_state + 1);
     k_cap = std::max<int64_t>(1, std::min<int64_t>({k_cap, 128, std::max<int64_t>(1, n_rows)}));
     const double row_step = std::max((double)n_in * rb / 55e9, (double)n_out * rb / 42.5e9);  // one streamed row, both directions busy
     int64_t best_k = 0, best_r = 0, best_res = 0;
@@ -82,10 +86,11 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
             //     directions together at 60 GB/s (round 4's first model, which the kept-row measurements were planned and
             //     verified with).  Not with one-row chunks: (1, 20, 47 kept) ran at 46.6 Gvoxel-iters/s where (2, 12, 56 kept)
             //     runs at 57.8 (profiles/r04_stream_rates.jsonl).
-            const int64_t res = may_keep && r > 1 ? std::min<int64_t>(n_rows, (budget - planes) / n_in) : 0;
+            const int n_store = 2 + nd * n_state;  // arrays a kept row holds in HBM: data term, recon, state
+            const int64_t res = may_keep && r > 1 ? std::min<int64_t>(n_rows, (budget - planes) / n_store) : 0;
             if (res > 0)
                 offer(res, std::max((double)(n_rows - res) * (n_in + n_out) * rb / 60e9,
-                                    t_sweeps + (double)res * (n_in + n_out) * 2.0 * rb / 4.8e12));
+                                    t_sweeps + (double)res * (2 * n_store - 1) * 2.0 * rb / 4.8e12));
         }
     }
     if (best_k < 1) {
@@ -144,7 +149,7 @@ size_t stream_device_bytes(int nd, int n_state, bool want_mse, int64_t R, int64_
     const size_t box_b = aligned((size_t)R * row_bytes), obox_b = aligned((size_t)(R + 1) * row_bytes), plane_b = aligned(row_bytes);
     const size_t n_rings = (size_t)(K + 1) + (size_t)(K + 2) * nd;
     if (per_resident_row) *per_resident_row = (size_t)n_store * plane_b;
-    return n_rings * ring_b + oring_b * (want_mse ? 2 : 1) + 2 * ((size_t)n_in * box_b + (size_t)n_out * obox_b) + 2 * (size_t)(K + 1) * plane_b + plane_b;
+    return n_rings * ring_b + oring_b * (want_mse ? 2 : 1) + 3 * (size_t)n_in * box_b + 2 * (size_t)n_out * obox_b + 2 * (size_t)(K + 1) * plane_b + plane_b;
 }
 
 // What one slab of a multi-process streamed run holds where: the depth its passes settle on (= the halo rows it keeps of each

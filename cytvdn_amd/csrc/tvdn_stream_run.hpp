@@ -80,15 +80,15 @@ struct StreamRun {
     char *cursor = nullptr;
     std::vector<Ring> Rw, Aw;  // recon rings by level; accumulator rings [level + 1][axis]
     Ring Ow, Fw;               // data term, reference
-    char *inbox[2][12], *outbox[2][12];
+    char *inbox[3][12], *outbox[2][12];  // chain() uploads two chunks ahead (three in-boxes); pass() uses two of them
     char *zero_plane = nullptr;
     std::vector<char *> row0, row0b;  // row 0 of every level, kept for the top face (second set: two chained passes at a seam)
     char *row0b_base = nullptr;
     std::vector<char *> store;        // resident rows, packed: 0 data term, 1 recon, 2 + q * n_state + s state
     int discard = 0;
     Events evs;
-    hipEvent_t in_ready[2], in_free[2], out_ready[2], out_free[2];
-    bool in_free_set[2] = {false, false}, out_free_set[2] = {false, false};
+    hipEvent_t in_ready[3], in_free[3], out_ready[2], out_free[2];
+    bool in_free_set[3] = {false, false, false}, out_free_set[2] = {false, false};
     std::thread pinner, stager;  // helper threads: page-lock the host state / stage the resident rows' data term
     int h_old = 0;               // which set holds the current state (two sets: periodic runs, slabs)
     bool local_rows = false;
@@ -111,6 +111,8 @@ struct StreamRun {
     // ---- small helpers (the lambdas of round 4) -------------------------------------------------------------------------------------
     static double since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); }
     static size_t aligned(size_t b) { return (b + 255) / 256 * 256; }
+    // chain(): recon crosses PCIe every pass (round 4's way) instead of being rebuilt from the state at level 0 (tvdn_rebuild.hip)
+    bool ships_recon() const { return exact_wrap || a->use_stop || getenv("TVDN_STREAM_SHIP_RECON") != nullptr; }
     int depth_of_pass(int q) const { return a->use_stop ? 1 : n_total / n_pass_plan + (q < n_total % n_pass_plan ? 1 : 0); }
     bool resident(int64_t g) const { return RES > 0 && rm.resident(g); }
     char *host_row(const HostArr &h, int64_t g) const { return h.cube_rows ? h.p + (size_t)g * row_bytes : h.p + (size_t)rm.host_below(g) * row_bytes; }

@@ -92,6 +92,15 @@ int tvdn_datacube_update(tvdn_ctx *ctx, int dtype, int ndim, const int64_t *shap
                          void *recon, const void *const *b, const double *lambda_mu, int bc_mode,
                          double *sums_out, void *stream);
 
+/* ABI 7.  datacube_update_{3D,4D} (cyTVDN/utils.pyx:54-125, :131-199, Jia-Zhao / periodic wrap inside a plane) on the COMPACT
+ * state: recon <- orig - sum_ax lambda_mu[ax] * (b_ax - b_ax[next along ax]) with b_ax = d_ax + tk_prev (d_ax - dprev_ax) when
+ * `dprev` is given (the expression that formed b, anisotropic.pyx:128), else b_ax = d_ax as they are.  Bit-identical to the
+ * recon the iteration that left this state behind wrote -- which is why a streamed run does not carry recon across PCIe between
+ * its passes (csrc/tvdn_rebuild.hip).  Rows [row0, row1) of a block of shape[0] rows; past the last row the axis-0 accumulator
+ * reads as zero (the Jia-Zhao wrap onto a finite first row).  `d` / `dprev`: HOST arrays of ndim device pointers. */
+int tvdn_recon_from_state(int dtype, int ndim, const int64_t *shape, const void *orig, void *recon, const void *const *d,
+                          const void *const *dprev, const double *lambda_mu, double tk_prev, int64_t row0, int64_t row1, void *stream);
+
 /* sum_square_error_{3D,4D}  (cyTVDN/utils.pyx:35-49, :14-30):  *out <- sum (a-b)^2. */
 int tvdn_sum_square_error(tvdn_ctx *ctx, int dtype, int ndim, const int64_t *shape, const void *a,
                           const void *b, double *out, void *stream);

@@ -476,3 +476,48 @@ def test_streamed_device_list_mse_in_place_and_nonfinite_first_row(oracle):
         got = _run(x, mu, n_f, n_p, stream=stream, devices=devs, stop=stop)
         ref = _oracle(oracle, x, mu, n_f, n_p, stopping_relative_change=stop)
         assert np.isnan(ref["recon"][-1]).any() and bits_equal(got[0], ref["recon"]), devs
+
+
+@pytest.mark.parametrize("shape,dtype,n_f,n_p,rows,k,chain", [
+    ((24, 3, 4, 8), np.float32, 12, 0, 2, 4, "1"), ((24, 3, 4, 8), np.float32, 12, 0, 2, 4, "0"),
+    ((24, 3, 4, 8), np.float32, 5, 7, 3, 4, "1"),            # hybrid: the last FISTA pass leaves b, the rebuild follows the form
+    ((30, 6, 16), np.float64, 0, 9, 1, 3, "1"), ((30, 6, 16), np.float64, 8, 0, 4, 2, "0"),
+])
+def test_recon_does_not_cross_pcie_between_passes(oracle, monkeypatch, shape, dtype, n_f, n_p, rows, k, chain):
+    """Round 5: a pass that continues a run uploads the data term and the accumulator state only -- recon is rebuilt from them on
+    the device (csrc/tvdn_rebuild.hip: the reconstruction update of cyTVDN/utils.pyx:90-104 applied to state that is already
+    there) -- and only the last pass brings recon down.  Same bits as the oracle and as the run that ships recon
+    (TVDN_STREAM_SHIP_RECON=1, round 4's way); the byte counts say which of the two ran."""
+    from cytvdn_amd import _lib, synth
+    monkeypatch.setenv("TVDN_STREAM_CHAIN", chain)
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=43, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    n = n_f + n_p
+    ref = _oracle(oracle, x, mu, n_f, n_p)
+    cube = x.nbytes
+    seen = {}
+    for ship in (False, True):
+        if ship:
+            monkeypatch.setenv("TVDN_STREAM_SHIP_RECON", "1")
+        else:
+            monkeypatch.delenv("TVDN_STREAM_SHIP_RECON", raising=False)
+        st = _lib.RunStats()
+        got = _run(x, mu, n_f, n_p, stream=(rows, k), resident=0, stats=st)
+        assert bits_equal(got[0], ref["recon"]) and got[3] == n, ship
+        _check_traces(got[1], ref, n)
+        seen[ship] = (st.h2d_bytes, st.d2h_bytes, st.n_passes)
+    P = seen[False][2]
+    assert P == seen[True][2] >= 3
+    # arrays of state a pass carries: d pairs while the iterations before / after it are FISTA ones, b afterwards
+    depth = [n // P + (1 if q < n % P else 0) for q in range(P)]
+    start = [sum(depth[:q]) for q in range(P)]
+    n_in = [0 if q == 0 else nd * (2 if start[q] <= n_f and n_f > 0 and start[q] - 1 < n_f else 1) for q in range(P)]
+    n_out = [nd * (2 if start[q] + depth[q] <= n_f and n_f > 0 else 1) for q in range(P)]
+    up_free = cube * sum(1 + n_in[q] for q in range(P))
+    down_free = cube * (sum(n_out) + 1)                       # ... + recon once, with the last pass
+    up_ship = cube * sum(1 + n_in[q] + (1 if q else 0) for q in range(P))
+    down_ship = cube * sum(n_out[q] + 1 for q in range(P))
+    assert seen[False][:2] == (up_free, down_free), (seen, up_free, down_free)
+    assert seen[True][:2] == (up_ship, down_ship), (seen, up_ship, down_ship)
