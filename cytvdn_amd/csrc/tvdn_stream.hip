@@ -337,10 +337,10 @@ int StreamRun::set_up(bool &nothing_to_do)
     for (Ring &r : Aw) r = Ring{take(ring_b), cap, row_bytes};
     Ow = Ring{take(oring_b), ocap, row_bytes};
     if (want_mse) Fw = Ring{take(oring_b), ocap, row_bytes};
-    for (int h = 0; h < 3; ++h)
+    for (int h = 0; h < 2; ++h) {
         for (int i = 0; i < n_in; ++i) inbox[h][i] = take(box_b);
-    for (int h = 0; h < 2; ++h)
         for (int i = 0; i < n_out; ++i) outbox[h][i] = take(obox_b);
+    }
     zero_plane = take(plane_b);  // the accumulator state a run starts from (cyTVDN.py:131-145): the first pass uploads none
     row0b_base = nullptr;
     if (exact_wrap) {
@@ -361,10 +361,8 @@ int StreamRun::set_up(bool &nothing_to_do)
         TVDN_HIP(hipMalloc(&mse_d.p, sizeof(double) * (size_t)(n_total + 1) * (size_t)N0));
         TVDN_HIP(hipMemsetAsync(mse_d.p, 0, sizeof(double) * (size_t)(n_total + 1) * (size_t)N0, st.main));
     }
-    for (int h = 0; h < 3; ++h)
-        if ((rc = evs.make(&in_ready[h])) || (rc = evs.make(&in_free[h]))) return rc;
     for (int h = 0; h < 2; ++h)
-        if ((rc = evs.make(&out_ready[h])) || (rc = evs.make(&out_free[h]))) return rc;
+        if ((rc = evs.make(&in_ready[h])) || (rc = evs.make(&in_free[h])) || (rc = evs.make(&out_ready[h])) || (rc = evs.make(&out_free[h]))) return rc;
 
     stager = std::thread([this] {  // resident rows of the data term: pageable `data` -> store, through the library's pinned lanes
         if (sh && RES <= 0) {
@@ -453,7 +451,7 @@ int StreamRun::schedule()
     // Default: chain from 3 passes on when no row is resident; TVDN_STREAM_CHAIN=1 / 0 forces it on (where possible) / off.
     bool want_chain = RES == 0 && n_pass_plan >= 3 && !sh;
     if (const char *e = getenv("TVDN_STREAM_CHAIN")) want_chain = atoi(e) != 0;
-    const bool can_chain = want_chain && !periodic && !a->use_stop && n_pass_plan > 1 && K <= N0 - 4 * R  /* uploads run two chunks ahead */;
+    const bool can_chain = want_chain && !periodic && !a->use_stop && n_pass_plan > 1 && K <= N0 - 3 * R;
     down_blocks = can_chain ? 8 : 0;
     if (const char *e = getenv("TVDN_STREAM_DOWN_BLOCKS")) down_blocks = std::max(0, atoi(e));
     if (!periodic && exact_wrap)

@@ -57,9 +57,9 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
     for (const PassDesc &pd : ps) kmax = std::max<int64_t>(kmax, pd.kk);
     // Recon does not cross PCIe (tvdn_rebuild.hip): a pass that continues a run uploads the data term and the accumulator state,
     // and the level-0 recon of its host rows is REBUILT from them on the rings; only the run's last pass brings recon down.  The
-    // last row of a chunk needs the axis-0 accumulator of the row after it, which is the first row of the NEXT chunk: that chunk
-    // is therefore already on the device when this one is scattered (uploads run two chunks ahead, three in-boxes), and the
-    // rebuild reads those two planes straight from its box.  Shipped as before when the cube's first row is not finite (the exact
+    // last row of a chunk needs the axis-0 accumulator of the row after it, which is the first row of the NEXT chunk: the rebuild
+    // reads those two planes straight from that chunk's in-box, i.e. chunk t is scattered once chunk t + 1 has arrived (its
+    // upload started when chunk t - 1 left the box, a whole chunk's sweeps ago).  Shipped as before when the cube's first row is not finite (the exact
     // wrap keeps row 0's recon of every level, and its accumulator is not the constant zero the rebuild takes at the top face)
     // and with a stopping rule (any pass may be the last).
     const bool ship_recon = ships_recon();
@@ -110,7 +110,7 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
         if (u0 >= u1 || host_rows_in(u0, u1) == 0) return TVDN_OK;
         int rcu = orig_ready.wait();
         if (rcu) return rcu;
-        const int h = (int)(t % 3);
+        const int h = (int)(t % 2);
         if (in_free_set[h]) TVDN_HIP(hipStreamWaitEvent(st.up, in_free[h], 0));
         int64_t s_orig = 0, s_recon = 0, s_ref = 0;
         std::vector<int64_t> s_state((size_t)nd * 2, 0);
@@ -163,15 +163,14 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
     };
 
     int rc2 = upload(0, 0);
-    if (!rc2) rc2 = upload(1, 0);
     if (rc2) return rc2;
     for (int64_t t = 0; t < n_chunks; ++t) {
-        if ((rc2 = upload(t + 2, t))) return rc2;  // the chunk after the next crosses PCIe while this one is swept
-        const int h = (int)(t % 2), hi3 = (int)(t % 3);  // out boxes alternate, in boxes take turns by three
+        if ((rc2 = upload(t + 1, t))) return rc2;  // the next chunk crosses PCIe while this one is swept
+        const int h = (int)(t % 2);
         const int64_t u0 = t * R, u1 = std::min((t + 1) * R, V1);
         if (u0 < u1) {
             const bool from_host = host_rows_in(u0, u1) > 0;
-            if (from_host) TVDN_HIP(hipStreamWaitEvent(st.main, in_ready[hi3], 0));
+            if (from_host) TVDN_HIP(hipStreamWaitEvent(st.main, in_ready[h], 0));
             cdst.clear();
             csrc.clear();
             int64_t slot = 0;
@@ -185,7 +184,7 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                     cdst.push_back(rg.row(v));
                     csrc.push_back((void *)src);
                 };
-                auto boxed = [&](int bx) { return inbox[hi3][bx] + (size_t)slot * row_bytes; };
+                auto boxed = [&](int bx) { return inbox[h][bx] + (size_t)slot * row_bytes; };
                 const char *o_src = res_row ? store_row(0, g) : boxed(0);
                 put(Ow, o_src);
                 if (pd.first || res_row || ship_recon)  // (else: rebuilt from the state, below)
@@ -203,7 +202,7 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
             if (!ship_recon) {
                 // level-0 recon of this chunk's host rows, pass by pass (each with its own form and momentum ratio), run of host
                 // rows by run; the axis-0 accumulator of the row after a run: the next ring row, the store (a resident row), the
-                // first row of the next chunk's box (already uploaded: see above), or nothing at a pass's top face
+                // first row of the next chunk's box (its upload has been queued: a wait away), or nothing at a pass's top face
                 bool next_box_waited = false;
                 rc2 = pieces(u0, u1, [&](int q, int64_t v_lo, int64_t v_hi) -> int {
                     const PassDesc &pd = ps[(size_t)q];
@@ -242,10 +241,10 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                                 n1 = store_row(2, gn);
                                 if (ra.d_form) n2 = store_row(3, gn);
                             } else {
-                                if (!next_box_waited) TVDN_HIP(hipStreamWaitEvent(st.main, in_ready[(t + 1) % 3], 0));
+                                if (!next_box_waited) TVDN_HIP(hipStreamWaitEvent(st.main, in_ready[(t + 1) % 2], 0));
                                 next_box_waited = true;
-                                n1 = inbox[(t + 1) % 3][bx_state(0, 0)];  // box row 0: the first host row of the next chunk is this very row
-                                if (ra.d_form) n2 = inbox[(t + 1) % 3][bx_state(0, 1)];
+                                n1 = inbox[(t + 1) % 2][bx_state(0, 0)];  // box row 0: the first host row of the next chunk is this very row
+                                if (ra.d_form) n2 = inbox[(t + 1) % 2][bx_state(0, 1)];
                             }
                             ra.next1 = ra.d_form ? n2 : n1;
                             ra.next2 = ra.d_form ? n1 : nullptr;
@@ -267,8 +266,8 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                     if ((rc2 = sse_row(Rw[0].row(v), Fw.row(v), 0, g))) return rc2;
             }
             if (from_host) {
-                TVDN_HIP(hipEventRecord(in_free[hi3], st.main));
-                in_free_set[hi3] = true;
+                TVDN_HIP(hipEventRecord(in_free[h], st.main));
+                in_free_set[h] = true;
             }
         }
         // the wavefront: level j+1 trails level j by one running row; a launch is cut at the seam between two passes

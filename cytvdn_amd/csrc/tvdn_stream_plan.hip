@@ -34,8 +34,7 @@ void host_unpin_result(void *user) { (void)hipHostUnregister(user); }
 // Python side).
 int64_t stream_planes(int nd, int64_t rows, int64_t k, bool mse, bool wrap)
 {
-    // (three in-boxes of 2 + 2 nd arrays -- uploads run two chunks ahead --, two out boxes of 1 + 2 nd arrays holding rows + 1)
-    return ((k + 1) + (k + 2) * nd) * (rows + 2) + (rows + k + 3) * (mse ? 2 : 1) + (3 * (2 + 2 * nd) + 2 * (1 + 2 * nd)) * rows + 2 * (1 + 2 * nd) + (wrap ? 2 * (k + 1) : 0) + 1;
+    return ((k + 1) + (k + 2) * nd) * (rows + 2) + (rows + k + 3) * (mse ? 2 : 1) + 2 * (3 + 4 * nd) * rows + 2 * (1 + 2 * nd) + (wrap ? 2 * (k + 1) : 0) + 1;
 }
 
 // Chunk height R, depth K and the number of rows whose state STAYS in HBM between passes (the resident + streamed hybrid).
@@ -149,7 +148,7 @@ size_t stream_device_bytes(int nd, int n_state, bool want_mse, int64_t R, int64_
     const size_t box_b = aligned((size_t)R * row_bytes), obox_b = aligned((size_t)(R + 1) * row_bytes), plane_b = aligned(row_bytes);
     const size_t n_rings = (size_t)(K + 1) + (size_t)(K + 2) * nd;
     if (per_resident_row) *per_resident_row = (size_t)n_store * plane_b;
-    return n_rings * ring_b + oring_b * (want_mse ? 2 : 1) + 3 * (size_t)n_in * box_b + 2 * (size_t)n_out * obox_b + 2 * (size_t)(K + 1) * plane_b + plane_b;
+    return n_rings * ring_b + oring_b * (want_mse ? 2 : 1) + 2 * ((size_t)n_in * box_b + (size_t)n_out * obox_b) + 2 * (size_t)(K + 1) * plane_b + plane_b;
 }
 
 // What one slab of a multi-process streamed run holds where: the depth its passes settle on (= the halo rows it keeps of each

@@ -80,15 +80,15 @@ struct StreamRun {
     char *cursor = nullptr;
     std::vector<Ring> Rw, Aw;  // recon rings by level; accumulator rings [level + 1][axis]
     Ring Ow, Fw;               // data term, reference
-    char *inbox[3][12], *outbox[2][12];  // chain() uploads two chunks ahead (three in-boxes); pass() uses two of them
+    char *inbox[2][12], *outbox[2][12];
     char *zero_plane = nullptr;
     std::vector<char *> row0, row0b;  // row 0 of every level, kept for the top face (second set: two chained passes at a seam)
     char *row0b_base = nullptr;
     std::vector<char *> store;        // resident rows, packed: 0 data term, 1 recon, 2 + q * n_state + s state
     int discard = 0;
     Events evs;
-    hipEvent_t in_ready[3], in_free[3], out_ready[2], out_free[2];
-    bool in_free_set[3] = {false, false, false}, out_free_set[2] = {false, false};
+    hipEvent_t in_ready[2], in_free[2], out_ready[2], out_free[2];
+    bool in_free_set[2] = {false, false}, out_free_set[2] = {false, false};
     std::thread pinner, stager;  // helper threads: page-lock the host state / stage the resident rows' data term
     int h_old = 0;               // which set holds the current state (two sets: periodic runs, slabs)
     bool local_rows = false;

@@ -132,8 +132,8 @@ def state_arrays(ndim: int, fista: bool) -> int:
 def wavefront_windows(ndim: int, rows: int, k: int) -> int:
     """Rows of HBM a streamed run keeps resident for chunk height `rows` and depth k with no row of the cube resident
     (csrc/tvdn_stream.hip stream_planes, without an MSE trace: recon rings for levels 0..k, accumulator rings for levels -1..k
-    per axis, the input ring, three in boxes and two out boxes, the planes kept aside for an exact wrap)."""
-    return (((k + 1) + (k + 2) * ndim) * (rows + 2) + (rows + k + 3) + (3 * (2 + 2 * ndim) + 2 * (1 + 2 * ndim)) * rows
+    per axis, the input ring, in/out boxes, the planes kept aside for an exact wrap)."""
+    return (((k + 1) + (k + 2) * ndim) * (rows + 2) + (rows + k + 3) + 2 * (3 + 4 * ndim) * rows
             + 2 * (1 + 2 * ndim) + 2 * (k + 1) + 1)     # out boxes hold rows + 1; the planes of an exact wrap; the plane of zeros
 
 

@@ -151,7 +151,7 @@ def test_staged_slabs_match_single_process(oracle, world, shape, dtype, its, fis
 @pytest.mark.parametrize("world,shape,dtype,its,fista,stop,hbm", [
     (2, (40, 8, 32, 64), "float32", 9, True, None, "12M"),      # a slab's state (22 MB) exceeds what a rank may count on: streamed
     (3, (45, 8, 32, 64), "float32", [5, 3], True, None, "12M"),  # ... three ranks, hybrid schedule
-    (2, (40, 8, 32, 64), "float32", 30, True, 0.05, "14M"),      # ... with a stopping rule: one iteration per pass (a 2-row window with three in-boxes: 11.3 MB)
+    (2, (40, 8, 32, 64), "float32", 30, True, 0.05, "12M"),      # ... with a stopping rule: one iteration per pass
     (2, (40, 8, 32, 64), "float32", 9, True, None, "1G"),        # room to spare: the slabs stay resident, halo rows over the wire
 ], ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
 def test_staged_auto_lets_the_planner_decide(oracle, monkeypatch, world, shape, dtype, its, fista, stop, hbm):
