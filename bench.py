@@ -137,6 +137,8 @@ def cpu_baseline(target_s, x_host=None):
     oracle.set_threads(cores)
     if x_host is not None:
         x, what = x_host, "BASELINE config 2 in full"
+        if not x.flags.writeable:      # the reference's kernels take writable buffers only, also in read-only roles
+            x = np.array(x)
     else:
         x, what = synth.stem4d((16, 256, 128, 128), dtype=np.float32), "a 16-row slice (1/16) of config 2: host memory is short"
     shape = x.shape

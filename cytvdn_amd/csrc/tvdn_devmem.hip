@@ -37,6 +37,7 @@
 #include <chrono>
 #include <mutex>
 #include <random>
+#include <thread>
 #include <unordered_map>
 
 #include "tvdn_common.hpp"
@@ -233,8 +234,23 @@ hipError_t dev_free(void *p)
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(b.device);
     (void)hipDeviceSynchronize();  // as hipFree does: nothing in flight may still touch the range when it is unmapped
+    size_t free0 = 0, total0 = 0;
+    (void)hipMemGetInfo(&free0, &total0);
     release_block(b, b.handles.size());
     tlb_flush();                   // ... and no translation of it may outlive it (the addresses come back with the next block)
+    // hipMemRelease returns before the driver has the memory back (it clears released pages in the background): a caller that
+    // plans its next block by hipMemGetInfo right away would see it still missing -- the streamed bench entry kept 53 rows
+    // resident instead of 56 that way.  hipFree has come back with the memory; so does this, within reason.
+    if (b.va_bytes >= (size_t(1) << 30)) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            size_t f = 0, t = 0;
+            if (hipMemGetInfo(&f, &t) != hipSuccess || f >= free0 + b.va_bytes / 10 * 9) break;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 3.0) break;
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+        (void)hipGetLastError();
+    }
     if (prev >= 0) (void)hipSetDevice(prev);
     return hipSuccess;
 }
