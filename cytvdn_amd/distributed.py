@@ -90,7 +90,7 @@ def denoise_slabs(my_rows, global_shape, mu, iterations=10, FISTA=True, stopping
         plan = [None]
         if rank == 0:
             p = plan_run(tuple(int(v) for v in global_shape), dtype, FISTA, world, stop=stopping_relative_change is not None,
-                         device=device)
+                         device=device, swap_through_host=dist.get_backend(group) != "nccl")
             plan[0] = None if p["mode"] in ("slabs", "in-core") else (p["mode"], p.get("chunk_rows"), p.get("k"),
                                                                        p.get("resident_rows_per_rank", -1), p["why"])
         dist.broadcast_object_list(plan, src=0 if group is None else dist.get_global_rank(group, 0), group=group)

@@ -115,7 +115,7 @@ def check_host_fits(plan: dict, ranks_on_host: int = 1) -> None:
     need = plan.get("host_bytes_per_rank")
     if not need:
         return
-    need *= max(1, int(ranks_on_host))
+    need = (need + (plan.get("host_beside_per_rank") or 0)) * max(1, int(ranks_on_host))
     avail = host_available()
     if avail is not None and need > HOST_FRACTION * avail:
         raise MemoryError(f"streaming this cube needs {need / 2 ** 30:.1f} GiB of page-locked host memory "
@@ -138,12 +138,14 @@ def wavefront_windows(ndim: int, rows: int, k: int) -> int:
 
 
 def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int = None, stop: bool = False,
-             device: int = 0, host_bytes: int = None) -> dict:
+             device: int = 0, host_bytes: int = None, swap_through_host: bool = False) -> dict:
     """Pick the engine and the slab count for a cube of `shape` / `dtype` on `n_gpus` GPUs of `hbm_bytes` each.
 
     Returns a dict: mode, n_slabs, arrays, bytes_per_gpu (HBM the chosen mode needs per GPU), state_bytes (whole
-    state), hbm_bytes (what was assumed available), chunk_rows / k for streamed modes, host_bytes_per_rank for them,
-    min_slabs_in_core (smallest slab count whose slab state fits, or None), and a one-line `why`."""
+    state), hbm_bytes (what was assumed available), chunk_rows / k for streamed modes, host_bytes_per_rank for them
+    (page-locked) and host_beside_per_rank (what a rank of denoise_slabs holds beside that in the same memory: its slab, the
+    result, and with `swap_through_host` -- gloo -- the rows of one swap in flight), min_slabs_in_core (smallest slab count
+    whose slab state fits, or None), and a one-line `why`."""
     shape = tuple(int(s) for s in shape)
     nd = len(shape)
     if nd not in (3, 4):
@@ -213,8 +215,13 @@ def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int =
         # by the library's model (csrc/tvdn_stream.hip choose_stream_shape: a row crosses the busy link in max(up / 55,
         # down / 42.5 GB/s), 60 GB/s both ways when rows are kept; ring sweeps at 0.82 x 5.6 TB/s, 0.77 x in one-row chunks;
         # device copies at 4.8 TB/s) AMONG those whose page-locked state fits 80 % of the host memory n_gpus ranks share.
+        # What the ranks hold is what distributed._check_hosts_hold_the_slabs will add up before any of them pins: the
+        # page-locked arrays, the slab and its result as the caller holds them, the rows of a swap that goes through host memory.
         host = host_bytes if host_bytes is not None else host_available()
         host_cap = None if host is None else HOST_FRACTION * host / s
+
+        def beside(k):
+            return (2 * rows_own + (2 * k * (1 + nd * n_state) if swap_through_host else 0)) * plane
         rb = float(plane)
         row_step = max(n_in * rb / 55e9, n_out * rb / 42.5e9)
         best = fallback = None
@@ -231,7 +238,7 @@ def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int =
                     cand = (max(t_pcie, t_gpu) / k, k, rows, res, host_arrays * (rows_own + 2 * k - res) * plane)
                     if fallback is None or cand[4] < fallback[4]:
                         fallback = cand                                  # the plan that page-locks least, should none fit
-                    if (host_cap is None or cand[4] <= host_cap) and (best is None or cand[0] < best[0]):
+                    if (host_cap is None or cand[4] + beside(k) <= host_cap) and (best is None or cand[0] < best[0]):
                         best = cand
         fits_host = best is not None
         if best is None:
@@ -240,6 +247,7 @@ def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int =
             t, k, rows, res, host_need = best
             out.update(mode="slabs+wavefront", n_slabs=s, chunk_rows=rows, k=k, resident_rows_per_rank=int(res),
                        bytes_per_gpu=(wavefront_windows(nd, rows, k) + res * n_in) * plane, host_bytes_per_rank=int(host_need),
+                       host_beside_per_rank=int(beside(k)),
                        seconds_per_iteration_model=t,
                        why=f"state of {out['state_bytes'] / 2 ** 30:.1f} GiB exceeds {s} x {avail / 2 ** 30:.1f} GiB of HBM: every "
                            f"rank streams its slab from pinned host memory, {res} of its {rows_own} rows resident in HBM")
