@@ -21,12 +21,15 @@ def main():
     o = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/first_node"
     print(open(os.path.join(o, "summary.txt")).read().rstrip())
     base = None
-    for name in sorted((f for f in os.listdir(o) if f.startswith("bench_gpus_") and f.endswith(".out")),
-                       key=lambda f: int(f[len("bench_gpus_"):-4])):
+    def key(f):          # bench_gpus_2.out, bench_gpus_2_plain.out (TVDN_VMM=0: the state on plain hipMalloc memory)
+        n, _, variant = f[len("bench_gpus_"):-4].partition("_")
+        return int(n), variant
+
+    for name in sorted((f for f in os.listdir(o) if f.startswith("bench_gpus_") and f.endswith(".out")), key=key):
         d = last_json(os.path.join(o, name))
-        n = int(name[len("bench_gpus_"):-4])
+        n, variant = key(name)
         if d is None:
-            print(f"--gpus {n}: no JSON line (see {name[:-4]}.err)")
+            print(f"--gpus {n}{' ' + variant if variant else ''}: no JSON line (see {name[:-4]}.err)")
             continue
         pf = d.get("preflight") or {}
         per_gpu = d["value"] / max(1, d["n_gpus"])
@@ -34,7 +37,8 @@ def main():
             base = d["value"]
         eff = f", {d['value'] / base:.2f}x the 1-GPU line" if base else ""
         ok = (pf.get("ranks_seen") in (None, d["n_gpus"])) and (pf.get("distinct_gpus") in (None, d["n_gpus"]))
-        print(f"--gpus {n}: {d['value']} {d['unit']} ({per_gpu:.1f} per GPU{eff}), {d['ms_per_step']} ms per step, "
+        print(f"--gpus {n}{' ' + variant if variant else ''}: {d['value']} {d['unit']} ({per_gpu:.1f} per GPU{eff}), {d['ms_per_step']} ms per step, "
+              f"state on {d['config'].get('state_mem')}, "
               f"transport {d['config'].get('transport')}, overlap {d['config'].get('overlap')}, fallback {d.get('transport_fallback')}, "
               f"preflight overlap/blocking {pf.get('overlap')}/{pf.get('blocking')}, ranks seen {pf.get('ranks_seen')} of {pf.get('world')}, "
               f"distinct GPUs {pf.get('distinct_gpus')}{'' if ok else '  <-- NOT one GPU per rank'}, roofline frac {d['roofline']['frac']}")

@@ -10,6 +10,10 @@
 #   4. tools/device_list_streamed.py     the same structure inside ONE process: tvdn_run with the node's GPUs as a device list,
 #                                        every slab streamed from host arrays the slabs share (no launcher, no messages)
 #   5. tools/first_node_report.py        one page: what ran, what it gave, scaling efficiency against the 1-GPU line
+# Since round 5 a state of 2 GiB or more lives on 1 GiB granules of HIP virtual memory (csrc/tvdn_devmem.hip) -- memory RCCL has
+# never been handed on hardware either.  The 2-GPU bench therefore runs twice, the second time with TVDN_VMM=0 (plain hipMalloc):
+# if only the first fails, the granules are the cause and TVDN_VMM=0 is the way round it; if both run, the pair is the first
+# measurement of placement under an exchange.
 # Usage (on the node, from the repo root):   bash tools/first_node_run.sh [OUTDIR]
 # Rehearsal on a one-GPU box (several ranks share the GPU, halo rows staged through host memory over gloo; at most 6 processes
 # may use a GPU at once on the pool's boxes, launcher included: 4 ranks is the most that rehearses safely):   TVDN_DIST_BACKEND=gloo REHEARSE_RANKS="2 4" REHEARSE_SHAPE=1 bash tools/first_node_run.sh
@@ -36,6 +40,7 @@ for n in $RANKS; do
     step bench_gpus_$n 300 python3 bench.py --gpus "$n" --steps 6 --warmup 2 --shape $((2 * n))x64x64x64
   elif [ "$n" -le "$NGPU" ]; then
     step bench_gpus_$n 900 python3 bench.py --gpus "$n" --steps 10 --warmup 3
+    if [ "$n" -eq 2 ]; then TVDN_VMM=0 step bench_gpus_2_plain 900 python3 bench.py --gpus 2 --steps 10 --warmup 3; fi
   else
     echo "bench_gpus_$n skipped: $NGPU GPUs" | tee -a "$O/summary.txt"
   fi
