@@ -449,7 +449,11 @@ def api_streamed(shape, rows, k, iters, what, x=None, device=0, force_stream=Fal
         a.shape[i] = int(v)
     if force_stream and rows < 0:
         # the library's own (rows, k, resident rows) for a STREAMED run of this cube, even where the whole state would fit
+        import gc
+        gc.collect()
         torch.cuda.empty_cache()
+        free_b, total_b = torch.cuda.mem_get_info(device)
+        entry["hbm_free_GiB_at_plan"] = round((free_b + _lib.state_kept_bytes(device)) / 2 ** 30, 2)
         po = _lib.StreamPlanOut()
         _lib.check(_lib.lib().tvdn_stream_plan(C.byref(a), 0, C.byref(po)))
         a.stream_rows, a.stream_k, a.stream_resident = int(po.rows), int(po.k), int(po.resident_rows)
@@ -748,8 +752,8 @@ def main():
             out["hipmalloc_placements"] = best_placement
         if sustained is not None:
             out["sustained"] = sustained
-        if also is not None:
-            out["also"] = also + (api or [])
+        if also is not None or api:
+            out["also"] = (also or []) + (api or [])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -215,7 +215,7 @@ int sums_defer_end(tvdn_ctx *ctx, hipStream_t s);
 int ensure_partials(tvdn_ctx *ctx, long long nblocks);
 // tvdn_stream.hip: the out-of-core branch of tvdn_run
 int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_bytes, bool mse, bool wrap, int n_state, bool may_keep,
-                        int64_t k_cap, int64_t *rows_out, int64_t *k_out, int64_t *res_out);
+                        int64_t k_cap, int64_t *rows_out, int64_t *k_out, int64_t *res_out, int64_t n_iters = 0);
 // One slab of a streamed DEVICE-LIST run (tvdn_stream.hip run_streamed_slabs): the cube's state lives in page-locked host
 // arrays shared by all slabs of the process -- two sets, a pass reads one and writes the other, so a slab may read its
 // neighbours' rows (k of them beyond each interior face: the trapezoid of a temporally blocked pass) while they write theirs.

@@ -881,7 +881,8 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
             int64_t rows = 0, k = 0, res = 0;
             const bool keep = a->bc_mode == TVDN_BC_JIA_ZHAO && !(a->mse_out && a->reference) && a->stream_resident != 0;
             const int rc2 = tvdn::choose_stream_shape(a->ndim, a->shape[0], row_bytes, (size_t)pl.free_bytes, a->mse_out && a->reference, true,
-                                                      a->n_fista > 0 ? 2 : 1, keep, a->use_stop ? 1 : a->n_fista + a->n_plain, &rows, &k, &res);
+                                                      a->n_fista > 0 ? 2 : 1, keep, a->use_stop ? 1 : a->n_fista + a->n_plain, &rows, &k, &res,
+                                                      a->use_stop ? 0 : a->n_fista + a->n_plain);
             if (rc2) return rc2;
             return tvdn::run_streamed(a, rows, k, a->stream_resident > 0 ? a->stream_resident : (keep ? res : 0));
         }
@@ -894,7 +895,8 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
             int64_t rows = 0, k = 0, res = 0;
             const int rc2 = tvdn::choose_stream_shape(a->ndim, (a->shape[0] + world - 1) / world, row_bytes, (size_t)(pl.free_bytes / same),
                                                       a->mse_out && a->reference, false, a->n_fista > 0 ? 2 : 1, false,
-                                                      a->use_stop ? 1 : a->n_fista + a->n_plain, &rows, &k, &res);
+                                                      a->use_stop ? 1 : a->n_fista + a->n_plain, &rows, &k, &res,
+                                                      a->use_stop ? 0 : a->n_fista + a->n_plain);
             if (rc2) return rc2;
             return tvdn::run_streamed_slabs(a, rows, k);
         }

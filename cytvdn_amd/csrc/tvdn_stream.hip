@@ -203,6 +203,9 @@ int StreamRun::set_up(bool &nothing_to_do)
         if (const char *e = getenv("TVDN_STREAM_RESIDENT")) rm.res = std::max<int64_t>(0, std::min<int64_t>({(int64_t)atoll(e), N0, fits(0.92)}));
     }
     RES = rm.res, HR = N0 - RES;  // rows in HBM / rows on the host
+    if (getenv("TVDN_RUN_TIMING"))
+        fprintf(stderr, "[tvdn_run streamed] device %d: %.2f GiB free (%.2f of them the kept block), rings and boxes %.2f GiB, %lld rows asked resident, %lld kept\n", device,
+                (double)free_b / 1073741824.0, (double)state_kept_bytes(device) / 1073741824.0, (double)dev_bytes_max / 1073741824.0, (long long)res_req, (long long)RES);
     // BEFORE anything of the caller's is touched: can the host hold what stays there?  (page-locked: it cannot swap)
     {
         int64_t need = 0, avail = 0;

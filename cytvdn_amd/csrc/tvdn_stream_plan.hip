@@ -48,7 +48,7 @@ int64_t stream_planes(int nd, int64_t rows, int64_t k, bool mse, bool wrap)
 // kernel down; a pass of N rows at depth K takes N + K such steps: 3 x 64 rows at K = 50 modelled 13.8 s, measured 13.8 s);
 // sweeps on rings at 0.82 x 5.6 TB/s of moved bytes (0.77 x in one-row launches); device copies at 4.8 TB/s.
 int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_bytes, bool mse, bool wrap, int n_state, bool may_keep,
-                        int64_t k_cap, int64_t *rows_out, int64_t *k_out, int64_t *res_out)
+                        int64_t k_cap, int64_t *rows_out, int64_t *k_out, int64_t *res_out, int64_t n_iters)
 {
     const int64_t budget = (int64_t)(0.85 * (double)free_bytes / (double)row_bytes);
     const double rb = (double)row_bytes;
@@ -68,9 +68,16 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
         for (int64_t k = 1; k <= k_cap; ++k) {
             const int64_t planes = stream_planes(nd, r, k, mse, wrap);
             if (planes > budget) break;
+            // With the number of iterations known, only the depths a run settles on: ceil(n / k) passes of (almost) equal depth
+            // (StreamRun::set_up).  80 iterations asked at k = 13 run as 7 passes of 12 -- and would size the rows kept for
+            // rings of 13 levels (53 rows of 256 MiB planes kept where 56 fit).
+            int64_t passes = 0;
+            if (n_iters > 0) {
+                passes = (n_iters + k - 1) / k;
+                if ((n_iters + passes - 1) / passes != k) continue;
+            }
             const double t_sweeps = (double)n_rows * (double)k * moved * rb / (5.6e12 * eff);
-            auto offer = [&](int64_t res, double t_pass) {
-                const double t = t_pass / (double)k;
+            auto offer = [&](int64_t res, double t) {  // t: seconds per iteration
                 if (best_k == 0 || t < best_t * 0.999) {
                     best_t = t;
                     best_k = k;
@@ -78,18 +85,31 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
                     best_res = res;
                 }
             };
+            auto per_iteration = [&](double t_pass) { return passes > 0 ? t_pass * (double)passes / (double)n_iters : t_pass / (double)k; };
             // (a) nothing kept: the pipeline of a pass fills and drains over K rows; chained passes share that between them
             //     (half of it counted)
-            offer(0, std::max(((double)n_rows + 0.5 * (double)std::min<int64_t>(k, n_rows)) * row_step, t_sweeps));
-            // (b) what the rest of the budget holds kept.  The streamed rows are spread over a pass that is drained, both
-            //     directions together at 60 GB/s (round 4's first model, which the kept-row measurements were planned and
-            //     verified with).  Not with one-row chunks: (1, 20, 47 kept) ran at 46.6 Gvoxel-iters/s where (2, 12, 56 kept)
-            //     runs at 57.8 (profiles/r04_stream_rates.jsonl).
+            offer(0, per_iteration(std::max(((double)n_rows + 0.5 * (double)std::min<int64_t>(k, n_rows)) * row_step, t_sweeps)));
+            // (b) what the rest of the budget holds kept.  The passes are drained, so the link works both ways at once: 68 GB/s
+            //     together when a pass waits for it.  When it does not, a row-plane takes 0.89 ms per level (the 0.82 x 5.6 TB/s
+            //     above), a kept row 1.44 ms per pass on top (its 2 x (2 n_store - 1) plane copies between store and rings, mostly
+            //     beside the sweeps: 7.1 TB/s) and a streamed row 10 ms per pass although its transfers are hidden (they share
+            //     the HBM with the sweeps).  Fitted to 32 rows of 256 MiB planes, all kept, at k = 8 and 16 (profiles/
+            //     r04_stream_rates.jsonl, run r4ah) and 64 rows, 80 iterations at k = 8 / 10 / 12 / 16 / 20 with 64 / 60 / 56 /
+            //     47 / 37 rows kept: 5.22 / 5.50 / 5.50 / 5.84 / 6.53 s measured, 5.48 / 5.72 / 5.81 / 5.83 / 7.25 modelled
+            //     (profiles/r05_hybrid_depths.jsonl).  Not with one-row chunks: (1, 20, 47 kept) ran at 46.6 Gvoxel-iters/s
+            //     where (2, 12, 56 kept) ran at 57.8.
             const int n_store = 2 + nd * n_state;  // arrays a kept row holds in HBM: data term, recon, state
             const int64_t res = may_keep && r > 1 ? std::min<int64_t>(n_rows, (budget - planes) / n_store) : 0;
-            if (res > 0)
-                offer(res, std::max((double)(n_rows - res) * (n_in + n_out) * rb / 60e9,
-                                    t_sweeps + (double)res * (2 * n_store - 1) * 2.0 * rb / 4.8e12));
+            if (res > 0) {
+                const double link = (double)(n_rows - res) * (n_in + n_out) * rb;
+                // (a pass that streams anything also waits for a fifth of one row's way up and down: 63 of 64 rows kept at k = 9
+                //  ran 5.53 s where all 64 at k = 8 ran 5.22)
+                const double fill = n_rows > res ? 0.2 * ((double)n_in * rb / 55e9 + (double)n_out * rb / 42.5e9) : 0.0;
+                const double beside = (double)res * (2 * n_store - 1) * 2.0 * rb / 7.1e12 + link / 460e9 + fill;  // per pass
+                const double sweeps_it = (double)n_rows * moved * rb / (5.6e12 * 0.82);                    // per iteration
+                const double per_it = passes > 0 ? (double)passes / (double)n_iters : 1.0 / (double)k;     // passes per iteration
+                offer(res, std::max(link / 68e9 * per_it, sweeps_it + beside * per_it));
+            }
         }
     }
     if (best_k < 1) {
@@ -254,7 +274,7 @@ extern "C" int tvdn_stream_plan(const tvdn_run_args *a, int64_t hbm_free_bytes, 
     int64_t rows = 0, k = 0, res = 0;
     const int n_total = a->n_fista + a->n_plain;
     const int rc = choose_stream_shape(a->ndim, a->shape[0], row_bytes, (size_t)hbm_free_bytes, mse, true, n_state, keep,
-                                       a->use_stop ? 1 : (n_total > 0 ? n_total : 128), &rows, &k, &res);
+                                       a->use_stop ? 1 : (n_total > 0 ? n_total : 128), &rows, &k, &res, a->use_stop ? 0 : n_total);
     if (rc) return rc;
     if (a->stream_resident > 0) res = std::min<int64_t>(res, a->stream_resident);
     out->rows = rows;

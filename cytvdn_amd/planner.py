@@ -213,8 +213,8 @@ def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int =
         # page-locks host_arrays x (own rows + 2 k halo rows - rows it keeps resident in HBM); interior rows -- none of the k
         # at a face shared with a neighbour -- stay resident as far as the HBM beside the rings allows.  The fastest (rows, k)
         # by the library's model (csrc/tvdn_stream.hip choose_stream_shape: a row crosses the busy link in max(up / 55,
-        # down / 42.5 GB/s), 60 GB/s both ways when rows are kept; ring sweeps at 0.82 x 5.6 TB/s, 0.77 x in one-row chunks;
-        # device copies at 4.8 TB/s) AMONG those whose page-locked state fits 80 % of the host memory n_gpus ranks share.
+        # down / 42.5 GB/s), 68 GB/s both ways when rows are kept; ring sweeps at 0.82 x 5.6 TB/s, 0.77 x in one-row chunks;
+        # device copies at 7.1 TB/s) AMONG those whose page-locked state fits 80 % of the host memory n_gpus ranks share.
         # What the ranks hold is what distributed._check_hosts_hold_the_slabs will add up before any of them pins: the
         # page-locked arrays, the slab and its result as the caller holds them, the rows of a swap that goes through host memory.
         host = host_bytes if host_bytes is not None else host_available()
@@ -233,8 +233,16 @@ def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int =
                 interior = max(0, rows_own - 2 * k)
                 for res in ({0, min(interior, (budget - planes) // n_in)} if rows > 1 else {0}):
                     streamed = rows_own - res
-                    t_pcie = streamed * (n_in + n_out) * rb / 60e9 if res else (streamed + 0.5 * min(k, streamed)) * row_step
-                    t_gpu = rows_own * k * moved * rb / (5.6e12 * (0.77 if rows == 1 else 0.82)) + res * (n_in + n_out) * 2 * rb / 4.8e12
+                    # (rows kept: csrc/tvdn_stream_plan.hip choose_stream_shape (b) -- 68 GB/s over the link both ways together;
+                    #  beside the sweeps a kept row's store <-> ring copies at 7.1 TB/s and 10 ms per streamed row of 256 MiB
+                    #  planes whose transfers are hidden)
+                    link = streamed * (n_in + n_out) * rb
+                    t_pcie = link / 68e9 if res else (streamed + 0.5 * min(k, streamed)) * row_step
+                    t_gpu = rows_own * k * moved * rb / (5.6e12 * (0.77 if rows == 1 else 0.82))
+                    if res:
+                        t_gpu += res * (2 * host_arrays - 1) * 2 * rb / 7.1e12 + link / 460e9
+                        if streamed:
+                            t_gpu += 0.2 * (n_in * rb / 55e9 + n_out * rb / 42.5e9)
                     cand = (max(t_pcie, t_gpu) / k, k, rows, res, host_arrays * (rows_own + 2 * k - res) * plane)
                     if fallback is None or cand[4] < fallback[4]:
                         fallback = cand                                  # the plan that page-locks least, should none fit

@@ -272,12 +272,12 @@ def test_the_streamed_plan_as_arithmetic():
     for hbm in (200 * gib, 268 * gib, 288 * gib):
         rc, full = _stream_plan((128, 1024, 256, 256), hbm)
         assert rc == 0 and full.hbm_bytes <= 0.85 * hbm
-        assert (full.rows, full.resident_rows) == (1, 0) and full.k >= 30          # PCIe-bound: depth is speed
+        assert (full.rows, full.resident_rows) == (1, 0) and full.k >= 25          # PCIe-bound: depth is speed (200 iterations: 29 = 7 passes, 34 = 6, 40 = 5)
         assert full.host_bytes == 10 * 128 * plane                                   # data term, recon, 8 accumulator arrays
         rc, half = _stream_plan((64, 1024, 256, 256), hbm)
         assert rc == 0 and half.hbm_bytes <= 0.85 * hbm
         if hbm >= 268 * gib:
-            assert half.rows == 2 and half.resident_rows >= 48 and 6 <= half.k <= 16  # most rows fit: keep them, shallow rings
+            assert half.rows == 2 and half.resident_rows >= 48 and 4 <= half.k <= 16  # most rows fit (all of them, at 268 GiB, beside rings of 5 levels): keep them, shallow rings
             assert half.host_bytes == 10 * (64 - half.resident_rows) * plane
         rc, none = _stream_plan((64, 1024, 256, 256), hbm, resident=0)
         assert rc == 0 and none.resident_rows == 0 and none.rows == 1 and none.k >= half.k and (none.k > half.k or half.resident_rows == 0)
