@@ -499,7 +499,7 @@ def api_streamed(shape, rows, k, iters, what, x=None, device=0, force_stream=Fal
         "passes_s": round(st.loop_s, 3), "setup_s": round(st.setup_s, 3), "whole_call_s": round(whole, 3),
         "h2d_GBps": round(st.h2d_bytes / st.loop_s / 1e9, 2), "d2h_GBps": round(st.d2h_bytes / st.loop_s / 1e9, 2),
         "h2d_GB": round(st.h2d_bytes / 1e9, 1), "d2h_GB": round(st.d2h_bytes / 1e9, 1),
-        "pinned_host_GiB": round(need.value / 2 ** 30, 1), "pcie_inclusive": True,
+        "kept_in_place": st.kept_in_place, "pinned_host_GiB": round(need.value / 2 ** 30, 1), "pcie_inclusive": True,
         "background_release_s": round(released, 3),
         "check": {"b_norm_last": float(sums[-1, 0])}})
     if st.n_passes > 1 and 0 < st.first_pass_s < st.loop_s and 0 < st.first_pass_iters < iters:

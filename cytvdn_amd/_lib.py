@@ -52,6 +52,8 @@ class IterArgs(C.Structure):
         ("sweep_lo", C.c_int64), ("sweep_hi", C.c_int64), ("accumulate", C.c_int32), ("reserved", C.c_int32),
         ("wrap_recon", C.c_void_p),
         ("ring_rows", C.c_int64), ("orig_ring_rows", C.c_int64),
+        ("recon_in_ring_rows", C.c_int64), ("cur_ring_rows", C.c_int64), ("prev_ring_rows", C.c_int64),
+        ("recon_out_ring_rows", C.c_int64), ("out_ring_rows", C.c_int64),
     ]
 
 
@@ -71,14 +73,14 @@ class PlanOut(C.Structure):
 
 
 class RunStats(C.Structure):
-    """struct tvdn_run_stats (include/tvdn.h, ABI 7)."""
+    """struct tvdn_run_stats (include/tvdn.h, ABI 8)."""
     _fields_ = [
         ("engine", C.c_int32), ("pipelined", C.c_int32), ("stream_rows", C.c_int32), ("stream_k", C.c_int32),
         ("resident_rows", C.c_int64), ("n_passes", C.c_int64), ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64),
         ("setup_s", C.c_double), ("loop_s", C.c_double), ("total_s", C.c_double),
         ("audition_n", C.c_int32), ("audition_kept", C.c_int32), ("audition_ms", C.c_double * 8),
         ("first_pass_s", C.c_double), ("first_pass_iters", C.c_int32), ("results_under_last_pass", C.c_int32),
-        ("state_mem", C.c_int32), ("reserved", C.c_int32),
+        ("state_mem", C.c_int32), ("kept_in_place", C.c_int32),
     ]
 
     def as_dict(self):
@@ -194,7 +196,7 @@ def lib():
     L.tvdn_state_kept_bytes.restype = C.c_int64
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header and library out of step
-    if L.tvdn_abi_version() != 7:
+    if L.tvdn_abi_version() != 8:
         raise TvdnError("libtvdn_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -73,8 +73,10 @@ struct FusedParams {
     int xcd;          // 1: remap workgroup ids so each XCD sweeps a contiguous run of tiles
     // patch order of the tiles of a cross-section (0 = plain order): patches of patch_a A-rows x patch_t tiles
     long long patch_a, patch_t, tiles_per_arow;
-    // row rings (RING instantiations only): row m of recon / accumulators lives at slot m % ring, of orig at m % ring_orig
-    unsigned ring, ring_orig;
+    // row rings (RING instantiations only): row m of r_in lives at slot m % ring, of the in1 / in2 arrays at m % ring_in1 / m %
+    // ring_in2, of r_out at m % ring_rout, of the out1 / out2 arrays at m % ring_out, of orig at m % ring_orig (one ring size for
+    // all of them but orig in a plain streamed pass; a "ring" longer than the cube is an array: rows kept in HBM, swept in place)
+    unsigned ring, ring_in1, ring_in2, ring_rout, ring_out, ring_orig;
     double *partials;
 };
 
@@ -200,17 +202,17 @@ struct ContigLoads {  // axis C
 };
 
 template <typename T, int VEC, int MODE, bool nt_own, bool nt_next>
-__device__ __forceinline__ void load_pack(PackLoads<T, VEC> &l, const T *r_row, const AxisState<T> &s, long long row,
+__device__ __forceinline__ void load_pack(PackLoads<T, VEC> &l, const T *r_row, const AxisState<T> &s, long long row1, long long row2,
                                           unsigned e0, unsigned e_prev, unsigned e_next)
 {
     using M = ModeTraits<MODE>;
     l.rp = ldb<T, VEC, false>(r_row, e_prev);
     l.rn = ldb<T, VEC, false>(r_row, e_next);
-    l.v1_own = ldb<T, VEC, nt_own>(s.in1 + row, e0);
-    l.v1_nx = ldb<T, VEC, nt_next>(s.in1 + row, e_next);
+    l.v1_own = ldb<T, VEC, nt_own>(s.in1 + row1, e0);
+    l.v1_nx = ldb<T, VEC, nt_next>(s.in1 + row1, e_next);
     if (M::kIn2) {
-        l.v2_own = ldb<T, VEC, nt_own>(s.in2 + row, e0);
-        l.v2_nx = ldb<T, VEC, nt_next>(s.in2 + row, e_next);
+        l.v2_own = ldb<T, VEC, nt_own>(s.in2 + row2, e0);
+        l.v2_nx = ldb<T, VEC, nt_next>(s.in2 + row2, e_next);
     }
 }
 
@@ -218,7 +220,7 @@ __device__ __forceinline__ void load_pack(PackLoads<T, VEC> &l, const T *r_row, 
 // +1 neighbour, add lm * (b_new(x) - b_new(x+e)) to `sum` (left-to-right as utils.c:5641).
 template <typename T, int VEC, int MODE>
 __device__ __forceinline__ void axis_pack(const Pack<T, VEC> &r_cur, const PackLoads<T, VEC> &l, const AxisState<T> &s,
-                                          long long row, unsigned e0, bool self_next, T tk, T tkp, T cl, T lm,
+                                          long long row_o, unsigned e0, bool self_next, T tk, T tkp, T cl, T lm,
                                           Pack<T, VEC> &sum, double &bnorm)
 {
     using P = Pack<T, VEC>;
@@ -234,28 +236,28 @@ __device__ __forceinline__ void axis_pack(const Pack<T, VEC> &r_cur, const PackL
         sum.v[j] = sum.v[j] + lm * (bn_own - bn_next);
         bnorm += fabs((double)bn_own);
     }
-    if (M::kOut1) stb<T, VEC>(s.out1 + row, e0, o1);
-    if (M::kOut2) stb<T, VEC>(s.out2 + row, e0, o2);
+    if (M::kOut1) stb<T, VEC>(s.out1 + row_o, e0, o1);
+    if (M::kOut2) stb<T, VEC>(s.out2 + row_o, e0, o2);
 }
 
 template <typename T, int VEC, int MODE, bool nt_own>
-__device__ __forceinline__ void load_contig(ContigLoads<T, VEC> &l, const T *r_row, const AxisState<T> &s, long long row,
+__device__ __forceinline__ void load_contig(ContigLoads<T, VEC> &l, const T *r_row, const AxisState<T> &s, long long row1, long long row2,
                                             unsigned e0, unsigned e_prev, unsigned e_next)
 {
     using M = ModeTraits<MODE>;
     l.r_before = ldb1<T>(r_row, e_prev);
     l.r_after = ldb1<T>(r_row, e_next);
-    l.v1_after = ldb1<T>(s.in1 + row, e_next);
-    l.v2_after = M::kIn2 ? ldb1<T>(s.in2 + row, e_next) : (T)0;
-    l.v1_own = ldb<T, VEC, nt_own>(s.in1 + row, e0);
-    if (M::kIn2) l.v2_own = ldb<T, VEC, nt_own>(s.in2 + row, e0);
+    l.v1_after = ldb1<T>(s.in1 + row1, e_next);
+    l.v2_after = M::kIn2 ? ldb1<T>(s.in2 + row2, e_next) : (T)0;
+    l.v1_own = ldb<T, VEC, nt_own>(s.in1 + row1, e0);
+    if (M::kIn2) l.v2_own = ldb<T, VEC, nt_own>(s.in2 + row2, e0);
 }
 
 // Contiguous axis C: neighbours inside the pack come from registers; only the element before the
 // pack and the one after it are fetched.
 template <typename T, int VEC, int MODE>
 __device__ __forceinline__ void axis_contig(const Pack<T, VEC> &r_cur, const ContigLoads<T, VEC> &l, const AxisState<T> &s,
-                                            long long row, unsigned e0, bool self_next, T tk, T tkp, T cl, T lm,
+                                            long long row_o, unsigned e0, bool self_next, T tk, T tkp, T cl, T lm,
                                             Pack<T, VEC> &sum, double &bnorm)
 {
     using P = Pack<T, VEC>;
@@ -276,8 +278,8 @@ __device__ __forceinline__ void axis_contig(const Pack<T, VEC> &r_cur, const Con
         const T bn_next = (j + 1 < VEC) ? bn_own.v[j + 1 < VEC ? j + 1 : 0] : bn_after;
         sum.v[j] = sum.v[j] + lm * (bn_own.v[j] - bn_next);
     }
-    if (M::kOut1) stb<T, VEC>(s.out1 + row, e0, o1);
-    if (M::kOut2) stb<T, VEC>(s.out2 + row, e0, o2);
+    if (M::kOut1) stb<T, VEC>(s.out1 + row_o, e0, o1);
+    if (M::kOut2) stb<T, VEC>(s.out2 + row_o, e0, o2);
 }
 
 // RING: the arrays are rings of row-planes (tvdn.h, ring_rows): the only change is where a row starts.  Row numbers
@@ -364,23 +366,28 @@ __global__ void __launch_bounds__(BLOCK) TVDN_OCCUPANCY fused_iter_kernel(FusedP
             else
                 mp = bc2 ? m0 : p.row_hi - 1;  // TVDN_EDGE_BC: Jia-Zhao -> itself, periodic -> last row
             const long long row0 = row_slot<RING>(m0, p.ring) * SM;
+            const long long row0_1 = RING ? row_slot<RING>(m0, p.ring_in1) * SM : row0, row0_2 = RING ? row_slot<RING>(m0, p.ring_in2) * SM : row0;
+            const long long row0_o = RING ? row_slot<RING>(m0, p.ring_out) * SM : row0;
             const P r_prev = ldb<T, VEC, false>(p.r_in + row_slot<RING>(mp, p.ring) * SM, e0);
-            const P v1 = ldb<T, VEC, kNtLoads>(sM.in1 + row0, e0);
+            const P v1 = ldb<T, VEC, kNtLoads>(sM.in1 + row0_1, e0);
             P v2, o1, o2;
-            if (MT::kIn2) v2 = ldb<T, VEC, kNtLoads>(sM.in2 + row0, e0);
+            if (MT::kIn2) v2 = ldb<T, VEC, kNtLoads>(sM.in2 + row0_2, e0);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 bM_cur.v[j] = acc_new<T, MODE>(r_cur.v[j], r_prev.v[j], v1.v[j], MT::kIn2 ? v2.v[j] : (T)0, tk, tkp, clM,
                                                o1.v[j], o2.v[j]);
                 acc[0] += fabs((double)bM_cur.v[j]);
             }
-            if (MT::kOut1) stb<T, VEC>(sM.out1 + row0, e0, o1);
-            if (MT::kOut2) stb<T, VEC>(sM.out2 + row0, e0, o2);
+            if (MT::kOut1) stb<T, VEC>(sM.out1 + row0_o, e0, o1);
+            if (MT::kOut2) stb<T, VEC>(sM.out2 + row0_o, e0, o2);
         }
 
         // ---- march -------------------------------------------------------------------------------
         for (long long m = m0; m < m1; ++m) {
-            const long long row = row_slot<RING>(m, p.ring) * SM;   // wave-uniform start of this row in every array
+            // wave-uniform start of this row: in r_in, in the in1 / in2 arrays, in r_out, in the out1 / out2 arrays
+            const long long row = row_slot<RING>(m, p.ring) * SM;
+            const long long row_1 = RING ? row_slot<RING>(m, p.ring_in1) * SM : row, row_2 = RING ? row_slot<RING>(m, p.ring_in2) * SM : row;
+            const long long row_ro = RING ? row_slot<RING>(m, p.ring_rout) * SM : row, row_o = RING ? row_slot<RING>(m, p.ring_out) * SM : row;
             const T *r_row = p.r_in + row;
             const bool last = (m + 1 == m1);
             const bool at_end = (m + 1 == p.row_hi);
@@ -396,11 +403,14 @@ __global__ void __launch_bounds__(BLOCK) TVDN_OCCUPANCY fused_iter_kernel(FusedP
             // is not (anisotropic.pyx:65-73).  p.wrap holds row 0's current recon; its state is that zero (the
             // state loads below then land on the own row and are discarded).
             const bool wrapz = at_end && p.hi_mode == TVDN_EDGE_WRAP;
-            const long long rown = row_slot<RING>(wrap ? p.row_lo : (wrapz ? m : m + 1), p.ring) * SM;
+            const long long mn = wrap ? p.row_lo : (wrapz ? m : m + 1);
+            const long long rown = row_slot<RING>(mn, p.ring) * SM;
+            const long long rown_1 = RING ? row_slot<RING>(mn, p.ring_in1) * SM : rown, rown_2 = RING ? row_slot<RING>(mn, p.ring_in2) * SM : rown;
+            const long long rown_o = RING ? row_slot<RING>(mn, p.ring_out) * SM : rown;
             if (look) {
                 r_next = ldb<T, VEC, false>(wrapz ? p.wrap : p.r_in + rown, e0);
-                mv1 = ldb<T, VEC, kNtLoads>(sM.in1 + rown, e0);
-                if (MT::kIn2) mv2 = ldb<T, VEC, kNtLoads>(sM.in2 + rown, e0);
+                mv1 = ldb<T, VEC, kNtLoads>(sM.in1 + rown_1, e0);
+                if (MT::kIn2) mv2 = ldb<T, VEC, kNtLoads>(sM.in2 + rown_2, e0);
             }
             // With 64-bit addresses per load this needed 144-163 VGPRs in the 4-D FISTA forms (3 waves per SIMD); with the
             // row-based buffer addressing above it is 112 (f32) / 113 (f64) there and 68-87 elsewhere.  Against the
@@ -410,9 +420,9 @@ __global__ void __launch_bounds__(BLOCK) TVDN_OCCUPANCY fused_iter_kernel(FusedP
             PackLoads<T, VEC> lA, lB;
             ContigLoads<T, VEC> lC;
             if (HAS_A)
-                load_pack<T, VEC, MODE, (kNtMask & 4) != 0, (kNtMask & 16) != 0>(lA, r_row, p.ax[iA], row, e0, eA_prev, eA_next);
-            load_pack<T, VEC, MODE, (kNtMask & 1) != 0, (kNtMask & 8) != 0>(lB, r_row, p.ax[iB], row, e0, eB_prev, eB_next);
-            load_contig<T, VEC, MODE, (kNtMask & 2) != 0>(lC, r_row, p.ax[iC], row, e0, eC_prev, eC_next);
+                load_pack<T, VEC, MODE, (kNtMask & 4) != 0, (kNtMask & 16) != 0>(lA, r_row, p.ax[iA], row_1, row_2, e0, eA_prev, eA_next);
+            load_pack<T, VEC, MODE, (kNtMask & 1) != 0, (kNtMask & 8) != 0>(lB, r_row, p.ax[iB], row_1, row_2, e0, eB_prev, eB_next);
+            load_contig<T, VEC, MODE, (kNtMask & 2) != 0>(lC, r_row, p.ax[iC], row_1, row_2, e0, eC_prev, eC_next);
             const P og = ldb<T, VEC, kNtLoads>(p.orig + (RING ? row_slot<RING>(m, p.ring_orig) * SM : row), e0);
 
             // (1) M-axis accumulator of the next row (look-ahead by one row)
@@ -432,8 +442,8 @@ __global__ void __launch_bounds__(BLOCK) TVDN_OCCUPANCY fused_iter_kernel(FusedP
                                                     MT::kIn2 ? mv2.v[j] : (T)0, tk, tkp, clM, o1.v[j], o2.v[j]);
                 // rows inside the chunk are owned here, and so is a halo row sitting at row_hi
                 if (!last || (at_end && p.hi_mode == TVDN_EDGE_HALO)) {
-                    if (MT::kOut1) stb<T, VEC>(sM.out1 + rown, e0, o1);
-                    if (MT::kOut2) stb<T, VEC>(sM.out2 + rown, e0, o2);
+                    if (MT::kOut1) stb<T, VEC>(sM.out1 + rown_o, e0, o1);
+                    if (MT::kOut2) stb<T, VEC>(sM.out2 + rown_o, e0, o2);
                 }
                 if (!last) {
 #pragma unroll
@@ -446,9 +456,9 @@ __global__ void __launch_bounds__(BLOCK) TVDN_OCCUPANCY fused_iter_kernel(FusedP
 #pragma unroll
             for (int j = 0; j < VEC; ++j) sum.v[j] = lmM * (bM_cur.v[j] - bM_next.v[j]);
             if (HAS_A)
-                axis_pack<T, VEC, MODE>(r_cur, lA, p.ax[iA], row, e0, selfA, tk, tkp, p.clip[iA], p.lm[iA], sum, acc[0]);
-            axis_pack<T, VEC, MODE>(r_cur, lB, p.ax[iB], row, e0, selfB, tk, tkp, clB, lmB, sum, acc[0]);
-            axis_contig<T, VEC, MODE>(r_cur, lC, p.ax[iC], row, e0, selfC, tk, tkp, clC, lmC, sum, acc[0]);
+                axis_pack<T, VEC, MODE>(r_cur, lA, p.ax[iA], row_o, e0, selfA, tk, tkp, p.clip[iA], p.lm[iA], sum, acc[0]);
+            axis_pack<T, VEC, MODE>(r_cur, lB, p.ax[iB], row_o, e0, selfB, tk, tkp, clB, lmB, sum, acc[0]);
+            axis_contig<T, VEC, MODE>(r_cur, lC, p.ax[iC], row_o, e0, selfC, tk, tkp, clC, lmC, sum, acc[0]);
 
             // (3) reconstruction update at row m (utils.pyx:90-104)
             P r_new;
@@ -459,7 +469,7 @@ __global__ void __launch_bounds__(BLOCK) TVDN_OCCUPANCY fused_iter_kernel(FusedP
                 acc[1] += fabs((double)df);
                 acc[2] += fabs((double)r_cur.v[j]);
             }
-            stb<T, VEC>(p.r_out + row, e0, r_new);
+            stb<T, VEC>(p.r_out + row_ro, e0, r_new);
 
             r_cur = r_next;
             bM_cur = bM_next;
@@ -536,10 +546,18 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
     p.lo_mode = a->lo_mode; p.hi_mode = a->hi_mode; p.bc = a->bc_mode;
     if (a->hi_mode == TVDN_EDGE_WRAP)  // an explicit plane, or by convention the row that follows the own rows
         p.wrap = a->wrap_recon ? (const T *)a->wrap_recon : p.r_in + a->row_hi * (p.A * p.B * p.C);
-    p.ring = (unsigned)a->ring_rows;
+    p.ring = (unsigned)(a->recon_in_ring_rows ? a->recon_in_ring_rows : a->ring_rows);
+    {   // in1 / in2 by mode (above): b_in and d_in are the state of this level, dprev_in that of the level before
+        const unsigned cur = (unsigned)(a->cur_ring_rows ? a->cur_ring_rows : a->ring_rows), prv = (unsigned)(a->prev_ring_rows ? a->prev_ring_rows : a->ring_rows);
+        const bool d_modes = mode == TVDN_ITER_FISTA_D || mode == TVDN_ITER_FISTA_D_TO_PLAIN;
+        p.ring_in1 = d_modes ? prv : cur;
+        p.ring_in2 = cur;
+    }
+    p.ring_rout = (unsigned)(a->recon_out_ring_rows ? a->recon_out_ring_rows : a->ring_rows);
+    p.ring_out = (unsigned)(a->out_ring_rows ? a->out_ring_rows : a->ring_rows);
     p.ring_orig = (unsigned)(a->ring_rows ? (a->orig_ring_rows ? a->orig_ring_rows : a->shape[0]) : 0);
     if (!p.ring && getenv("TVDN_FORCE_RING") && a->shape[0] < (1LL << 31))  // measurement knob: the ring instantiation on
-        p.ring = p.ring_orig = (unsigned)a->shape[0];                        // resident arrays (same rows, same bits)
+        p.ring = p.ring_in1 = p.ring_in2 = p.ring_rout = p.ring_out = p.ring_orig = (unsigned)a->shape[0];  // resident arrays (same rows, same bits)
     p.partials = ctx->partials;
 
     const int vec = (al && (p.C % VMAX == 0)) ? VMAX : 1;
@@ -672,16 +690,19 @@ extern "C" int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *a, double
     TVDN_REQUIRE(!(a->hi_mode == TVDN_EDGE_ZERO && a->bc_mode != TVDN_BC_JIA_ZHAO), "hi_mode ZERO is a Jia-Zhao property");
     TVDN_REQUIRE(!(a->lo_mode == TVDN_EDGE_BC && a->bc_mode == TVDN_BC_PERIODIC && a->hi_mode != TVDN_EDGE_BC),
                  "periodic BC with lo_mode BC needs the whole ring in this block (hi_mode BC)");
+    const int64_t own_rings[5] = {a->recon_in_ring_rows, a->cur_ring_rows, a->prev_ring_rows, a->recon_out_ring_rows, a->out_ring_rows};
     TVDN_REQUIRE(a->ring_rows >= 0 && a->orig_ring_rows >= 0, "negative ring size");
     TVDN_REQUIRE(a->ring_rows > 0 || a->orig_ring_rows == 0, "orig_ring_rows without ring_rows");
+    for (int64_t r : own_rings) TVDN_REQUIRE(r >= 0 && (r == 0 || a->ring_rows > 0), "a ring size of its own needs ring_rows, and none is negative");
     if (a->ring_rows > 0) {
         const long long s0 = (a->sweep_lo == 0 && a->sweep_hi == 0) ? a->row_lo : a->sweep_lo;
         const long long s1 = (a->sweep_lo == 0 && a->sweep_hi == 0) ? a->row_hi : a->sweep_hi;
         // rows of the level below that one launch reads: the swept rows, the row before and the row after
         const long long need = (s1 - s0) + ((s0 > a->row_lo || a->lo_mode == TVDN_EDGE_HALO) ? 1 : 0) +
                                ((s1 < a->row_hi || a->hi_mode == TVDN_EDGE_HALO) ? 1 : 0);
-        TVDN_REQUIRE(a->shape[0] < (1LL << 31) && a->ring_rows < (1LL << 31) && a->orig_ring_rows < (1LL << 31),
-                     "row rings index rows with 32 bits");
+        TVDN_REQUIRE(a->shape[0] < (1LL << 31) && a->ring_rows < (1LL << 31) && a->orig_ring_rows < (1LL << 31), "row rings index rows with 32 bits");
+        for (int64_t r : own_rings)
+            TVDN_REQUIRE(r < (1LL << 31) && (r == 0 || r >= need), "ring of %lld rows cannot hold the %lld rows this sweep touches", (long long)r, need);
         TVDN_REQUIRE(a->ring_rows >= need, "ring of %lld rows cannot hold the %lld rows this sweep reads",
                      (long long)a->ring_rows, need);
         TVDN_REQUIRE(a->orig_ring_rows == 0 || a->orig_ring_rows >= s1 - s0, "orig ring shorter than the sweep");

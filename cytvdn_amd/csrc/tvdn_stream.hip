@@ -624,6 +624,7 @@ int StreamRun::finish()
         s.first_pass_iters = (int32_t)depth_of_pass(0);
         s.results_under_last_pass = recon_direct ? 1 : 0;
         s.state_mem = block_kind;
+        s.kept_in_place = inplace_kind;
     }
     return TVDN_OK;
 }

@@ -64,6 +64,40 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
     // and with a stopping rule (any pass may be the last).
     const bool ship_recon = ships_recon();
     const int64_t n_chunks = (V1 + ps[(size_t)P - 1].kk + R - 1) / R;
+    // Rows kept in HBM are swept IN PLACE where their neighbours are kept too (one pass at a time: P == 1, v == g).  The store of
+    // the kept rows is a set of arrays; to a sweep an array is a ring longer than the cube (tvdn_iter_args.*_ring_rows), so level
+    // 0 reads recon and the state straight from the store and the last level writes them there, instead of a copy of every
+    // array into the level-0 rings and one out of the last level's.  In place are: level 0's inputs when every row it reads is
+    // kept (not in a run's first pass, whose inputs are the data term and zeros); the last level's outputs and `orig` when every
+    // row of the launch is kept; and when ALL rows are kept (`full`) also the state that two levels share -- level 1 reads d_k
+    // from the store, level kk - 2 writes d_k+kk-1 there, level kk - 1 reads it there -- so that such a pass copies nothing.
+    // Order makes it safe: the launches of a chunk run one after the other on one stream, level j trails level 0 by j rows, so
+    // what level kk - 1 (kk - 2) overwrites at chunk t -- rows below (t + 1) R - kk (+ 1) -- level 0 (1) has read at chunks <= t
+    // and never reads again: kk >= 2, and kk >= 3 where level kk - 2 writes the array level 0 reads (`full`).
+    const PassDesc &pd0 = ps[0];
+    const char *e_inplace = getenv("TVDN_STREAM_INPLACE");
+    const bool inplace = RES > 0 && P == 1 && !want_mse && pd0.kk >= 2 && !(e_inplace && atoi(e_inplace) == 0);
+    const bool full = inplace && RES == N0 && pd0.kk >= 3;
+    inplace_kind = std::max(inplace_kind, full ? 2 : (inplace ? 1 : 0));
+    const int64_t kAsArray = (1LL << 31) - 1;  // a ring size no row index reaches: slot = row
+    auto all_kept = [&](int64_t g0, int64_t g1) {  // every cube row of [g0, g1), clipped to the cube, is kept (and there is one)
+        g0 = std::max<int64_t>(g0, 0);
+        g1 = std::min<int64_t>(g1, N0);
+        return g0 < g1 && rm.host_below(g1) == rm.host_below(g0);
+    };
+    // array `i_store` of the store as an array indexed by cube row, valid over the run of kept rows around g (their slots are consecutive)
+    auto kept_base = [&](int i_store, int64_t g) { return store_row(i_store, g) - (size_t)g * row_bytes; };
+    auto is_d_mode = [](int m) { return m == TVDN_ITER_FISTA_D || m == TVDN_ITER_FISTA_D_TO_PLAIN; };
+    // which kept rows still go through the level-0 rings: those a level-0 launch reads that also reads a streamed row
+    std::vector<char> ring_in((size_t)(inplace ? N0 : 0), 0), ring_orig_row((size_t)(inplace ? N0 : 0), 0);
+    if (inplace && !full)
+        for (int64_t t = 0; t < n_chunks; ++t) {
+            const int64_t v_lo = std::max<int64_t>(0, t * R - 1), v_hi = std::min<int64_t>(N0, (t + 1) * R - 1);
+            if (v_lo < v_hi && !all_kept(v_lo - 1, v_hi + 1))
+                for (int64_t g = std::max<int64_t>(v_lo - 1, 0); g < std::min<int64_t>(v_hi + 1, N0); ++g) ring_in[(size_t)g] = 1;
+        }
+    if (inplace && !full)  // (a launch of any level holds R consecutive rows: a kept row within R - 1 rows of a streamed one may share one with it)
+        for (int64_t g = 0; g < N0; ++g) ring_orig_row[(size_t)g] = all_kept(g - (R - 1), g + R) ? 0 : 1;
     std::vector<hipEvent_t> down_done((size_t)n_chunks, nullptr);
     const int bx_recon = 1, bx_ref = 2 + nd * n_state;  // fixed box numbers: 0 data term, 1 recon, 2 + q n_state + s state
     auto bx_state = [&](int q, int s) { return 2 + q * n_state + s; };
@@ -186,12 +220,16 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                 };
                 auto boxed = [&](int bx) { return inbox[h][bx] + (size_t)slot * row_bytes; };
                 const char *o_src = res_row ? store_row(0, g) : boxed(0);
-                put(Ow, o_src);
-                if (pd.first || res_row || ship_recon)  // (else: rebuilt from the state, below)
+                // a kept row goes through the rings only where a launch that reads it also reads a streamed row (above)
+                const bool via_rings = !res_row || !inplace || pd.first || ring_in[(size_t)g];
+                if (via_rings || ring_orig_row[(size_t)g]) put(Ow, o_src);
+                if ((pd.first || res_row || ship_recon) && via_rings)  // (else: rebuilt from the state, below)
                     put(Rw[0], pd.first ? o_src : (res_row ? store_row(1, g) : boxed(bx_recon)));
+                const bool level1_reads = !full && pd.kk >= 2 && is_d_mode(pd.modes[1]);  // d_k is level 1's d_k-1: read from its ring
                 for (int qx = 0; qx < nd; ++qx) {
-                    put(A(0, qx), pd.first ? zero_plane : (res_row ? store_row(2 + qx * n_state, g) : boxed(bx_state(qx, 0))));
-                    if (pd.n_in_state == 2)
+                    if (via_rings || level1_reads)
+                        put(A(0, qx), pd.first ? zero_plane : (res_row ? store_row(2 + qx * n_state, g) : boxed(bx_state(qx, 0))));
+                    if (pd.n_in_state == 2 && via_rings)
                         put(A(-1, qx), pd.first ? zero_plane : (res_row ? store_row(2 + qx * n_state + 1, g) : boxed(bx_state(qx, 1))));
                 }
                 if (want_mse) put(Fw, boxed(bx_ref));
@@ -260,8 +298,10 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
             for (int64_t v = u0; v < u1; ++v) {
                 const int q = (int)(v / N0);
                 const int64_t g = v - (int64_t)q * N0;
-                if (exact_wrap && g == 0)
-                    TVDN_HIP(hipMemcpyAsync(((q & 1) ? row0b : row0)[0], Rw[0].row(v), row_bytes, hipMemcpyDeviceToDevice, st.main));
+                if (exact_wrap && g == 0) {
+                    const bool in_ring = !resident(g) || !inplace || ps[(size_t)q].first || ring_in[(size_t)g];
+                    TVDN_HIP(hipMemcpyAsync(((q & 1) ? row0b : row0)[0], in_ring ? Rw[0].row(v) : store_row(1, g), row_bytes, hipMemcpyDeviceToDevice, st.main));
+                }
                 if (want_mse && ps[(size_t)q].it0 == 0 && ps[(size_t)q].first)  // MSE[0]: the input against the reference (cyTVDN.py:124-125)
                     if ((rc2 = sse_row(Rw[0].row(v), Fw.row(v), 0, g))) return rc2;
             }
@@ -298,13 +338,57 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                         it.b_in[qx] = cur; it.b_out[qx] = nxt;
                     }
                 }
+                it.orig = Ow.base;
+                it.orig_ring_rows = ocap;
+                it.recon_in_ring_rows = it.cur_ring_rows = it.prev_ring_rows = it.recon_out_ring_rows = it.out_ring_rows = 0;
+                bool out_kept = false;
+                if (inplace) {  // (P == 1: v == g)
+                    const int64_t g_in = std::max<int64_t>(v_lo - 1, 0);
+                    const bool in_kept = j == 0 && !pd.first && all_kept(v_lo - 1, v_hi + 1);
+                    const bool rows_kept = all_kept(v_lo, v_hi);
+                    out_kept = j == pd.kk - 1 && rows_kept;
+                    const bool shared_kept = full && pd.n_out_state == 2;  // d_k+kk-1 goes to the store from level kk - 2, and level kk - 1 reads it there
+                    if (in_kept) {
+                        it.recon_in = kept_base(1, g_in);
+                        it.recon_in_ring_rows = it.cur_ring_rows = it.prev_ring_rows = kAsArray;
+                    }
+                    if (out_kept) {
+                        it.recon_out = kept_base(1, v_lo);
+                        it.recon_out_ring_rows = it.out_ring_rows = kAsArray;
+                    } else if (j == pd.kk - 2 && shared_kept) {
+                        it.out_ring_rows = kAsArray;
+                    }
+                    if (j == 1 && full && !pd.first && is_d_mode(mode)) it.prev_ring_rows = kAsArray;
+                    if (j == pd.kk - 1 && shared_kept) it.cur_ring_rows = kAsArray;
+                    for (int qx = 0; qx < nd; ++qx) {
+                        char *cur = nullptr, *prv = nullptr, *nxt = nullptr;
+                        if (in_kept) {
+                            cur = kept_base(2 + qx * n_state, g_in);
+                            if (pd.n_in_state == 2) prv = kept_base(2 + qx * n_state + 1, g_in);
+                        }
+                        if (j == 1 && full && !pd.first && is_d_mode(mode)) prv = kept_base(2 + qx * n_state, g_in);
+                        if (j == pd.kk - 1 && shared_kept) cur = kept_base(2 + qx * n_state + 1, g_in);
+                        if (out_kept)
+                            nxt = kept_base(2 + qx * n_state, v_lo);
+                        else if (j == pd.kk - 2 && shared_kept)
+                            nxt = kept_base(2 + qx * n_state + 1, v_lo);
+                        if (cur) (is_d_mode(mode) ? it.d_in[qx] : it.b_in[qx]) = cur;
+                        if (prv && is_d_mode(mode)) it.dprev_in[qx] = prv;
+                        if (nxt) (mode == TVDN_ITER_FISTA_D ? it.d_out[qx] : it.b_out[qx]) = nxt;
+                    }
+                    if (rows_kept && !pd.first) {
+                        it.orig = kept_base(0, v_lo);
+                        it.orig_ring_rows = kAsArray;
+                    }
+                }
                 int r3 = tvdn_iterate_fused(ctx.c, &it, (double *)sums_d.p + 3 * (size_t)(pd.it0 + (int)j), st.main);
                 if (r3) return r3;
                 if (want_mse)
                     for (int64_t v = v_lo; v < v_hi; ++v)
                         if ((r3 = sse_row(Fw.row(v), Rw[(size_t)j + 1].row(v), pd.it0 + (int)j + 1, v - (int64_t)q * N0))) return r3;
                 if (exact_wrap && v_lo == (int64_t)q * N0)
-                    TVDN_HIP(hipMemcpyAsync(((q & 1) ? row0b : row0)[(size_t)j + 1], Rw[(size_t)j + 1].row(v_lo), row_bytes, hipMemcpyDeviceToDevice, st.main));
+                    TVDN_HIP(hipMemcpyAsync(((q & 1) ? row0b : row0)[(size_t)j + 1], out_kept ? store_row(1, 0) : Rw[(size_t)j + 1].row(v_lo), row_bytes, hipMemcpyDeviceToDevice,
+                                            st.main));
                 return TVDN_OK;
             });
             if (rc2) return rc2;
@@ -333,6 +417,8 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
             }
             const bool direct = pd.last && recon_direct;
             outs.push_back(Out{q, lo - (int64_t)q * N0, hi - (int64_t)q * N0, oslot});
+            // (in place: these rows are the last level's launch of this chunk -- what it wrote into the store stays there)
+            const bool out_kept = inplace && all_kept(lo, hi), shared_kept = full && pd.n_out_state == 2;
             for (int64_t v = lo; v < hi; ++v) {
                 const int64_t g = v - (int64_t)q * N0;
                 const bool res_row = resident(g);
@@ -342,14 +428,14 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                 };
                 if (res_row && direct) {  // the result only, into the out box like a host row's
                     cdst.push_back(outbox[h][0] + (size_t)oslot * row_bytes);
-                    csrc.push_back(Rw[(size_t)pd.kk].row(v));
+                    csrc.push_back(out_kept ? (void *)store_row(1, g) : Rw[(size_t)pd.kk].row(v));
                     ++oslot;
                     continue;
                 }
-                if (res_row || recon_down) put(1, 0, Rw[(size_t)pd.kk]);
+                if ((res_row || recon_down) && !out_kept) put(1, 0, Rw[(size_t)pd.kk]);
                 for (int qx = 0; qx < nd; ++qx) {
-                    put(2 + qx * n_state, ox_state(qx, 0), A(pd.kk, qx));
-                    if (pd.n_out_state == 2) put(2 + qx * n_state + 1, ox_state(qx, 1), A(pd.kk - 1, qx));
+                    if (!out_kept) put(2 + qx * n_state, ox_state(qx, 0), A(pd.kk, qx));
+                    if (pd.n_out_state == 2 && !shared_kept) put(2 + qx * n_state + 1, ox_state(qx, 1), A(pd.kk - 1, qx));
                 }
                 if (!res_row) ++oslot;
             }

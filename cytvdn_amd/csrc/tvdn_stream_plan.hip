@@ -100,7 +100,12 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
             //     where (2, 12, 56 kept) ran at 57.8.
             const int n_store = 2 + nd * n_state;  // arrays a kept row holds in HBM: data term, recon, state
             const int64_t res = may_keep && r > 1 ? std::min<int64_t>(n_rows, (budget - planes) / n_store) : 0;
-            if (res > 0) {
+            if (res >= n_rows && k >= 3) {
+                // every row kept: swept in place (tvdn_stream_chain.hip), no copy after the first pass -- 0.81 ms per 256 MiB plane and
+                // level at k = 6 and at k = 8 (64 rows, 80 iterations: 4.16 s where the copying schedule took 5.2); a millisecond
+                // per pass for its drain, so that the deepest such k wins
+                offer(res, (double)n_rows * moved * rb / (5.6e12 * 0.88) + 1e-3 * (passes > 0 ? (double)passes / (double)n_iters : 1.0 / (double)k));
+            } else if (res > 0) {
                 const double link = (double)(n_rows - res) * (n_in + n_out) * rb;
                 // (a pass that streams anything also waits for a fifth of one row's way up and down: 63 of 64 rows kept at k = 9
                 //  ran 5.53 s where all 64 at k = 8 ran 5.22)

@@ -103,6 +103,7 @@ struct StreamRun {
     std::vector<void *> cdst, csrc;
     int down_blocks = 0;
     bool recon_direct = false, recon_direct_decided = false;  // the last pass sends the resident rows' results home itself
+    int inplace_kind = 0;  // kept rows swept in place (tvdn_stream_chain.hip): 0 no, 1 where their neighbours are kept too, 2 every one (all rows kept)
     std::vector<double> ratios;
     int ran = 0, ran_phase[2] = {0, 0};
     std::chrono::steady_clock::time_point t_passes, t_end_passes;

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TVDN_ABI_VERSION 7
+#define TVDN_ABI_VERSION 8
 
 typedef enum tvdn_dtype { TVDN_F32 = 0, TVDN_F64 = 1 } tvdn_dtype;
 
@@ -190,6 +190,15 @@ typedef struct tvdn_iter_args {
      * block loop it replaces upstream: cyTVDN/cyTVDN.py:148-242 on a cube that does not fit). */
     int64_t ring_rows;
     int64_t orig_ring_rows;
+    /* ABI 8.  Ring sizes of their own, 0 = ring_rows: recon_in; b_in and d_in (the state of this level); dprev_in (the state of
+     * the level before); recon_out; b_out and d_out.  A "ring" longer than the cube is an array: the first levels of a streamed
+     * pass read rows that are kept in HBM between passes where they are kept, and the last ones write them there, instead of
+     * copying them into and out of the levels' rings (csrc/tvdn_stream_chain.hip). */
+    int64_t recon_in_ring_rows;
+    int64_t cur_ring_rows;
+    int64_t prev_ring_rows;
+    int64_t recon_out_ring_rows;
+    int64_t out_ring_rows;
 } tvdn_iter_args;
 
 int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *args, double *sums_out, void *stream);
@@ -276,7 +285,10 @@ typedef struct tvdn_run_stats {
                               (result array page-locked in place, no stopping rule) instead of in one piece after it   */
     int32_t state_mem;     /* ABI 7.  TVDN_MEM_*: what the run's big device block (the state, or the rings and kept rows
                               of a streamed run) is made of; TVDN_MEM_CALLER for a caller's workspace                  */
-    int32_t reserved;
+    int32_t kept_in_place; /* ABI 8.  streamed with resident rows: 0 = they entered and left the levels' rings by device copies;
+                              1 = swept in place (level 0 reads them where they are kept, the last level writes them there)
+                              wherever the rows next to them are kept too; 2 = all rows kept, every pass but the first
+                              without a copy                                                                          */
 } tvdn_run_stats;
 
 /* ABI 6.  One slab of a cube that several PROCESSES denoise together, each streaming ITS slab through its GPU from its own

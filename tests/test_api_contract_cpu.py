@@ -30,12 +30,14 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/tvdn.h but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert _lib.lib().tvdn_abi_version() == 7
+    assert _lib.lib().tvdn_abi_version() == 8
 
 
 def test_iter_args_struct_matches_header_layout():
     # 2 int32 + 4 int64 + 2 int64 + 4 int32 + 2 double + 8 doubles + 3 ptr + 20 ptr + 2 int64 + 2 int32 + 1 ptr (ABI v2) + 2 int64 (ABI v3: row rings)
-    assert ctypes.sizeof(_lib.IterArgs) == 8 + 32 + 16 + 16 + 16 + 64 + 24 + 160 + 16 + 8 + 8 + 16
+    # + 5 int64 (ABI 8: ring sizes of their own for recon_in, the state of this level, of the level before, recon_out, the outputs)
+    assert ctypes.sizeof(_lib.IterArgs) == 8 + 32 + 16 + 16 + 16 + 64 + 24 + 160 + 16 + 8 + 8 + 16 + 40
+    assert _lib.IterArgs.recon_in_ring_rows.offset == _lib.IterArgs.ring_rows.offset + 16 and _lib.IterArgs.out_ring_rows.offset == _lib.IterArgs.ring_rows.offset + 48
     assert _lib.IterArgs.shape.offset == 8 and _lib.IterArgs.tk.offset == 72 and _lib.IterArgs.orig.offset == 152
     assert _lib.IterArgs.dprev_in.offset == 304 and _lib.IterArgs.sweep_lo.offset == 336
 
