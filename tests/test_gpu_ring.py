@@ -124,6 +124,101 @@ def test_ring_sweeps_equal_the_resident_sweep(shape, dtype, bc, R, mode):
         np.testing.assert_allclose(sums_ring.cpu().numpy(), sums_full.cpu().numpy(), rtol=1e-12)
 
 
+@pytest.mark.parametrize("shape,dtype,R", [((23, 4, 6, 16), np.float32, 4), ((17, 5, 8), np.float64, 3), ((19, 3, 5, 7), np.float32, 2)])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("which", ["inputs as arrays", "outputs as arrays", "previous level and recon_out as arrays"])
+def test_ring_sizes_per_array_class(shape, dtype, R, mode, which):
+    """ABI 8: recon_in, the state of this level (b_in / d_in), of the level before (dprev_in), recon_out and the outputs (b_out /
+    d_out) each take a ring size of their own (0 = ring_rows); a ring longer than the cube is an array.  What the streamed engine
+    sweeps rows in place with: some classes are whole arrays, the others rings of R + 2 rows, the bits those of the resident sweep."""
+    import torch
+    from cytvdn_amd import _lib
+    L, ctx = _lib.lib(), _lib.ctx(0)
+    nd, N0 = len(shape), shape[0]
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    rng = np.random.default_rng(11 + mode)
+
+    def rand(scale=1.0):
+        return torch.from_numpy((rng.standard_normal(shape) * scale).astype(dtype)).cuda()
+
+    def zeros():
+        return torch.zeros(shape, dtype=tdt, device="cuda")
+
+    full = {"orig": rand(4), "r_in": rand(4), "r_out": zeros(), "s1": [rand(0.4) for _ in range(nd)], "s2": [rand(0.4) for _ in range(nd)],
+            "o1": [zeros() for _ in range(nd)], "o2": [zeros() for _ in range(nd)]}
+    for k in ("s1", "s2"):
+        full[k][0][0].zero_()
+
+    def args():
+        a = _lib.IterArgs(dtype=_lib.dtype_code(np.dtype(dtype)), ndim=nd, row_lo=0, row_hi=N0, lo_mode=_lib.EDGE_BC,
+                          hi_mode=_lib.EDGE_ZERO, bc_mode=2, mode=mode, tk=0.37, tk_prev=0.21, accumulate=1)
+        for i, s_ in enumerate(shape):
+            a.shape[i] = s_
+        for q in range(nd):
+            a.clip[q], a.lambda_mu[q] = 0.5 + 0.1 * q, 0.3 - 0.05 * q
+        return a
+
+    a = args()
+    a.hi_mode = _lib.EDGE_BC
+    _fill(a, full, mode, _lib, lambda t: t.data_ptr())
+    _lib.check(L.tvdn_iterate_fused(ctx, C.byref(a), torch.zeros(3, dtype=torch.float64, device="cuda").data_ptr(), _lib.current_stream(0)))
+    torch.cuda.synchronize()
+
+    cap = R + 2
+    AS_ARRAY = 2 ** 31 - 1
+    d_modes = mode in (_lib.ITER_FISTA_D, _lib.ITER_FISTA_D_TO_PLAIN)
+    # which tensors of _fill's dictionary belong to which class: s1 is dprev_in in the d modes (the level before), else b_in (this level)
+    prev_keys = ["s1"] if d_modes else []
+    cur_keys = ["s2"] + ([] if d_modes else ["s1"])
+    as_array = {"inputs as arrays": {"r_in", "s1", "s2", "orig"}, "outputs as arrays": {"r_out", "o1", "o2"},
+                "previous level and recon_out as arrays": set(prev_keys) | {"r_out"}}[which]
+
+    def ring():
+        return torch.full((cap,) + shape[1:], float("nan"), dtype=tdt, device="cuda")
+
+    work = {}
+    for k in ("orig", "r_in", "r_out"):
+        work[k] = (full[k].clone() if k != "r_out" else zeros()) if k in as_array else ring()
+    for k in ("s1", "s2", "o1", "o2"):
+        work[k] = [((full[k][q].clone() if k in ("s1", "s2") else zeros()) if k in as_array else ring()) for q in range(nd)]
+    got = {"r_out": zeros(), "o1": [zeros() for _ in range(nd)], "o2": [zeros() for _ in range(nd)]}
+    sums = torch.zeros(3, dtype=torch.float64, device="cuda")
+    for c0 in range(0, N0, R):
+        c1 = min(c0 + R, N0)
+        for g in range(max(0, c0 - 1), min(N0, c1 + 1)):
+            if "r_in" not in as_array:
+                work["r_in"][g % cap].copy_(full["r_in"][g])
+            for k in ("s1", "s2"):
+                if k not in as_array:
+                    for q in range(nd):
+                        work[k][q][g % cap].copy_(full[k][q][g])
+        if "orig" not in as_array:
+            for g in range(c0, c1):
+                work["orig"][g % cap].copy_(full["orig"][g])
+        a = args()
+        a.sweep_lo, a.sweep_hi = c0, c1
+        a.ring_rows, a.orig_ring_rows = cap, (AS_ARRAY if "orig" in as_array else cap)
+        a.recon_in_ring_rows = AS_ARRAY if "r_in" in as_array else 0
+        a.cur_ring_rows = AS_ARRAY if all(k in as_array for k in cur_keys) else 0
+        a.prev_ring_rows = AS_ARRAY if prev_keys and all(k in as_array for k in prev_keys) else 0
+        a.recon_out_ring_rows = AS_ARRAY if "r_out" in as_array else 0
+        a.out_ring_rows = AS_ARRAY if "o1" in as_array else 0
+        _fill(a, work, mode, _lib, lambda t: t.data_ptr())
+        _lib.check(L.tvdn_iterate_fused(ctx, C.byref(a), sums.data_ptr(), _lib.current_stream(0)))
+        for g in range(c0, c1):
+            got["r_out"][g].copy_(work["r_out"][g] if "r_out" in as_array else work["r_out"][g % cap])
+            for k in ("o1", "o2"):
+                for q in range(nd):
+                    got[k][q][g].copy_(work[k][q][g] if k in as_array else work[k][q][g % cap])
+    torch.cuda.synchronize()
+    assert torch.equal(got["r_out"].view(torch.uint8), full["r_out"].view(torch.uint8))
+    for q in range(nd):
+        if mode in (_lib.ITER_PLAIN, _lib.ITER_FISTA, _lib.ITER_FISTA_D_TO_PLAIN):
+            assert torch.equal(got["o1"][q].view(torch.uint8), full["o1"][q].view(torch.uint8)), ("out1", q)
+        if mode in (_lib.ITER_FISTA, _lib.ITER_FISTA_D):
+            assert torch.equal(got["o2"][q].view(torch.uint8), full["o2"][q].view(torch.uint8)), ("out2", q)
+
+
 def test_ring_argument_checks():
     import torch
     from cytvdn_amd import _lib
