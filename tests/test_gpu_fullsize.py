@@ -305,3 +305,54 @@ def test_streamed_run_at_a_size_that_page_locks_in_place(monkeypatch, bc):
     assert hashlib.sha1(streamed[0].tobytes()).hexdigest() == hashlib.sha1(resident[0].tobytes()).hexdigest()
     np.testing.assert_allclose(streamed[1].astype(np.float64), resident[1].astype(np.float64), rtol=1e-6)
     np.testing.assert_allclose(streamed[2].astype(np.float64), resident[2].astype(np.float64), rtol=1e-6)
+
+
+def test_streamed_engine_at_config5_plane_size_against_the_oracle(oracle):
+    """The streamed engine at BASELINE config 5's plane size (1024 x 256 x 256 f32, 256 MiB per row; 16 rows = 4 GiB per array: 40 GiB page-locked, inside the 64 GiB the tests may pin)
+    DIRECTLY against the oracle: nine FISTA iterations as three passes of three levels, two-row chunks -- (a) every row kept in HBM
+    and swept in place, (b) 13 of 16 kept (in place between the streamed rows), (c) every row streamed, the three passes chained,
+    recon rebuilt on the device instead of crossing PCIe.  The three results are the same bits, and windows of them at both faces,
+    in the middle and across a chunk seam equal the oracle on the enlarged windows of the input."""
+    import torch
+    from cytvdn_amd import _lib, planner, synth
+    from test_gpu_run_streamed import _run
+    shape = (16, 1024, 256, 256)
+    its, rows, k = 9, 2, 3
+    avail = planner.host_available()
+    if avail is None or avail < 60 * 2 ** 30:
+        pytest.skip("the host offers less than 60 GiB (40 GiB page-locked + the cube and two results)")
+    dt = np.dtype(np.float32)
+    mu = np.array([1.0, 1.0, 0.5, 0.5], dt)
+    buf = torch.empty(shape, dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().tvdn_synth_fill(0, 4, _lib.shape_arr(shape), synth.SEED_4D, 0, shape[0], buf.data_ptr(),
+                                          _lib.current_stream(0)))
+    x = buf.cpu().numpy()
+    del buf
+    torch.cuda.empty_cache()
+    results = []
+    for resident, kind, passes in ((16, 2, 3), (13, 1, 3), (0, 0, 3)):
+        st = _lib.RunStats()
+        recon, sums, _, ran = _run(x, mu, its, 0, stream=(rows, k), resident=resident, stats=st)
+        assert ran == its and st.engine == 1 and (st.stream_rows, st.stream_k, st.n_passes) == (rows, k, passes)
+        assert st.resident_rows == resident and st.kept_in_place == kind
+        if resident == 0:       # recon stays on the device between the passes: data term up 3 x, state 2 x each way, recon down once
+            assert st.h2d_bytes == x.nbytes * (3 + 2 * 8) and st.d2h_bytes == x.nbytes * (1 + 3 * 8)
+        results.append((hashlib.sha1(recon.tobytes()).hexdigest(), sums.copy()))
+        if resident == 16:
+            kept = recon
+        del recon
+    assert results[0][0] == results[1][0] == results[2][0]
+    np.testing.assert_allclose(results[1][1], results[0][1], rtol=1e-12)
+    np.testing.assert_allclose(results[2][1], results[0][1], rtol=1e-12)
+    recon = kept
+    halo = 2 * its
+    A, B, Cc = shape[1:]
+    for start, ext in (((0, 0, 0, 0), (3, 6, 8, 16)), ((13, A - 6, B - 9, Cc - 16), (3, 6, 9, 16)), ((7, 500, 100, 64), (3, 5, 6, 12)),
+                       ((5, A - 7, 0, Cc - 12), (2, 7, 8, 12))):
+        lo = [max(0, s - halo) for s in start]
+        hi = [min(n, s + e + halo) for s, e, n in zip(start, ext, shape)]
+        ref = oracle.denoise(np.ascontiguousarray(x[tuple(slice(a, b) for a, b in zip(lo, hi))]), mu, its, True)["recon"]
+        inner = tuple(slice(s - a, s - a + e) for s, a, e in zip(start, lo, ext))
+        assert bits_equal(recon[tuple(slice(s, s + e) for s, e in zip(start, ext))], ref[inner]), start
+    # the sums of a cube this size are finite and positive
+    assert np.all(np.isfinite(results[0][1])) and np.all(results[0][1][:, 2] > 0)
