@@ -609,6 +609,27 @@ def main():
                 overlap = False                  # keep measuring, visibly, with the blocking exchange
             if not preflight["blocking"] and rank == 0:
                 print(f"[bench] exchange self-check FAILED on {transport}: {preflight}", file=sys.stderr, flush=True)
+            # The slabs of the measurement live on granules of HIP virtual memory (csrc/tvdn_devmem.hip), which no transport has been
+            # handed on hardware before the first node: the same check with its small states on granules.  Wrong bits or an error
+            # there, with the plain check green, puts the measurement on plain hipMalloc memory (TVDN_VMM=0) and says so in the line.
+            if preflight["blocking"] and os.environ.get("TVDN_VMM", "1") != "0":
+                prev_min = os.environ.get("TVDN_VMM_MIN_MIB")
+                os.environ["TVDN_VMM_MIN_MIB"] = "0"
+                try:
+                    pg = selfcheck_exchange(group=group, device=local_rank)
+                finally:
+                    if prev_min is None:
+                        os.environ.pop("TVDN_VMM_MIN_MIB", None)
+                    else:
+                        os.environ["TVDN_VMM_MIN_MIB"] = prev_min
+                preflight["on_granules"] = {k: pg[k] for k in ("overlap", "blocking", "error")}
+                if not pg["blocking"]:
+                    os.environ["TVDN_VMM"] = "0"
+                    preflight["state_mem_fallback"] = "plain: the exchange self-check failed with the states on granules"
+                    if rank == 0:
+                        print(f"[bench] exchange self-check on granules FAILED on {transport}: {pg}; measuring on plain memory", file=sys.stderr, flush=True)
+                elif not pg["overlap"]:
+                    overlap = False
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)

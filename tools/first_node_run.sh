@@ -13,7 +13,8 @@
 # Since round 5 a state of 2 GiB or more lives on 1 GiB granules of HIP virtual memory (csrc/tvdn_devmem.hip) -- memory RCCL has
 # never been handed on hardware either.  The 2-GPU bench therefore runs twice, the second time with TVDN_VMM=0 (plain hipMalloc):
 # if only the first fails, the granules are the cause and TVDN_VMM=0 is the way round it; if both run, the pair is the first
-# measurement of placement under an exchange.
+# measurement of placement under an exchange.  (bench.py also repeats its pre-flight with the small states on granules and falls
+# back to plain memory by itself when that one gives wrong bits or an error: preflight.on_granules / state_mem_fallback in its line.)
 # Usage (on the node, from the repo root):   bash tools/first_node_run.sh [OUTDIR]
 # Rehearsal on a one-GPU box (several ranks share the GPU, halo rows staged through host memory over gloo; at most 6 processes
 # may use a GPU at once on the pool's boxes, launcher included: 4 ranks is the most that rehearses safely):   TVDN_DIST_BACKEND=gloo REHEARSE_RANKS="2 4" REHEARSE_SHAPE=1 bash tools/first_node_run.sh
