@@ -104,7 +104,10 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
                 // every row kept: swept in place (tvdn_stream_chain.hip), no copy after the first pass -- 0.81 ms per 256 MiB plane and
                 // level at k = 6 and at k = 8 (64 rows, 80 iterations: 4.16 s where the copying schedule took 5.2); a millisecond
                 // per pass for its drain, so that the deepest such k wins
-                offer(res, (double)n_rows * moved * rb / (5.6e12 * 0.88) + 1e-3 * (passes > 0 ? (double)passes / (double)n_iters : 1.0 / (double)k));
+                // (by chunk height, K = 3 and 8: one-row launches 0.89 ms, two-row 0.81-0.83, four-row 0.80: the rows a launch reads
+                //  beside its own weigh less in a taller one)
+                const double eff_kept = r >= 4 ? 0.90 : (r == 2 ? 0.88 : 0.80);
+                offer(res, (double)n_rows * moved * rb / (5.6e12 * eff_kept) + 1e-3 * (passes > 0 ? (double)passes / (double)n_iters : 1.0 / (double)k));
             } else if (res > 0) {
                 const double link = (double)(n_rows - res) * (n_in + n_out) * rb;
                 // (a pass that streams anything also waits for a fifth of one row's way up and down: 63 of 64 rows kept at k = 9
