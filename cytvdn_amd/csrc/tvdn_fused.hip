@@ -701,8 +701,10 @@ extern "C" int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *a, double
         const long long need = (s1 - s0) + ((s0 > a->row_lo || a->lo_mode == TVDN_EDGE_HALO) ? 1 : 0) +
                                ((s1 < a->row_hi || a->hi_mode == TVDN_EDGE_HALO) ? 1 : 0);
         TVDN_REQUIRE(a->shape[0] < (1LL << 31) && a->ring_rows < (1LL << 31) && a->orig_ring_rows < (1LL << 31), "row rings index rows with 32 bits");
-        for (int64_t r : own_rings)
-            TVDN_REQUIRE(r < (1LL << 31) && (r == 0 || r >= need), "ring of %lld rows cannot hold the %lld rows this sweep touches", (long long)r, need);
+        for (int i = 0; i < 5; ++i) {  // (what is READ may be a ring of ONE row: every row is that plane -- a constant, e.g. the zeros a run starts from)
+            const int64_t r = own_rings[i];
+            TVDN_REQUIRE(r < (1LL << 31) && (r == 0 || r >= need || (r == 1 && i < 3)), "ring of %lld rows cannot hold the %lld rows this sweep touches", (long long)r, need);
+        }
         TVDN_REQUIRE(a->ring_rows >= need, "ring of %lld rows cannot hold the %lld rows this sweep reads",
                      (long long)a->ring_rows, need);
         TVDN_REQUIRE(a->orig_ring_rows == 0 || a->orig_ring_rows >= s1 - s0, "orig ring shorter than the sweep");

@@ -173,15 +173,37 @@ int StreamRun::set_up(bool &nothing_to_do)
     free_b += state_kept_bytes(device);  // the block the last run kept is this run's to take over or to release
     if (const size_t cap_b = env_bytes("TVDN_HBM_LIMIT"))  // what the planner of the Python side counts on (tests: "48G")
         free_b = std::min(free_b, cap_b);
-    if (dev_bytes_max > free_b) {
-        set_error("streamed run with %lld-row chunks and k = %lld needs %zu bytes of HBM, device %d has %zu free", (long long)R,
-                  (long long)K, dev_bytes_max, device, free_b);
-        return TVDN_ERR_UNSUPPORTED;
-    }
     // RES of the N0 rows keep their state (data term, recon, accumulators: n_store arrays) in HBM between passes: they enter
     // the rings and leave them by device copies instead of crossing PCIe.  Jia-Zhao runs without an MSE trace (the periodic
     // schedule walks a wrapped virtual cube whose ends are both streamed; the reference cube of an MSE trace stays on the host).
     rm.n0 = N0;
+    // Every row kept and every pass at least three levels deep: the lean layout (tvdn_stream_plan.hip stream_planes_all_kept) --
+    // rings for the levels between the first and the last only, no boxes, no data-term ring; the rows are swept in place
+    // (tvdn_stream_chain.hip).  Asked for by stream_resident < 0 (as many as fit) or >= the cube's rows.
+    lean_layout = false;
+    {
+        const char *e_inplace = getenv("TVDN_STREAM_INPLACE"), *e_res = getenv("TVDN_STREAM_RESIDENT"), *e_lean = getenv("TVDN_STREAM_LEAN");
+        int min_depth = K > 0 ? (int)K : 0;
+        for (int q = 0; q < n_pass_plan; ++q) min_depth = std::min(min_depth, depth_of_pass(q));
+        const bool wanted = !sh && !periodic && !want_mse && !a->use_stop && min_depth >= 3 && (res_req < 0 || res_req >= N0) && !e_res &&
+                            !(e_inplace && atoi(e_inplace) == 0) && !(e_lean && atoi(e_lean) == 0);
+        if (wanted) {
+            const size_t lean_b = stream_device_bytes_all_kept(nd, R, K, row_bytes);
+            const size_t need_b = lean_b + (size_t)N0 * (size_t)n_store * plane_b;
+            if (need_b <= (size_t)((res_req < 0 ? 0.85 : 0.92) * (double)free_b)) {
+                lean_layout = true;
+                dev_bytes_max = lean_b;
+                rm.res = N0;
+            }
+        }
+    }
+    if (lean_layout) {
+        // (nothing else to decide)
+    } else if (dev_bytes_max > free_b) {
+        set_error("streamed run with %lld-row chunks and k = %lld needs %zu bytes of HBM, device %d has %zu free", (long long)R,
+                  (long long)K, dev_bytes_max, device, free_b);
+        return TVDN_ERR_UNSUPPORTED;
+    }
     if (sh) {  // a slab keeps none of the rows its neighbours read
         rm.slab_window(sh->g0, sh->g1, art_lo, art_hi, K);
     }
@@ -194,6 +216,8 @@ int StreamRun::set_up(bool &nothing_to_do)
             return TVDN_ERR_UNSUPPORTED;
         }
         rm.res = res_req;
+    } else if (lean_layout) {
+        // (all of them: decided above)
     } else if (!periodic && !want_mse && res_req != 0) {
         auto fits = [&](double share) -> int64_t {
             const size_t lim = (size_t)(share * (double)free_b);
@@ -336,13 +360,23 @@ int StreamRun::set_up(bool &nothing_to_do)
     cursor = (char *)mem.p;
     Rw.assign((size_t)K + 1, Ring{});
     Aw.assign((size_t)(K + 2) * nd, Ring{});  // [level + 1][axis]
-    for (Ring &r : Rw) r = Ring{take(ring_b), cap, row_bytes};
-    for (Ring &r : Aw) r = Ring{take(ring_b), cap, row_bytes};
-    Ow = Ring{take(oring_b), ocap, row_bytes};
-    if (want_mse) Fw = Ring{take(oring_b), ocap, row_bytes};
-    for (int h = 0; h < 2; ++h) {
-        for (int i = 0; i < n_in; ++i) inbox[h][i] = take(box_b);
-        for (int i = 0; i < n_out; ++i) outbox[h][i] = take(obox_b);
+    if (!lean_layout) {
+        for (Ring &r : Rw) r = Ring{take(ring_b), cap, row_bytes};
+        for (Ring &r : Aw) r = Ring{take(ring_b), cap, row_bytes};
+        Ow = Ring{take(oring_b), ocap, row_bytes};
+        if (want_mse) Fw = Ring{take(oring_b), ocap, row_bytes};
+        for (int h = 0; h < 2; ++h) {
+            for (int i = 0; i < n_in; ++i) inbox[h][i] = take(box_b);
+            for (int i = 0; i < n_out; ++i) outbox[h][i] = take(obox_b);
+        }
+    } else {  // rings of the levels 1 .. K-1 only; the others are never touched (a null base would show at once)
+        for (Ring &r : Rw) r = Ring{nullptr, cap, row_bytes};
+        for (Ring &r : Aw) r = Ring{nullptr, cap, row_bytes};
+        Ow = Ring{nullptr, ocap, row_bytes};
+        for (int64_t j = 1; j <= K - 1; ++j) {
+            Rw[(size_t)j].base = take(ring_b);
+            for (int q = 0; q < nd; ++q) A(j, q).base = take(ring_b);
+        }
     }
     zero_plane = take(plane_b);  // the accumulator state a run starts from (cyTVDN.py:131-145): the first pass uploads none
     row0b_base = nullptr;
@@ -454,6 +488,7 @@ int StreamRun::schedule()
     // Default: chain from 3 passes on when no row is resident; TVDN_STREAM_CHAIN=1 / 0 forces it on (where possible) / off.
     bool want_chain = RES == 0 && n_pass_plan >= 3 && !sh;
     if (const char *e = getenv("TVDN_STREAM_CHAIN")) want_chain = atoi(e) != 0;
+    if (lean_layout) want_chain = false;  // (one pass at a time: what "in place" is safe for)
     const bool can_chain = want_chain && !periodic && !a->use_stop && n_pass_plan > 1 && K <= N0 - 3 * R;
     down_blocks = can_chain ? 8 : 0;
     if (const char *e = getenv("TVDN_STREAM_DOWN_BLOCKS")) down_blocks = std::max(0, atoi(e));

@@ -78,7 +78,12 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
     const char *e_inplace = getenv("TVDN_STREAM_INPLACE");
     const bool inplace = RES > 0 && P == 1 && !want_mse && pd0.kk >= 2 && !(e_inplace && atoi(e_inplace) == 0);
     const bool full = inplace && RES == N0 && pd0.kk >= 3;
-    inplace_kind = std::max(inplace_kind, full ? 2 : (inplace ? 1 : 0));
+    // The lean layout (tvdn_stream.hip set_up) has no level-0 rings, no boxes and no data-term ring: also the run's FIRST pass is
+    // in place -- level 0 reads recon from the data term in the store and its state from the plane of zeros (a ring of one row:
+    // every row is that plane), level 1 its d_k-1 from the same plane.
+    const bool lean = lean_layout;
+    TVDN_REQUIRE(!lean || full, "the lean layout of a streamed run needs every pass swept in place (depth %d, %d pass(es) at once)", pd0.kk, P);
+    inplace_kind = std::max(inplace_kind, lean ? 3 : (full ? 2 : (inplace ? 1 : 0)));
     const int64_t kAsArray = (1LL << 31) - 1;  // a ring size no row index reaches: slot = row
     auto all_kept = [&](int64_t g0, int64_t g1) {  // every cube row of [g0, g1), clipped to the cube, is kept (and there is one)
         g0 = std::max<int64_t>(g0, 0);
@@ -221,7 +226,7 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                 auto boxed = [&](int bx) { return inbox[h][bx] + (size_t)slot * row_bytes; };
                 const char *o_src = res_row ? store_row(0, g) : boxed(0);
                 // a kept row goes through the rings only where a launch that reads it also reads a streamed row (above)
-                const bool via_rings = !res_row || !inplace || pd.first || ring_in[(size_t)g];
+                const bool via_rings = !res_row || !inplace || (pd.first && !lean) || ring_in[(size_t)g];
                 if (via_rings || ring_orig_row[(size_t)g]) put(Ow, o_src);
                 if ((pd.first || res_row || ship_recon) && via_rings)  // (else: rebuilt from the state, below)
                     put(Rw[0], pd.first ? o_src : (res_row ? store_row(1, g) : boxed(bx_recon)));
@@ -299,8 +304,9 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                 const int q = (int)(v / N0);
                 const int64_t g = v - (int64_t)q * N0;
                 if (exact_wrap && g == 0) {
-                    const bool in_ring = !resident(g) || !inplace || ps[(size_t)q].first || ring_in[(size_t)g];
-                    TVDN_HIP(hipMemcpyAsync(((q & 1) ? row0b : row0)[0], in_ring ? Rw[0].row(v) : store_row(1, g), row_bytes, hipMemcpyDeviceToDevice, st.main));
+                    const bool in_ring = !resident(g) || !inplace || (ps[(size_t)q].first && !lean) || ring_in[(size_t)g];
+                    const char *kept_recon = ps[(size_t)q].first ? store_row(0, g) : store_row(1, g);  // a run starts from recon = data term
+                    TVDN_HIP(hipMemcpyAsync(((q & 1) ? row0b : row0)[0], in_ring ? Rw[0].row(v) : kept_recon, row_bytes, hipMemcpyDeviceToDevice, st.main));
                 }
                 if (want_mse && ps[(size_t)q].it0 == 0 && ps[(size_t)q].first)  // MSE[0]: the input against the reference (cyTVDN.py:124-125)
                     if ((rc2 = sse_row(Rw[0].row(v), Fw.row(v), 0, g))) return rc2;
@@ -345,12 +351,19 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                 if (inplace) {  // (P == 1: v == g)
                     const int64_t g_in = std::max<int64_t>(v_lo - 1, 0);
                     const bool in_kept = j == 0 && !pd.first && all_kept(v_lo - 1, v_hi + 1);
+                    const bool from_zero = lean && pd.first;  // the first pass of a lean run: recon = data term, state = zeros
                     const bool rows_kept = all_kept(v_lo, v_hi);
                     out_kept = j == pd.kk - 1 && rows_kept;
                     const bool shared_kept = full && pd.n_out_state == 2;  // d_k+kk-1 goes to the store from level kk - 2, and level kk - 1 reads it there
                     if (in_kept) {
                         it.recon_in = kept_base(1, g_in);
                         it.recon_in_ring_rows = it.cur_ring_rows = it.prev_ring_rows = kAsArray;
+                    } else if (from_zero && j == 0) {
+                        it.recon_in = kept_base(0, g_in);
+                        it.recon_in_ring_rows = kAsArray;
+                        it.cur_ring_rows = it.prev_ring_rows = 1;
+                    } else if (from_zero && j == 1 && is_d_mode(mode)) {
+                        it.prev_ring_rows = 1;
                     }
                     if (out_kept) {
                         it.recon_out = kept_base(1, v_lo);
@@ -367,6 +380,8 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                             if (pd.n_in_state == 2) prv = kept_base(2 + qx * n_state + 1, g_in);
                         }
                         if (j == 1 && full && !pd.first && is_d_mode(mode)) prv = kept_base(2 + qx * n_state, g_in);
+                        if (from_zero && j == 0) cur = prv = zero_plane;
+                        if (from_zero && j == 1) prv = zero_plane;
                         if (j == pd.kk - 1 && shared_kept) cur = kept_base(2 + qx * n_state + 1, g_in);
                         if (out_kept)
                             nxt = kept_base(2 + qx * n_state, v_lo);
@@ -376,7 +391,7 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                         if (prv && is_d_mode(mode)) it.dprev_in[qx] = prv;
                         if (nxt) (mode == TVDN_ITER_FISTA_D ? it.d_out[qx] : it.b_out[qx]) = nxt;
                     }
-                    if (rows_kept && !pd.first) {
+                    if (rows_kept && (!pd.first || lean)) {
                         it.orig = kept_base(0, v_lo);
                         it.orig_ring_rows = kAsArray;
                     }
@@ -412,7 +427,7 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
             // caller's result array is page-locked in place, i.e. has a place for every row.
             if (pd.last && RES > 0 && !recon_direct_decided) {
                 if ((rc2 = wait_recon(0))) return rc2;
-                recon_direct = recon_h.cube_rows && getenv("TVDN_STREAM_HOME_AFTER") == nullptr;
+                recon_direct = !lean && recon_h.cube_rows && getenv("TVDN_STREAM_HOME_AFTER") == nullptr;  // (the lean layout has no out box)
                 recon_direct_decided = true;
             }
             const bool direct = pd.last && recon_direct;

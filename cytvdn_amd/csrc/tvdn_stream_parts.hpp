@@ -524,6 +524,8 @@ struct Joiner {
 
 // ---- tvdn_stream_plan.hip: what a shape costs, and what a run may choose -------------------------------------------------------
 int64_t stream_planes(int nd, int64_t rows, int64_t k, bool mse, bool wrap);
+int64_t stream_planes_all_kept(int nd, int64_t rows, int64_t k, bool wrap);
+size_t stream_device_bytes_all_kept(int nd, int64_t R, int64_t K, size_t row_bytes);
 int stream_host_need(const tvdn_run_args *a, int64_t res, int64_t *need_bytes, int64_t *avail_bytes);
 size_t stream_device_bytes(int nd, int n_state, bool want_mse, int64_t R, int64_t K, size_t row_bytes, size_t *per_resident_row);
 int slab_shape(const tvdn_run_args *a, int64_t R, int64_t K, int64_t *kc_out, int64_t *res_out, int64_t *local_rows_out);

@@ -37,6 +37,20 @@ int64_t stream_planes(int nd, int64_t rows, int64_t k, bool mse, bool wrap)
     return ((k + 1) + (k + 2) * nd) * (rows + 2) + (rows + k + 3) * (mse ? 2 : 1) + 2 * (3 + 4 * nd) * rows + 2 * (1 + 2 * nd) + (wrap ? 2 * (k + 1) : 0) + 1;
 }
 
+// With EVERY row kept and swept in place (tvdn_stream_chain.hip) only the levels between the first and the last have rings: level 0
+// reads the store, the last level writes it (and with a d-form state the two levels next to them share d arrays through it), the
+// rows never pass a box and `orig` is read where it is kept.  Rings: recon of levels 1 .. K-1, state of levels 1 .. K-1.
+int64_t stream_planes_all_kept(int nd, int64_t rows, int64_t k, bool wrap)
+{
+    return (k - 1) * (1 + nd) * (rows + 2) + (wrap ? 2 * (k + 1) : 0) + 1;
+}
+
+size_t stream_device_bytes_all_kept(int nd, int64_t R, int64_t K, size_t row_bytes)
+{
+    auto aligned = [](size_t b) { return (b + 255) / 256 * 256; };
+    return (size_t)(K - 1) * (size_t)(1 + nd) * aligned((size_t)(R + 2) * row_bytes) + (2 * (size_t)(K + 1) + 1) * aligned(row_bytes);
+}
+
 // Chunk height R, depth K and the number of rows whose state STAYS in HBM between passes (the resident + streamed hybrid).
 // A pass costs max(PCIe time of the streamed rows, sweep time of all rows + the device copies of the resident rows); the
 // choice minimises that per iteration over every (R, K) whose rings fit 85 % of the free HBM, the rows kept being what the
@@ -67,7 +81,11 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
         const double eff = r == 1 ? 0.77 : 0.82;
         for (int64_t k = 1; k <= k_cap; ++k) {
             const int64_t planes = stream_planes(nd, r, k, mse, wrap);
-            if (planes > budget) break;
+            const int n_store = 2 + nd * n_state;  // arrays a kept row holds in HBM: data term, recon, state
+            const bool fits = planes <= budget;     // the rings and boxes of the general layout
+            const bool lean_fits = may_keep && !mse && k >= 3 && stream_planes_all_kept(nd, r, k, wrap) + (int64_t)n_store * n_rows <= budget;
+            if (!fits && !lean_fits && k >= 3) break;
+            if (!fits && !lean_fits) continue;
             // With the number of iterations known, only the depths a run settles on: ceil(n / k) passes of (almost) equal depth
             // (StreamRun::set_up).  80 iterations asked at k = 13 run as 7 passes of 12 -- and would size the rows kept for
             // rings of 13 levels (53 rows of 256 MiB planes kept where 56 fit).
@@ -88,7 +106,7 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
             auto per_iteration = [&](double t_pass) { return passes > 0 ? t_pass * (double)passes / (double)n_iters : t_pass / (double)k; };
             // (a) nothing kept: the pipeline of a pass fills and drains over K rows; chained passes share that between them
             //     (half of it counted)
-            offer(0, per_iteration(std::max(((double)n_rows + 0.5 * (double)std::min<int64_t>(k, n_rows)) * row_step, t_sweeps)));
+            if (fits) offer(0, per_iteration(std::max(((double)n_rows + 0.5 * (double)std::min<int64_t>(k, n_rows)) * row_step, t_sweeps)));
             // (b) what the rest of the budget holds kept.  The passes are drained, so the link works both ways at once: 68 GB/s
             //     together when a pass waits for it.  When it does not, a row-plane takes 0.89 ms per level (the 0.82 x 5.6 TB/s
             //     above), a kept row 1.44 ms per pass on top (its 2 x (2 n_store - 1) plane copies between store and rings, mostly
@@ -98,16 +116,15 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
             //     47 / 37 rows kept: 5.22 / 5.50 / 5.50 / 5.84 / 6.53 s measured, 5.48 / 5.72 / 5.81 / 5.83 / 7.25 modelled
             //     (profiles/r05_hybrid_depths.jsonl).  Not with one-row chunks: (1, 20, 47 kept) ran at 46.6 Gvoxel-iters/s
             //     where (2, 12, 56 kept) ran at 57.8.
-            const int n_store = 2 + nd * n_state;  // arrays a kept row holds in HBM: data term, recon, state
-            const int64_t res = may_keep && r > 1 ? std::min<int64_t>(n_rows, (budget - planes) / n_store) : 0;
-            if (res >= n_rows && k >= 3) {
-                // every row kept: swept in place (tvdn_stream_chain.hip), no copy after the first pass -- 0.81 ms per 256 MiB plane and
-                // level at k = 6 and at k = 8 (64 rows, 80 iterations: 4.16 s where the copying schedule took 5.2); a millisecond
-                // per pass for its drain, so that the deepest such k wins
-                // (by chunk height, K = 3 and 8: one-row launches 0.89 ms, two-row 0.81-0.83, four-row 0.80: the rows a launch reads
-                //  beside its own weigh less in a taller one)
-                const double eff_kept = r >= 4 ? 0.90 : (r == 2 ? 0.88 : 0.80);
-                offer(res, (double)n_rows * moved * rb / (5.6e12 * eff_kept) + 1e-3 * (passes > 0 ? (double)passes / (double)n_iters : 1.0 / (double)k));
+            const int64_t res = fits && may_keep && r > 1 ? std::min<int64_t>(n_rows, (budget - planes) / n_store) : 0;
+            // every row kept: swept in place, no copy (0.77-0.89 ms per 256 MiB plane and level by chunk height: the rows a launch
+            // reads beside its own weigh less in a taller one -- 32 rows of 256 MiB planes, 80 iterations: (R 2, K 3) 2.13 s, (4, 3)
+            // 2.03, (8, 3) 1.98, (4, 9) 1.96; a pass costs ~3.5 ms to fill and drain), on the lean layout above when every pass is
+            // at least three levels deep
+            const bool lean = lean_fits && (passes == 0 || n_iters / passes >= 3);
+            if (lean || (res >= n_rows && k >= 3)) {
+                const double eff_kept = r >= 16 ? 0.945 : (r >= 8 ? 0.935 : (r >= 4 ? 0.915 : (r == 2 ? 0.88 : 0.80)));
+                offer(n_rows, (double)n_rows * moved * rb / (5.6e12 * eff_kept) + 3.5e-3 * rb / 268.4e6 * (passes > 0 ? (double)passes / (double)n_iters : 1.0 / (double)k));
             } else if (res > 0) {
                 const double link = (double)(n_rows - res) * (n_in + n_out) * rb;
                 // (a pass that streams anything also waits for a fifth of one row's way up and down: 63 of 64 rows kept at k = 9
@@ -288,7 +305,8 @@ extern "C" int tvdn_stream_plan(const tvdn_run_args *a, int64_t hbm_free_bytes, 
     out->rows = rows;
     out->k = k;
     out->resident_rows = res;
-    out->hbm_bytes = (stream_planes(a->ndim, rows, k, mse, true) + res * (2 + a->ndim * n_state)) * (int64_t)row_bytes;
+    const bool lean = res >= a->shape[0] && k >= 3 && !mse && (a->use_stop || n_total <= 0 || n_total / ((n_total + k - 1) / k) >= 3);
+    out->hbm_bytes = ((lean ? stream_planes_all_kept(a->ndim, rows, k, true) : stream_planes(a->ndim, rows, k, mse, true)) + res * (2 + a->ndim * n_state)) * (int64_t)row_bytes;
     int64_t need = 0, avail = 0;
     (void)stream_host_need(a, res, &need, &avail);
     out->host_bytes = need;

@@ -103,6 +103,7 @@ struct StreamRun {
     std::vector<void *> cdst, csrc;
     int down_blocks = 0;
     bool recon_direct = false, recon_direct_decided = false;  // the last pass sends the resident rows' results home itself
+    bool lean_layout = false;  // every row kept, rings for the levels 1 .. K-1 only, no boxes (tvdn_stream.hip set_up)
     int inplace_kind = 0;  // kept rows swept in place (tvdn_stream_chain.hip): 0 no, 1 where their neighbours are kept too, 2 every one (all rows kept)
     std::vector<double> ratios;
     int ran = 0, ran_phase[2] = {0, 0};

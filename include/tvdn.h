@@ -193,7 +193,8 @@ typedef struct tvdn_iter_args {
     /* ABI 8.  Ring sizes of their own, 0 = ring_rows: recon_in; b_in and d_in (the state of this level); dprev_in (the state of
      * the level before); recon_out; b_out and d_out.  A "ring" longer than the cube is an array: the first levels of a streamed
      * pass read rows that are kept in HBM between passes where they are kept, and the last ones write them there, instead of
-     * copying them into and out of the levels' rings (csrc/tvdn_stream_chain.hip). */
+     * copying them into and out of the levels' rings (csrc/tvdn_stream_chain.hip).  What is read may also be a ring of ONE row:
+     * every row is then that plane (the zeros a run's state starts from). */
     int64_t recon_in_ring_rows;
     int64_t cur_ring_rows;
     int64_t prev_ring_rows;
@@ -288,7 +289,8 @@ typedef struct tvdn_run_stats {
     int32_t kept_in_place; /* ABI 8.  streamed with resident rows: 0 = they entered and left the levels' rings by device copies;
                               1 = swept in place (level 0 reads them where they are kept, the last level writes them there)
                               wherever the rows next to them are kept too; 2 = all rows kept, every pass but the first
-                              without a copy                                                                          */
+                              without a copy; 3 = all rows kept on the lean layout (rings for the levels between the
+                              first and the last only, no boxes): no copy at all                                      */
 } tvdn_run_stats;
 
 /* ABI 6.  One slab of a cube that several PROCESSES denoise together, each streaming ITS slab through its GPU from its own

@@ -330,7 +330,7 @@ def test_streamed_engine_at_config5_plane_size_against_the_oracle(oracle):
     del buf
     torch.cuda.empty_cache()
     results = []
-    for resident, kind, passes in ((16, 2, 3), (13, 1, 3), (0, 0, 3)):
+    for resident, kind, passes in ((16, 3, 3), (13, 1, 3), (0, 0, 3)):
         st = _lib.RunStats()
         recon, sums, _, ran = _run(x, mu, its, 0, stream=(rows, k), resident=resident, stats=st)
         assert ran == its and st.engine == 1 and (st.stream_rows, st.stream_k, st.n_passes) == (rows, k, passes)

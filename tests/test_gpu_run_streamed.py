@@ -148,23 +148,28 @@ def test_streamed_run_with_resident_rows(oracle, shape, dtype, n_f, n_p, rows, k
 
 
 @pytest.mark.parametrize("shape,dtype,n_f,n_p,rows,k,resident,kind", [
-    ((40, 4, 8, 16), np.float32, 12, 0, 4, 4, 40, 2),      # every row kept, three passes of four levels: no copy after the first pass
-    ((40, 4, 8, 16), np.float32, 12, 0, 2, 3, 40, 2),      # ... the shallowest depth at which the shared state is written in place
+    ((40, 4, 8, 16), np.float32, 12, 0, 4, 4, 40, 3),      # every row kept, three passes of four levels: the lean layout, no copy at all
+    ((40, 4, 8, 16), np.float32, 12, 0, 2, 3, 40, 3),      # ... the shallowest depth at which the shared state is written in place
+    ((40, 4, 8, 16), np.float32, 12, 0, 16, 3, 40, 3),     # ... tall chunks (the lean layout's rings leave room for them)
+    ((40, 4, 8, 16), np.float32, 11, 0, 4, 4, 40, 3),      # ... passes of 4 + 4 + 3 levels
+    ((40, 4, 8, 16), np.float32, 10, 0, 4, 4, 40, 3),      # ... of 4 + 3 + 3
+    ((40, 4, 8, 16), np.float32, 8, 0, 4, 3, 40, 2),       # 3 + 3 + 2 levels: a pass of two levels needs the level-0 rings -- general layout, in place
     ((40, 4, 8, 16), np.float32, 12, 0, 4, 2, 40, 1),      # two levels: level 0's inputs and level 1's outputs only
-    ((40, 4, 8, 16), np.float32, 7, 6, 3, 4, 40, 2),       # hybrid schedule: the kept state changes form inside a pass and between passes
-    ((40, 4, 8, 16), np.float32, 0, 9, 4, 3, 40, 2),       # unaccelerated: one state array per axis
+    ((40, 4, 8, 16), np.float32, 7, 6, 3, 4, 40, 3),       # hybrid schedule: the kept state changes form inside a pass and between passes
+    ((40, 4, 8, 16), np.float32, 0, 9, 4, 3, 40, 3),       # unaccelerated: one state array per axis
     ((40, 4, 8, 16), np.float32, 12, 0, 4, 4, 33, 1),      # seven streamed rows among the kept ones: in place between them
     ((40, 4, 8, 16), np.float32, 12, 0, 1, 4, 30, 1),      # one-row chunks
     ((40, 4, 8, 16), np.float32, 7, 6, 2, 5, 36, 1),
-    ((41, 6, 16), np.float64, 9, 0, 3, 3, 41, 2),          # 3-D, f64, a ragged last chunk
+    ((41, 6, 16), np.float64, 9, 0, 3, 3, 41, 3),          # 3-D, f64, a ragged last chunk
     ((41, 6, 16), np.float64, 5, 5, 5, 5, 37, 1),
-    ((23, 2, 5, 7), np.float32, 8, 0, 2, 4, 23, 2),        # scalar packs
+    ((23, 2, 5, 7), np.float32, 8, 0, 2, 4, 23, 3),        # scalar packs
     ((40, 4, 8, 16), np.float32, 12, 0, 4, 1, 40, 0),      # one level per pass: nothing to gain, copies as before
 ])
 def test_kept_rows_are_swept_in_place(oracle, monkeypatch, shape, dtype, n_f, n_p, rows, k, resident, kind):
     """Rows kept in HBM between the passes are read by level 0 where they are kept and written there by the last level (ring sizes of
     their own per array, tvdn_iter_args ABI 8; csrc/tvdn_stream_chain.hip) wherever the rows next to them are kept too -- every
-    row when all are (`kept_in_place` 2).  The bits are those of the copying schedule (TVDN_STREAM_INPLACE=0), of the resident run
+    row when all are (`kept_in_place` 2; 3 on the lean layout a run takes when every pass is at least three levels deep: rings for
+    the levels in between only, the first pass in place too, recon from the data term and the state from a plane of zeros).  The bits are those of the copying schedule (TVDN_STREAM_INPLACE=0), of the resident run
     and of the oracle, traces included; a non-finite first row (exact Jia-Zhao wrap: row 0 of every level kept aside) as well."""
     from cytvdn_amd import _lib, synth
     dt = np.dtype(dtype)
@@ -179,6 +184,13 @@ def test_kept_rows_are_swept_in_place(oracle, monkeypatch, shape, dtype, n_f, n_
         monkeypatch.delenv("TVDN_STREAM_INPLACE", raising=False)
         got = _run(x, mu, n_f, n_p, stream=(rows, k), resident=resident, stats=st)
         assert st.engine == 1 and st.resident_rows == resident and st.kept_in_place == kind
+        if kind == 3:       # the same run on the general layout: every pass but the first in place
+            st2 = _lib.RunStats()
+            monkeypatch.setenv("TVDN_STREAM_LEAN", "0")
+            fat = _run(x, mu, n_f, n_p, stream=(rows, k), resident=resident, stats=st2)
+            monkeypatch.delenv("TVDN_STREAM_LEAN")
+            assert st2.kept_in_place == 2 and bits_equal(got[0], fat[0])
+            np.testing.assert_array_equal(got[1], fat[1])
         st0 = _lib.RunStats()
         monkeypatch.setenv("TVDN_STREAM_INPLACE", "0")
         copied = _run(x, mu, n_f, n_p, stream=(rows, k), resident=resident, stats=st0)

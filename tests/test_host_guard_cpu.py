@@ -277,7 +277,7 @@ def test_the_streamed_plan_as_arithmetic():
         rc, half = _stream_plan((64, 1024, 256, 256), hbm)
         assert rc == 0 and half.hbm_bytes <= 0.85 * hbm
         if hbm >= 268 * gib:
-            assert half.rows in (2, 4) and half.resident_rows >= 48 and 3 <= half.k <= 16  # most rows fit (all of them, at 268 GiB, beside rings of 5 levels): keep them, shallow rings
+            assert half.rows >= 2 and half.resident_rows == 64 and 3 <= half.k <= 16    # every row fits beside the rings of the levels in between (the lean layout): tall chunks, shallow rings
             assert half.host_bytes == 10 * (64 - half.resident_rows) * plane
         rc, none = _stream_plan((64, 1024, 256, 256), hbm, resident=0)
         assert rc == 0 and none.resident_rows == 0 and none.rows == 1 and none.k >= half.k and (none.k > half.k or half.resident_rows == 0)

@@ -7,7 +7,7 @@ import bench
 from cytvdn_amd import _lib
 import cytvdn_amd as tv
 mode = sys.argv[1]
-half = (64, 1024, 256, 256)
+half = (int(os.environ.get("PROBE_ROWS", "64")), 1024, 256, 256)
 def free(tag):
     f, t = torch.cuda.mem_get_info(0)
     print(tag, round(f/2**30, 2), "kept", round(_lib.state_kept_bytes(0)/2**30, 2), flush=True)
