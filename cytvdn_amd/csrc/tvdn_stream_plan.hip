@@ -123,7 +123,8 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
             // at least three levels deep
             const bool lean = lean_fits && (passes == 0 || n_iters / passes >= 3);
             if (lean || (res >= n_rows && k >= 3)) {
-                const double eff_kept = r >= 16 ? 0.945 : (r >= 8 ? 0.935 : (r >= 4 ? 0.915 : (r == 2 ? 0.88 : 0.80)));
+                // (64 rows on the lean layout: (R 4, K 3) 4.05 s, (8, 5) 3.92, (16, 4) 3.98 -- nothing beyond eight-row chunks)
+                const double eff_kept = r >= 16 ? 0.925 : (r >= 8 ? 0.935 : (r >= 4 ? 0.915 : (r == 2 ? 0.88 : 0.80)));
                 offer(n_rows, (double)n_rows * moved * rb / (5.6e12 * eff_kept) + 3.5e-3 * rb / 268.4e6 * (passes > 0 ? (double)passes / (double)n_iters : 1.0 / (double)k));
             } else if (res > 0) {
                 const double link = (double)(n_rows - res) * (n_in + n_out) * rb;
