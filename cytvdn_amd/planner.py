@@ -205,6 +205,26 @@ def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int =
                        host_bytes_per_rank=host_arrays * (rows_own + 2 * k) * plane,   # in-place host state
                        why=f"state of {out['state_bytes'] / 2 ** 30:.1f} GiB exceeds {avail / 2 ** 30:.1f} GiB of HBM: "
                            f"streamed from pinned host memory")
+            # What the library itself would do with this much HBM on a long run (tvdn_stream_plan, pure arithmetic): it may keep
+            # rows in HBM between the passes -- all of them, swept in place, where ten arrays and a few rings fit (a cube up to
+            # 1.36 x what fits resident) -- and then page-locks only the rows it streams.
+            try:
+                import ctypes as C
+                from . import _lib
+                a = _lib.RunArgs(dtype=_lib.dtype_code(np.dtype(dtype)), ndim=nd, bc_mode=2, device=int(device), n_fista=1024 if FISTA else 0,
+                                 n_plain=0 if FISTA else 1024, use_stop=int(bool(stop)), stream_rows=-1, stream_k=-1, stream_resident=-1)
+                for i, v in enumerate(shape):
+                    a.shape[i] = int(v)
+                po = _lib.StreamPlanOut()
+                if _lib.lib().tvdn_stream_plan(C.byref(a), int(avail), C.byref(po)) == 0:
+                    out.update(chunk_rows=int(po.rows), k=int(po.k), resident_rows_per_rank=int(po.resident_rows),
+                               bytes_per_gpu=int(po.hbm_bytes), host_bytes_per_rank=host_arrays * (n0 - int(po.resident_rows)) * plane)
+                    if po.resident_rows >= n0:
+                        out["why"] += ": every row kept in HBM between the passes and swept in place (10 arrays + rings), nothing page-locked"
+                    elif po.resident_rows > 0:
+                        out["why"] += f", {int(po.resident_rows)} of {n0} rows kept in HBM between the passes"
+            except Exception:
+                pass            # (no library: the arithmetic above stands)
             if host_bytes is not None and out["host_bytes_per_rank"] > host_bytes:
                 out["why"] += " (WARNING: the pinned host state does not fit in the host memory given)"
             return out

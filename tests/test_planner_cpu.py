@@ -56,7 +56,9 @@ def test_limit_knob_and_misfits(monkeypatch):
     assert _parse_bytes("1000") == 1000
     monkeypatch.setenv("TVDN_HBM_LIMIT", "24M")
     p = plan_run((40, 8, 32, 64), "float32", True, 1)      # 39 MB of state against 24 MB
-    assert p["hbm_bytes"] == 24 * 2 ** 20 and p["mode"] == "wavefront" and (p["chunk_rows"], p["k"]) == (2, 8)
+    # (the shape of a streamed run is the library's own: tvdn_stream_plan with this much HBM, for a long run)
+    assert p["hbm_bytes"] == 24 * 2 ** 20 and p["mode"] == "wavefront" and p["chunk_rows"] >= 1 and p["k"] >= 8
+    assert p["bytes_per_gpu"] <= 0.85 * 24 * 2 ** 20 and 0 <= p["resident_rows_per_rank"] < 40
     ps = plan_run((40, 8, 32, 64), "float32", True, 1, stop=True)
     assert ps["mode"] == "wavefront" and ps["k"] == 1
     monkeypatch.setenv("TVDN_HBM_LIMIT", "1G")
