@@ -149,6 +149,45 @@ def test_planner_picks_the_streamed_engines_by_itself(oracle, monkeypatch, stop)
     assert not calls and bits_equal(again[0], got[0])
 
 
+def test_a_cube_between_resident_and_streamed_keeps_every_row_in_place(oracle, monkeypatch):
+    """A cube whose 15-array state does not fit the HBM the planner may count on, but whose 10 kept arrays and a few rings do (up
+    to 1.36 x what fits resident): the library's plan for that much HBM (tvdn_stream_plan, what denoise4D asks for) keeps every
+    row in HBM on the lean layout and sweeps it in place -- nothing page-locked, nothing across PCIe between the passes -- and
+    denoise4D gets there by itself.  The oracle's bits either way; plan_run says the same beforehand."""
+    import ctypes as C
+    import cytvdn_amd as tv
+    from cytvdn_amd import _lib, driver, planner, synth
+    monkeypatch.delenv("TVDN_WAVEFRONT", raising=False)
+    monkeypatch.delenv("TVDN_STAGED", raising=False)
+    monkeypatch.setenv("TVDN_HBM_LIMIT", "36M")            # 39 MB of resident state; 26 MB of kept arrays
+    shape, dt = (40, 8, 32, 64), np.dtype(np.float32)
+    x = synth.cube(shape, seed=6, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 1.0, 0.5, 0.5], dt)
+    lam = mu / dt.type(32.0)
+    its = 12
+    plan = planner.plan_run(shape, dt, True, 1)
+    assert plan["mode"] == "wavefront" and plan["resident_rows_per_rank"] == 40 and plan["host_bytes_per_rank"] == 0, plan
+    assert plan["bytes_per_gpu"] <= 0.85 * 36 * 2 ** 20
+    ref = oracle.denoise(x, mu, its, True)
+    rows, k = driver._library_stream_plan(x, its, 0, False, False, 2, 0, plan["hbm_bytes"])
+    assert rows >= 2 and 3 <= k <= its
+    a = _lib.RunArgs(dtype=0, ndim=4, bc_mode=2, device=0, n_fista=its, n_plain=0, stream_rows=rows, stream_k=k, stream_resident=-1)
+    for i, v in enumerate(shape):
+        a.shape[i] = v
+    for q in range(4):
+        a.clip[q] = float((1.0 / lam)[q])
+        a.lambda_mu[q] = float((lam / mu).astype(dt)[q])
+    recon, sums, st = np.empty_like(x), np.zeros((its, 3)), _lib.RunStats()
+    a.data, a.recon_out, a.sums_out, a.stats = x.ctypes.data, recon.ctypes.data, sums.ctypes.data, C.addressof(st)
+    _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+    assert st.engine == 1 and st.resident_rows == 40 and st.kept_in_place == 3 and (st.stream_rows, st.stream_k) == (rows, k), (st.engine, st.resident_rows, st.kept_in_place, st.stream_k)
+    assert st.h2d_bytes == x.nbytes and st.d2h_bytes == x.nbytes        # the cube in, the result out
+    assert bits_equal(recon, ref["recon"])
+    np.testing.assert_allclose(sums[:, 0], ref["b_norm64"], rtol=1e-9)
+    got = tv.denoise4D(x, mu, its, quiet=True)
+    assert bits_equal(got[0], ref["recon"])
+
+
 def test_planner_counts_what_torchs_cache_holds():
     """A process that has just denoised a cube keeps its state block in torch's caching allocator: the planner must count
     that as available (the next resident run reuses it), else the second large cube of a process is streamed for nothing."""
