@@ -740,6 +740,18 @@ def main():
                 api.append({"config": {"workload": what}, "error": repr(e)})
         x_half = None
         x2 = None
+        # A cube that does NOT fit resident (15 arrays of 22 GiB) but whose 10 kept arrays and a few rings do: the library keeps every
+        # row in HBM and sweeps it in place (the lean layout of the streamed engine) -- nothing page-locked, PCIe for the cube itself
+        try:
+            big = (88, 1024, 256, 256)
+            if mem_available_gib() >= 60.0:
+                _lib.lib().tvdn_release_cache()
+                torch.cuda.empty_cache()
+                api.append(api_streamed(big, -1, -1, 80, "88x1024x256x256 (22 GiB per array: 330 GiB of resident state, more than the HBM) with "
+                                                         "the library's own plan: every row kept in HBM (10 arrays + rings), swept in place",
+                                        None, local_rank, force_stream=True, resident=-1))
+        except Exception as e:
+            api.append({"config": {"workload": "88x1024x256x256 beyond the resident engine"}, "error": repr(e)})
 
     cpu = None
     if headline and rank == 0 and not a.no_cpu_baseline:
