@@ -183,15 +183,20 @@ int StreamRun::set_up(bool &nothing_to_do)
     lean_layout = false;
     {
         const char *e_inplace = getenv("TVDN_STREAM_INPLACE"), *e_res = getenv("TVDN_STREAM_RESIDENT"), *e_lean = getenv("TVDN_STREAM_LEAN");
-        int min_depth = K > 0 ? (int)K : 0;
-        for (int q = 0; q < n_pass_plan; ++q) min_depth = std::min(min_depth, depth_of_pass(q));
-        const bool wanted = !sh && !periodic && !want_mse && !a->use_stop && min_depth >= 3 && (res_req < 0 || res_req >= N0) && !e_res &&
+        const bool wanted = !sh && !periodic && !want_mse && !a->use_stop && K >= 3 && (res_req < 0 || res_req >= N0) && !e_res &&
                             !(e_inplace && atoi(e_inplace) == 0) && !(e_lean && atoi(e_lean) == 0);
         if (wanted) {
-            const size_t lean_b = stream_device_bytes_all_kept(nd, R, K, row_bytes);
+            // every pass at least three levels deep: 80 iterations asked at K = 3 would be 26 passes of 3 and one of 2 -- one pass
+            // fewer makes them 2 x 4 + 24 x 3 (nothing crosses PCIe between the passes of such a run: their number is free)
+            int passes = n_pass_plan;
+            while (passes > 1 && n_total / passes < 3) --passes;
+            const int64_t k_lean = (n_total + passes - 1) / passes;
+            const size_t lean_b = stream_device_bytes_all_kept(nd, R, k_lean, row_bytes);
             const size_t need_b = lean_b + (size_t)N0 * (size_t)n_store * plane_b;
-            if (need_b <= (size_t)((res_req < 0 ? 0.85 : 0.92) * (double)free_b)) {
+            if (n_total / passes >= 3 && need_b <= (size_t)((res_req < 0 ? 0.85 : 0.92) * (double)free_b)) {
                 lean_layout = true;
+                n_pass_plan = passes;
+                K = k_lean;  // (= depth_of_pass(0); nothing computed so far depends on K in a run that is neither periodic nor a slab)
                 dev_bytes_max = lean_b;
                 rm.res = N0;
             }

@@ -121,7 +121,7 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
             // reads beside its own weigh less in a taller one -- 32 rows of 256 MiB planes, 80 iterations: (R 2, K 3) 2.13 s, (4, 3)
             // 2.03, (8, 3) 1.98, (4, 9) 1.96; a pass costs ~3.5 ms to fill and drain), on the lean layout above when every pass is
             // at least three levels deep
-            const bool lean = lean_fits && (passes == 0 || n_iters / passes >= 3);
+            const bool lean = lean_fits && (passes == 0 || n_iters / passes >= 3);  // (depths of 3 and 2 are re-balanced by the run itself: a deeper K, offered as such)
             if (lean || (res >= n_rows && k >= 3)) {
                 // (64 rows on the lean layout: (R 4, K 3) 4.05 s, (8, 5) 3.92, (16, 4) 3.98 -- nothing beyond eight-row chunks)
                 const double eff_kept = r >= 16 ? 0.925 : (r >= 8 ? 0.935 : (r >= 4 ? 0.915 : (r == 2 ? 0.88 : 0.80)));

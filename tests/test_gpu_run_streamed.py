@@ -153,7 +153,7 @@ def test_streamed_run_with_resident_rows(oracle, shape, dtype, n_f, n_p, rows, k
     ((40, 4, 8, 16), np.float32, 12, 0, 16, 3, 40, 3),     # ... tall chunks (the lean layout's rings leave room for them)
     ((40, 4, 8, 16), np.float32, 11, 0, 4, 4, 40, 3),      # ... passes of 4 + 4 + 3 levels
     ((40, 4, 8, 16), np.float32, 10, 0, 4, 4, 40, 3),      # ... of 4 + 3 + 3
-    ((40, 4, 8, 16), np.float32, 8, 0, 4, 3, 40, 2),       # 3 + 3 + 2 levels: a pass of two levels needs the level-0 rings -- general layout, in place
+    ((40, 4, 8, 16), np.float32, 8, 0, 4, 3, 40, 3),       # asked as 3 + 3 + 2 levels: a pass of two needs the level-0 rings -- the lean run makes it 4 + 4
     ((40, 4, 8, 16), np.float32, 12, 0, 4, 2, 40, 1),      # two levels: level 0's inputs and level 1's outputs only
     ((40, 4, 8, 16), np.float32, 7, 6, 3, 4, 40, 3),       # hybrid schedule: the kept state changes form inside a pass and between passes
     ((40, 4, 8, 16), np.float32, 0, 9, 4, 3, 40, 3),       # unaccelerated: one state array per axis
@@ -190,13 +190,13 @@ def test_kept_rows_are_swept_in_place(oracle, monkeypatch, shape, dtype, n_f, n_
             fat = _run(x, mu, n_f, n_p, stream=(rows, k), resident=resident, stats=st2)
             monkeypatch.delenv("TVDN_STREAM_LEAN")
             assert st2.kept_in_place == 2 and bits_equal(got[0], fat[0])
-            np.testing.assert_array_equal(got[1], fat[1])
+            np.testing.assert_allclose(got[1], fat[1], rtol=1e-12)     # (the lean run may cut the iterations into other passes: f64 sums to rounding)
         st0 = _lib.RunStats()
         monkeypatch.setenv("TVDN_STREAM_INPLACE", "0")
         copied = _run(x, mu, n_f, n_p, stream=(rows, k), resident=resident, stats=st0)
         assert st0.kept_in_place == 0
         assert bits_equal(got[0], copied[0])
-        np.testing.assert_array_equal(got[1], copied[1])
+        np.testing.assert_allclose(got[1], copied[1], rtol=1e-12)
         assert (st.h2d_bytes, st.d2h_bytes) == (st0.h2d_bytes, st0.d2h_bytes)
         ref = _oracle(oracle, x, mu, n_f, n_p)
         assert bits_equal(got[0], ref["recon"])
