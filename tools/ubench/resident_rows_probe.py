@@ -1,7 +1,7 @@
 """Measurement aid: what a hybrid streamed run (rows kept in HBM + rows streamed) of half a config-5 rank slab costs by depth.
    python tools/ubench/resident_rows_probe.py fresh|after|shapes [k ...]    (profiles/r05_hybrid_depths.jsonl)"""
 import ctypes as C, sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import bench
 from cytvdn_amd import _lib
