@@ -363,6 +363,9 @@ def measure(shape, dtype_name, fista, state, steps, warmup, device, rank=0, worl
         "config": {"workload": name, "global_shape": list(shape), "local_block": list(lay.local_shape), "bc_mode": 2,
                    "state_arrays": be.n_arrays(), "state": state, "state_mem": be.state_mem,
                    "placement_audition_ms": getattr(be, "audition", []),
+                   "timed_loop": "engine.SlabRunner: one tvdn_iterate_fused launch + fold per step, driven from Python on a state "
+                                 "resident in HBM (the loop denoise3D/4D run by default is tvdn_run's, measured whole-call by the "
+                                 "'denoise4D NumPy -> NumPy' entries of also[])",
                    "parallelism": f"slab{world}" if world > 1 else ("one slab of %d" % slab_of if slab_of else "single")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
