@@ -64,6 +64,14 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
     // and with a stopping rule (any pass may be the last).
     const bool ship_recon = ships_recon();
     const int64_t n_chunks = (V1 + ps[(size_t)P - 1].kk + R - 1) / R;
+    // downloads: the runtime's copies behind events (drained passes), a copy kernel of a few workgroups (down_blocks), or the
+    // runtime's DMA engine one copy at a time from a helper thread (DownPump, tvdn_stream_parts.hpp)
+    std::unique_ptr<DownPump> pump_holder;
+    if (down_pump) {
+        pump_holder.reset(new DownPump);
+        pump_holder->start(device, st.down);
+    }
+    DownPump *pump = pump_holder.get();
     // Rows kept in HBM are swept IN PLACE where their neighbours are kept too (one pass at a time: P == 1, v == g).  The store of
     // the kept rows is a set of arrays; to a sweep an array is a ring longer than the cube (tvdn_iter_args.*_ring_rows), so level
     // 0 reads recon and the state straight from the store and the last level writes them there, instead of a copy of every
@@ -169,10 +177,14 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
             if (q > 0) {
                 // these rows came down at the end of pass q - 1: the upload stream waits for the chunk that sent the last of them
                 const int64_t t_out = ((int64_t)(q - 1) * N0 + (g1 - 1) + ps[(size_t)q - 1].kk) / R;
-                TVDN_REQUIRE(t_out < t_now && down_done[(size_t)t_out] != nullptr,
+                TVDN_REQUIRE(t_out < t_now && (pump || down_done[(size_t)t_out] != nullptr),
                              "chained passes: row %lld of pass %d is uploaded before pass %d has sent it home (k too deep to chain)",
                              (long long)(g1 - 1), q, q - 1);
-                TVDN_HIP(hipStreamWaitEvent(st.up, down_done[(size_t)t_out], 0));
+                if (pump) {
+                    if ((r3 = pump->wait(t_out))) return r3;
+                } else {
+                    TVDN_HIP(hipStreamWaitEvent(st.up, down_done[(size_t)t_out], 0));
+                }
             }
             if (ship_recon) {
                 if ((r3 = wait_recon(0))) return r3;
@@ -458,13 +470,24 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
         TVDN_REQUIRE(oslot <= R + 1, "chained passes: %lld rows come down in one chunk, the out boxes hold %lld (depths of consecutive passes differ by more than one)",
                      (long long)oslot, (long long)(R + 1));
         if (!cdst.empty()) {
-            if (oslot > 0 && out_free_set[h]) TVDN_HIP(hipStreamWaitEvent(st.main, out_free[h], 0));
+            if (oslot > 0 && pump) {  // the box's last rows (two chunks ago) are home: the helper has waited for their copies
+                if ((rc2 = pump->wait(t - 2))) return rc2;
+            } else if (oslot > 0 && out_free_set[h]) {
+                TVDN_HIP(hipStreamWaitEvent(st.main, out_free[h], 0));
+            }
             rc2 = copy_rows(cdst, csrc, row_bytes, st.main);
             if (rc2) return rc2;
         }
         if (oslot > 0) {
-            TVDN_HIP(hipEventRecord(out_ready[h], st.main));
-            TVDN_HIP(hipStreamWaitEvent(st.down, out_ready[h], 0));
+            DownPump::Job job;
+            if (pump) {
+                job.id = t;
+                if ((rc2 = evs.make(&job.ready))) return rc2;
+                TVDN_HIP(hipEventRecord(job.ready, st.main));
+            } else {
+                TVDN_HIP(hipEventRecord(out_ready[h], st.main));
+                TVDN_HIP(hipStreamWaitEvent(st.down, out_ready[h], 0));
+            }
             if ((rc2 = wait_recon(0))) return rc2;  // the host arrays these rows land in exist (first pass: the helper may still be at it)
             std::vector<void *> kd, ks;  // copies of whole rows for the copy kernel (down_blocks > 0)
             for (const Out &o : outs) {
@@ -476,7 +499,9 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                         if (direct) {  // its result went into the out box: one row, straight into the caller's array
                             char *dst = recon_h.p + (size_t)g * row_bytes;
                             const char *src = outbox[h][0] + (size_t)slot * row_bytes;
-                            if (down_blocks > 0 && row_bytes % 16 == 0 && ((uintptr_t)dst & 15) == 0) {
+                            if (pump) {
+                                job.copies.push_back(DownPump::Copy{dst, src, row_bytes});
+                            } else if (down_blocks > 0 && row_bytes % 16 == 0 && ((uintptr_t)dst & 15) == 0) {
                                 kd.push_back(dst);
                                 ks.push_back((void *)src);
                             } else {
@@ -494,6 +519,10 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                     while (g + n < o.g1 && !resident(g + n) && sb[0].block_of(hs + n) == sb[0].block_of(hs)) ++n;
                     const size_t boff = (size_t)slot * row_bytes, len = (size_t)n * row_bytes;
                     auto down = [&](char *dst, const char *src) -> int {
+                        if (pump) {
+                            job.copies.push_back(DownPump::Copy{dst, src, len});
+                            return TVDN_OK;
+                        }
                         if (down_blocks > 0 && row_bytes % 16 == 0 && ((uintptr_t)dst & 15) == 0) {
                             for (int64_t r = 0; r < n; ++r) {
                                 kd.push_back(dst + (size_t)r * row_bytes);
@@ -516,14 +545,19 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
             }
             // ONE launch of a few workgroups writes the chunk's rows into the page-locked host arrays (see down_blocks)
             if (!kd.empty() && (rc2 = tvdn_copy_many((int32_t)kd.size(), kd.data(), ks.data(), (int64_t)row_bytes, down_blocks, st.down))) return rc2;
-            TVDN_HIP(hipEventRecord(out_free[h], st.down));
-            out_free_set[h] = true;
+            if (pump) {
+                pump->push(std::move(job));
+            } else {
+                TVDN_HIP(hipEventRecord(out_free[h], st.down));
+                out_free_set[h] = true;
+            }
         }
-        if (P > 1) {  // what a later pass's uploads wait for (also for chunks that sent nothing: the stream is in order)
+        if (P > 1 && !pump) {  // what a later pass's uploads wait for (also for chunks that sent nothing: the stream is in order)
             if ((rc2 = evs.make(&down_done[(size_t)t]))) return rc2;
             TVDN_HIP(hipEventRecord(down_done[(size_t)t], st.down));
         }
     }
+    if (pump && (rc2 = pump->drain())) return rc2;
     TVDN_HIP(hipStreamSynchronize(st.down));
     TVDN_HIP(hipStreamSynchronize(st.main));
     TVDN_HIP(hipStreamSynchronize(st.up));

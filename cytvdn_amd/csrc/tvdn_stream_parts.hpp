@@ -12,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <deque>
 #include <thread>
 
 #include <sys/mman.h>
@@ -520,6 +521,94 @@ struct Joiner {
     {
         if (t.joinable()) t.join();
     }
+};
+
+// Downloads of chained passes by the runtime's DMA engine, ONE copy at a time.  hipMemcpyAsync takes the SDMA engine when its
+// stream is idle and a blit kernel otherwise (rocprofv3: 3 000 __amd_rocclr_copyBuffer launches and 21 ms per 256 MiB in a run
+// that queues a chunk's eight downloads back to back behind an event, 5.7 ms = 47 GB/s when each is handed to an idle stream);
+// blit kernels wait for the sweeps' wavefront slots, the DMA engine does not and leaves the sweeps alone
+// (tools/ubench/pcie_down_kernels.hip: 47.7 GB/s down beside 55.7 up and 5.9 TB/s of kernels, where the 8-workgroup copy kernel
+// gets 39-42 beside 54 and 5.5).  So a helper thread waits for a chunk's rows to be gathered, then issues its copies one by one,
+// waiting for each; the scheduling thread asks it (on the host) before it reuses an out box or uploads what has come down.
+struct DownPump {
+    struct Copy {
+        void *dst;
+        const void *src;
+        size_t len;
+    };
+    struct Job {
+        int64_t id = 0;
+        hipEvent_t ready = nullptr;  // recorded on the sweeps' stream behind the gather of this chunk
+        std::vector<Copy> copies;
+    };
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job> q;
+    int64_t finished = -1;  // every job pushed with id <= finished is done (ids ascend)
+    int64_t pushed = -1;
+    bool stop = false, running = false;
+    int rc = TVDN_OK;
+    std::string msg;
+    void start(int device, hipStream_t s)
+    {
+        running = true;
+        th = std::thread([this, device, s] {
+            (void)hipSetDevice(device);
+            for (;;) {
+                Job j;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || !q.empty(); });
+                    if (q.empty()) return;
+                    j = std::move(q.front());
+                    q.pop_front();
+                }
+                hipError_t e = hipEventSynchronize(j.ready);
+                for (size_t i = 0; i < j.copies.size() && e == hipSuccess; ++i) {
+                    e = hipMemcpyAsync(j.copies[i].dst, j.copies[i].src, j.copies[i].len, hipMemcpyDeviceToHost, s);
+                    if (e == hipSuccess) e = hipStreamSynchronize(s);
+                }
+                std::lock_guard<std::mutex> lk(mu);
+                if (e != hipSuccess && rc == TVDN_OK) {
+                    rc = TVDN_ERR_HIP;
+                    msg = std::string("a download of a streamed run failed: ") + hipGetErrorString(e);
+                    (void)hipGetLastError();
+                }
+                finished = j.id;
+                cv.notify_all();
+            }
+        });
+    }
+    void push(Job &&j)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        pushed = j.id;
+        q.push_back(std::move(j));
+        cv.notify_all();
+    }
+    // every job with id <= `id` is done (the helper has waited for its copies)
+    int wait(int64_t id)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        const int64_t upto = std::min(id, pushed);
+        cv.wait(lk, [&] { return finished >= upto || !running; });
+        if (rc) set_error("%s", msg.c_str());
+        return rc;
+    }
+    int drain() { return wait(INT64_MAX); }
+    void shutdown()
+    {
+        if (!running) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+        running = false;
+    }
+    ~DownPump() { shutdown(); }
 };
 
 // ---- tvdn_stream_plan.hip: what a shape costs, and what a run may choose -------------------------------------------------------

@@ -75,6 +75,7 @@ struct Variant {
     const char *name;
     int wgs;
     void (*launch)(int wgs, vec_t *d, const vec_t *s, size_t n, hipStream_t st);
+    int dma;  // arrays of a chunk that go down by hipMemcpyAsync on a second stream instead (0: none)
 };
 template <int U, int T, bool NT>
 static void launch(int wgs, vec_t *d, const vec_t *s, size_t n, hipStream_t st)
@@ -116,6 +117,10 @@ int main(int argc, char **argv)
         {"16 x 256, 4 in flight", 16, launch<4, 256, true>},
         {"8 x 256, 8 in flight, plain stores", 8, launch<8, 256, false>},
         {"2 x 1024, 16 in flight", 2, launch<16, 1024, true>},
+        {"8 x 256, 4 in flight + 2 of 8 arrays by hipMemcpyAsync", 8, launch<4, 256, true>, 2},
+        {"8 x 256, 4 in flight + 3 of 8 arrays by hipMemcpyAsync", 8, launch<4, 256, true>, 3},
+        {"8 x 256, 4 in flight + 4 of 8 arrays by hipMemcpyAsync", 8, launch<4, 256, true>, 4},
+        {"all 8 arrays by hipMemcpyAsync", 8, launch<4, 256, true>, 8},
     };
     for (int mode = 0; mode < 3; ++mode) {  // 0: downloads alone; 1: + uploads; 2: + uploads + an HBM-bound kernel stream
         for (const Variant &v : vs) {
@@ -132,7 +137,19 @@ int main(int argc, char **argv)
                     for (int i = 0; i < NU; ++i) CK(hipMemcpyAsync(in_box + (size_t)i * piece, hu[i] + (size_t)(c & 1) * piece, piece, hipMemcpyHostToDevice, s_up));
                 if (mode >= 2)
                     for (int j = 0; j < 30; ++j, ++n_bg) hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((big_n + 255) / 256)), dim3(256), 0, s_bg, (vec_t *)big, big_n);
-                for (int i = 0; i < ND; ++i) v.launch(v.wgs, (vec_t *)(hd[i] + (size_t)(c & 1) * piece), (const vec_t *)(out_box + (size_t)i * piece), piece / 16, s_dn);
+                for (int i = 0; i < ND; ++i) {
+                    if (i < ND - v.dma)
+                        v.launch(v.wgs, (vec_t *)(hd[i] + (size_t)(c & 1) * piece), (const vec_t *)(out_box + (size_t)i * piece), piece / 16, s_dn);
+                    else
+                        CK(hipMemcpyAsync(hd[i] + (size_t)(c & 1) * piece, out_box + (size_t)i * piece, piece, hipMemcpyDeviceToHost, s_dn2));
+                }
+            }
+            if (v.dma) {  // the downloads end when both streams have
+                hipEvent_t j;
+                CK(hipEventCreate(&j));
+                CK(hipEventRecord(j, s_dn2));
+                CK(hipStreamWaitEvent(s_dn, j, 0));
+                CK(hipEventDestroy(j));
             }
             CK(hipEventRecord(d1, s_dn));
             CK(hipEventRecord(u1, s_up));

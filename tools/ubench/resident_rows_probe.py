@@ -26,9 +26,11 @@ print({k: v for k, v in e.items() if k != "config"}, flush=True)
 free("end")
 if mode == "shapes":      # 80 iterations at explicit depths, the rows kept being what fits beside the rings of each
     import json
-    e = bench.api_streamed(half, -1, -1, 80, "the library's own plan for 80 iterations", x, 0, force_stream=True, resident=-1)
-    print(json.dumps({kk: v for kk, v in e.items() if kk != "config"}), flush=True)
+    if not os.environ.get("PROBE_SKIP_PLAN"):
+        e = bench.api_streamed(half, -1, -1, 80, "the library's own plan for 80 iterations", x, 0, force_stream=True, resident=-1)
+        print(json.dumps({kk: v for kk, v in e.items() if kk != "config"}), flush=True)
     for spec in sys.argv[2:] or ("8", "10", "12", "14", "16", "20"):     # K or R:K
         r, k = (int(v) for v in spec.split(":")) if ":" in spec else (2, int(spec))
-        e = bench.api_streamed(half, r, k, 80, f"{r}-row chunks, k = {k}", x, 0, force_stream=False, resident=-1)
+        e = bench.api_streamed(half, r, k, int(os.environ.get("PROBE_ITERS", "80")), f"{r}-row chunks, k = {k}", x, 0, force_stream=False,
+                               resident=int(os.environ.get("PROBE_RESIDENT", "-1")))
         print(json.dumps({kk: v for kk, v in e.items() if kk in ("value", "iterations", "stream_rows", "stream_k", "resident_rows", "passes", "passes_s", "setup_s", "h2d_GBps", "d2h_GBps")}), flush=True)
