@@ -501,8 +501,8 @@ int StreamRun::schedule()
     // chained passes of 49 levels over 64 rows of 256 MiB planes 13.35 -> 9.75 s (47.3 -> 64.8 Gvoxel-iters/s), 55 GB/s down beside
     // 42 up while rows come down, the sweeps undisturbed.  TVDN_STREAM_DOWN_PUMP=0 keeps the copy kernel (or, with
     // TVDN_STREAM_DOWN_BLOCKS=0, the runtime's copies queued behind events).
-    down_pump = !drained_pass_kind();
-    if (const char *e = getenv("TVDN_STREAM_DOWN_PUMP")) down_pump = atoi(e) != 0 && !drained_pass_kind();
+    down_pump = true;  // (also the drained passes of periodic cubes, slabs of a device list and ranks: tvdn_stream_pass.hip)
+    if (const char *e = getenv("TVDN_STREAM_DOWN_PUMP")) down_pump = atoi(e) != 0;
     if (getenv("TVDN_STREAM_DOWN_BLOCKS")) down_pump = false;
     if (down_pump) down_blocks = 0;
     if (!periodic && exact_wrap)

@@ -107,6 +107,13 @@ int StreamRun::pass(const double *ratios /* kk entries, NAN = unaccelerated */, 
         return TVDN_OK;
     };
 
+    // downloads by the DMA engine, one copy at a time from a helper thread (DownPump, tvdn_stream_parts.hpp), as in chain()
+    std::unique_ptr<DownPump> pump_holder;
+    if (down_pump) {
+        pump_holder.reset(new DownPump);
+        pump_holder->start(device, st.down);
+    }
+    DownPump *pump = pump_holder.get();
     int rc2 = upload(0);
     if (rc2) return rc2;
     for (int64_t c = 0; c < n_chunks; ++c) {
@@ -227,7 +234,11 @@ int StreamRun::pass(const double *ratios /* kk entries, NAN = unaccelerated */, 
         const int64_t lo = std::max(own0, E0 + c * R - kk), hi = std::min(own1, E0 + (c + 1) * R - kk);
         if (lo < hi) {
             const bool to_host = host_rows_in(lo, hi) > 0;
-            if (to_host && out_free_set[h]) TVDN_HIP(hipStreamWaitEvent(st.main, out_free[h], 0));
+            if (to_host && pump) {  // the box's last rows (two chunks ago) are home
+                if ((rc2 = pump->wait(c - 2))) return rc2;
+            } else if (to_host && out_free_set[h]) {
+                TVDN_HIP(hipStreamWaitEvent(st.main, out_free[h], 0));
+            }
             cdst.clear();
             csrc.clear();
             auto gather = [&](int i_store, int i_box, const Ring &rg) {
@@ -249,8 +260,22 @@ int StreamRun::pass(const double *ratios /* kk entries, NAN = unaccelerated */, 
             rc2 = copy_rows(cdst, csrc, row_bytes, st.main);
             if (rc2) return rc2;
             if (to_host) {
-                TVDN_HIP(hipEventRecord(out_ready[h], st.main));
-                TVDN_HIP(hipStreamWaitEvent(st.down, out_ready[h], 0));
+                DownPump::Job job;
+                if (pump) {
+                    job.id = c;
+                    if ((rc2 = evs.make(&job.ready))) return rc2;
+                    TVDN_HIP(hipEventRecord(job.ready, st.main));
+                } else {
+                    TVDN_HIP(hipEventRecord(out_ready[h], st.main));
+                    TVDN_HIP(hipStreamWaitEvent(st.down, out_ready[h], 0));
+                }
+                auto down = [&](char *dst, const char *src, size_t len) -> int {
+                    if (pump)
+                        job.copies.push_back(DownPump::Copy{dst, src, len});
+                    else
+                        TVDN_HIP(hipMemcpyAsync(dst, src, len, hipMemcpyDeviceToHost, st.down));
+                    return TVDN_OK;
+                };
                 if ((rc2 = wait_recon(h_new))) return rc2;  // the host arrays these rows land in exist (first pass: the helper may still be at it)
                 const HostArr &rh = (two_sets && h_new) ? recon2_h : recon_h;
                 // runs of host rows: consecutive cube rows (an array page-locked in place) or consecutive host slots inside
@@ -267,19 +292,24 @@ int StreamRun::pass(const double *ratios /* kk entries, NAN = unaccelerated */, 
                     while (g + n < hi - KX && !resident(g + n) && sb[h_new].block_of(hs + n) == sb[h_new].block_of(hs)) ++n;
                     const size_t boff = (size_t)slot * row_bytes, len = (size_t)n * row_bytes;
                     i = 0;
-                    TVDN_HIP(hipMemcpyAsync(hrow(rh, g, g + KX), outbox[h][i++] + boff, len, hipMemcpyDeviceToHost, st.down));
+                    if ((rc2 = down(hrow(rh, g, g + KX), outbox[h][i++] + boff, len))) return rc2;
                     for (int q = 0; q < nd; ++q)
                         for (int s = 0; s < n_out_state; ++s)
-                            TVDN_HIP(hipMemcpyAsync(srow(h_new, q * n_state + s, g, g + KX), outbox[h][i++] + boff, len, hipMemcpyDeviceToHost, st.down));
+                            if ((rc2 = down(srow(h_new, q * n_state + s, g, g + KX), outbox[h][i++] + boff, len))) return rc2;
                     bytes_down += (int64_t)len * (1 + (int64_t)n_out_state * nd);
                     slot += n;
                     g += n;
                 }
-                TVDN_HIP(hipEventRecord(out_free[h], st.down));
-                out_free_set[h] = true;
+                if (pump) {
+                    pump->push(std::move(job));
+                } else {
+                    TVDN_HIP(hipEventRecord(out_free[h], st.down));
+                    out_free_set[h] = true;
+                }
             }
         }
     }
+    if (pump && (rc2 = pump->drain())) return rc2;
     if (relay_recv && !relayed) {  // a slab that had no use for the planes still takes part in the hand-over
         const int rcr = sh->relay_row0(0, row0_host.p, kk);
         if (rcr) {

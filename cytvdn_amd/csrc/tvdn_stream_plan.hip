@@ -71,14 +71,17 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
     const int ships = k_cap <= 1 ? 1 : 0;
     const int n_in = 1 + ships + nd * n_state, n_out = ships + nd * n_state, moved = 3 + nd * (n_state + 1);
     k_cap = std::max<int64_t>(1, std::min<int64_t>({k_cap, 128, std::max<int64_t>(1, n_rows)}));
-    const double row_step = std::max((double)n_in * rb / 55e9, (double)n_out * rb / 42.5e9);  // one streamed row, both directions busy
+    // one streamed row, both directions busy: uploads and downloads by the DMA engines (round 5: downloads one copy at a time from
+    // a helper thread, tvdn_stream_parts.hpp DownPump -- 55.7 GB/s up beside 47.7 down and undisturbed sweeps in
+    // tools/ubench/pcie_down_kernels.hip; 42.5 down through round 4's copy kernel)
+    const double row_step = std::max((double)n_in * rb / 55e9, (double)n_out * rb / 48e9);
     int64_t best_k = 0, best_r = 0, best_res = 0;
     double best_t = 0.0;
     for (int64_t r : {32, 16, 8, 4, 2, 1}) {
         if (r > 1) r = std::min<int64_t>(r, std::max<int64_t>(2, n_rows));
         // sweeps on rings, launches of r rows: 0.86 ms per 256 MiB plane and level whether r is 2, 4 or 8 (83 % of the resident
         // sweep's rate; all rows resident, profiles/r04_stream_rates.jsonl), 0.92 ms in one-row launches
-        const double eff = r == 1 ? 0.77 : 0.82;
+        const double eff = r == 1 ? 0.80 : 0.82;  // (one-row launches: 0.89 ms per plane and level since nothing else runs kernels beside them)
         for (int64_t k = 1; k <= k_cap; ++k) {
             const int64_t planes = stream_planes(nd, r, k, mse, wrap);
             const int n_store = 2 + nd * n_state;  // arrays a kept row holds in HBM: data term, recon, state
@@ -106,7 +109,10 @@ int choose_stream_shape(int nd, int64_t n_rows, size_t row_bytes, size_t free_by
             auto per_iteration = [&](double t_pass) { return passes > 0 ? t_pass * (double)passes / (double)n_iters : t_pass / (double)k; };
             // (a) nothing kept: the pipeline of a pass fills and drains over K rows; chained passes share that between them
             //     (half of it counted)
-            if (fits) offer(0, per_iteration(std::max(((double)n_rows + 0.5 * (double)std::min<int64_t>(k, n_rows)) * row_step, t_sweeps)));
+            //     -- all of it when there are fewer than three passes to chain, a third of it when three, ...: 3 x 49 levels over
+            //     64 rows of 256 MiB planes 9.75 s measured (64.8 Gvoxel-iters/s), 2 x 49 drained 8.79 s
+            const double fill = passes >= 3 ? (double)std::min<int64_t>(k, n_rows) / (double)passes : (passes > 0 ? (double)std::min<int64_t>(k, n_rows) : 0.5 * (double)std::min<int64_t>(k, n_rows));
+            if (fits) offer(0, per_iteration(std::max(((double)n_rows + fill) * row_step, t_sweeps)));
             // (b) what the rest of the budget holds kept.  The passes are drained, so the link works both ways at once: 68 GB/s
             //     together when a pass waits for it.  When it does not, a row-plane takes 0.89 ms per level (the 0.82 x 5.6 TB/s
             //     above), a kept row 1.44 ms per pass on top (its 2 x (2 n_store - 1) plane copies between store and rings, mostly

@@ -233,7 +233,7 @@ def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int =
         # page-locks host_arrays x (own rows + 2 k halo rows - rows it keeps resident in HBM); interior rows -- none of the k
         # at a face shared with a neighbour -- stay resident as far as the HBM beside the rings allows.  The fastest (rows, k)
         # by the library's model (csrc/tvdn_stream.hip choose_stream_shape: a row crosses the busy link in max(up / 55,
-        # down / 42.5 GB/s), 68 GB/s both ways when rows are kept; ring sweeps at 0.82 x 5.6 TB/s, 0.77 x in one-row chunks;
+        # down / 48 GB/s: both by the DMA engines), 68 GB/s both ways when rows are kept; ring sweeps at 0.82 x 5.6 TB/s, 0.77 x in one-row chunks;
         # device copies at 7.1 TB/s) AMONG those whose page-locked state fits 80 % of the host memory n_gpus ranks share.
         # What the ranks hold is what distributed._check_hosts_hold_the_slabs will add up before any of them pins: the
         # page-locked arrays, the slab and its result as the caller holds them, the rows of a swap that goes through host memory.
@@ -243,7 +243,7 @@ def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int =
         def beside(k):
             return (2 * rows_own + (2 * k * (1 + nd * n_state) if swap_through_host else 0)) * plane
         rb = float(plane)
-        row_step = max(n_in * rb / 55e9, n_out * rb / 42.5e9)
+        row_step = max(n_in * rb / 55e9, n_out * rb / 48e9)
         best = fallback = None
         for rows in (2, 1) if not stop else (2,):
             for k in range(1, (1 if stop else min(MAX_DEPTH, rows_own)) + 1):
@@ -258,7 +258,7 @@ def plan_run(shape, dtype, FISTA: bool = True, n_gpus: int = 1, hbm_bytes: int =
                     #  planes whose transfers are hidden)
                     link = streamed * (n_in + n_out) * rb
                     t_pcie = link / 68e9 if res else (streamed + 0.5 * min(k, streamed)) * row_step
-                    t_gpu = rows_own * k * moved * rb / (5.6e12 * (0.77 if rows == 1 else 0.82))
+                    t_gpu = rows_own * k * moved * rb / (5.6e12 * (0.80 if rows == 1 else 0.82))
                     if res:
                         t_gpu += res * (2 * host_arrays - 1) * 2 * rb / 7.1e12 + link / 460e9
                         if streamed:
