@@ -497,7 +497,7 @@ int StreamRun::schedule()
     const bool can_chain = want_chain && !periodic && !a->use_stop && n_pass_plan > 1 && K <= N0 - 3 * R;
     down_blocks = can_chain ? 8 : 0;
     if (const char *e = getenv("TVDN_STREAM_DOWN_BLOCKS")) down_blocks = std::max(0, atoi(e));
-    // ... since round 5 by the DMA engine instead, one copy at a time from a helper thread (DownPump, tvdn_stream_parts.hpp): three
+    // ... since round 5 by the runtime's copies one at a time from a helper thread instead (DownPump, tvdn_stream_parts.hpp): three
     // chained passes of 49 levels over 64 rows of 256 MiB planes 13.35 -> 9.75 s (47.3 -> 64.8 Gvoxel-iters/s), 55 GB/s down beside
     // 42 up while rows come down, the sweeps undisturbed.  TVDN_STREAM_DOWN_PUMP=0 keeps the copy kernel (or, with
     // TVDN_STREAM_DOWN_BLOCKS=0, the runtime's copies queued behind events).

@@ -523,13 +523,14 @@ struct Joiner {
     }
 };
 
-// Downloads of chained passes by the runtime's DMA engine, ONE copy at a time.  hipMemcpyAsync takes the SDMA engine when its
-// stream is idle and a blit kernel otherwise (rocprofv3: 3 000 __amd_rocclr_copyBuffer launches and 21 ms per 256 MiB in a run
-// that queues a chunk's eight downloads back to back behind an event, 5.7 ms = 47 GB/s when each is handed to an idle stream);
-// blit kernels wait for the sweeps' wavefront slots, the DMA engine does not and leaves the sweeps alone
-// (tools/ubench/pcie_down_kernels.hip: 47.7 GB/s down beside 55.7 up and 5.9 TB/s of kernels, where the 8-workgroup copy kernel
-// gets 39-42 beside 54 and 5.5).  So a helper thread waits for a chunk's rows to be gathered, then issues its copies one by one,
-// waiting for each; the scheduling thread asks it (on the host) before it reuses an out box or uploads what has come down.
+// Downloads by the runtime's copies, ONE AT A TIME.  Eight hipMemcpyAsync calls queued on a stream behind an event -- a chunk's
+// rows on their way home -- are served slowly inside this engine: 21 ms per 256 MiB and thousands of __amd_rocclr_copyBuffer blit
+// kernels under rocprofv3 (they wait for wavefront slots the sweeps hold), 36 Gvoxel-iters/s where round 4's copy kernel of 8
+// workgroups gave 47 (and cost the sweeps 5 %).  The same copies handed to an idle stream one by one -- a helper thread waits for
+// a chunk's rows to be gathered, issues a copy, waits for it, issues the next -- run at 55 GB/s beside 42 GB/s of uploads and
+// leave the sweeps alone: 64.8 (profiles/r05_down_pump.jsonl; tools/ubench/pcie_down_kernels.hip shows the same link rates in
+// isolation: 47.7 down + 55.7 up + 5.9 TB/s of kernels).  The scheduling thread asks the helper, on the host, before it reuses an
+// out box or uploads what has come down.
 struct DownPump {
     struct Copy {
         void *dst;

@@ -1,12 +1,13 @@
 #!/bin/bash
 # Where do the runtime's downloads lose their time inside chained passes?  Every row of half a config-5 rank slab streamed, three
-# chained passes of 49 levels, downloads by hipMemcpyAsync (TVDN_STREAM_DOWN_BLOCKS=0), under rocprofv3 --memory-copy-trace
+# chained passes of 49 levels, downloads as DOWN_BLOCKS says (unset: the default, the DMA pump), under rocprofv3 --memory-copy-trace
 # --kernel-trace: duration of every copy by direction and size, and which kernels ran (blit kernels of the runtime included).
 R=$(pwd)
 O=$R/gpurun_out/r5dma
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-export PROBE_SKIP_PLAN=1 PROBE_RESIDENT=0 PROBE_ITERS=147 TVDN_STREAM_DOWN_BLOCKS=${DOWN_BLOCKS:-0}
+export PROBE_SKIP_PLAN=1 PROBE_RESIDENT=0 PROBE_ITERS=147
+[ -n "${DOWN_BLOCKS:-}" ] && export TVDN_STREAM_DOWN_BLOCKS=$DOWN_BLOCKS   # 0: the runtime's copies queued behind events; 8: the copy kernel; unset: the DMA pump (default)
 timeout -k 10 400 rocprofv3 --memory-copy-trace --kernel-trace --output-format csv -d $O/trace -- python3 $R/tools/ubench/resident_rows_probe.py shapes 1:49 > $O/run.log 2> $O/trace.log || { tail -5 $O/trace.log; exit 1; }
 cd $R
 python3 - <<'PY'
