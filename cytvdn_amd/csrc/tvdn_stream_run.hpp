@@ -102,7 +102,7 @@ struct StreamRun {
     int64_t bytes_up = 0, bytes_down = 0, n_passes = 0;  // across PCIe (tvdn_run_stats)
     std::vector<void *> cdst, csrc;
     int down_blocks = 0;
-    bool down_pump = false;  // chained passes: downloads by the DMA engine, one copy at a time from a helper thread (DownPump)
+    bool down_pump = false;  // downloads by the runtime's copies, one at a time from a helper thread (DownPump, tvdn_stream_parts.hpp)
     bool recon_direct = false, recon_direct_decided = false;  // the last pass sends the resident rows' results home itself
     bool lean_layout = false;  // every row kept, rings for the levels 1 .. K-1 only, no boxes (tvdn_stream.hip set_up)
     int inplace_kind = 0;  // kept rows swept in place (tvdn_stream_chain.hip): 0 no, 1 where their neighbours are kept too, 2 every one (all rows kept)
@@ -116,7 +116,6 @@ struct StreamRun {
     static size_t aligned(size_t b) { return (b + 255) / 256 * 256; }
     // chain(): recon crosses PCIe every pass (round 4's way) instead of being rebuilt from the state at level 0 (tvdn_rebuild.hip)
     bool ships_recon() const { return exact_wrap || a->use_stop || getenv("TVDN_STREAM_SHIP_RECON") != nullptr; }
-    bool drained_pass_kind() const { return periodic || sh != nullptr; }  // pass(): periodic cubes and slabs; chain(): the rest
     int depth_of_pass(int q) const { return a->use_stop ? 1 : n_total / n_pass_plan + (q < n_total % n_pass_plan ? 1 : 0); }
     bool resident(int64_t g) const { return RES > 0 && rm.resident(g); }
     char *host_row(const HostArr &h, int64_t g) const { return h.cube_rows ? h.p + (size_t)g * row_bytes : h.p + (size_t)rm.host_below(g) * row_bytes; }
