@@ -578,3 +578,36 @@ def test_recon_does_not_cross_pcie_between_passes(oracle, monkeypatch, shape, dt
     down_ship = cube * sum(n_out[q] + 1 for q in range(P))
     assert seen[False][:2] == (up_free, down_free), (seen, up_free, down_free)
     assert seen[True][:2] == (up_ship, down_ship), (seen, up_ship, down_ship)
+
+
+@pytest.mark.parametrize("shape,dtype,n_f,n_p,rows,k,bc,resident,devices", [
+    ((40, 4, 8, 16), np.float32, 12, 0, 2, 4, 2, 0, None),       # three chained passes, every row streamed
+    ((40, 4, 8, 16), np.float32, 8, 0, 4, 4, 2, 0, None),        # two drained passes
+    ((40, 4, 8, 16), np.float32, 9, 3, 3, 4, 2, 17, None),       # hybrid schedule, rows kept among streamed ones
+    ((24, 6, 16), np.float64, 9, 0, 2, 3, 0, 0, None),           # periodic: the drained pass with two sets of host state
+    ((40, 4, 8, 16), np.float32, 8, 0, 4, 4, 2, 0, [0, 0, 0]),   # a device list: every slab its own helper thread
+])
+def test_rows_come_down_the_same_whichever_way(oracle, monkeypatch, shape, dtype, n_f, n_p, rows, k, bc, resident, devices):
+    """Downloads by the runtime's copies one at a time from a helper thread (the default, csrc/tvdn_stream_parts.hpp DownPump), by
+    round 4's copy kernel (TVDN_STREAM_DOWN_PUMP=0) and by copies queued behind events (TVDN_STREAM_DOWN_BLOCKS=0): the same bits
+    and the same bytes across PCIe, and the oracle's."""
+    from cytvdn_amd import _lib, synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=31, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    results = []
+    for env in ({}, {"TVDN_STREAM_DOWN_PUMP": "0"}, {"TVDN_STREAM_DOWN_BLOCKS": "0"}):
+        for key in ("TVDN_STREAM_DOWN_PUMP", "TVDN_STREAM_DOWN_BLOCKS"):
+            monkeypatch.delenv(key, raising=False)
+        for key, v in env.items():
+            monkeypatch.setenv(key, v)
+        st = _lib.RunStats()
+        got = _run(x, mu, n_f, n_p, stream=(rows, k), resident=resident, bc=bc, stats=st, devices=devices)
+        results.append((got[0], got[1], st.h2d_bytes, st.d2h_bytes))
+    for r in results[1:]:
+        assert bits_equal(r[0], results[0][0])
+        np.testing.assert_allclose(r[1], results[0][1], rtol=1e-12)
+        assert (r[2], r[3]) == (results[0][2], results[0][3])
+    ref = _oracle_bc(oracle, x, mu, n_f, n_p, bc)
+    assert bits_equal(results[0][0], ref["recon"])
