@@ -156,7 +156,7 @@ int StreamRun::set_up(bool &nothing_to_do)
     KX = (periodic || sh) ? K : 0, NV = N0 + 2 * KX, G0 = KX, G1 = KX + N0;
     own0 = sh ? KX + sh->g0 : G0, own1 = sh ? KX + sh->g1 : G1;  // virtual rows whose results and sums are this run's
     art_lo = periodic || (sh && sh->g0 > 0), art_hi = periodic || (sh && sh->g1 < N0);  // faces that are not the cube's own
-    if (sh) res_req = sh->local_rows ? sh->resident_rows : 0;  // (a device list shares host arrays indexed by cube row: none kept)
+    if (sh) res_req = sh->local_rows ? sh->resident_rows : (sh->keep_rows ? -1 : 0);  // (a rank: what its coordinator sized; a device list: what fits)
     TVDN_HIP(hipSetDevice(device));
 
     // ---- what fits where: rings and boxes first, then as many resident rows as asked for / as fit ---------------------------
@@ -212,7 +212,7 @@ int StreamRun::set_up(bool &nothing_to_do)
     if (sh) {  // a slab keeps none of the rows its neighbours read
         rm.slab_window(sh->g0, sh->g1, art_lo, art_hi, K);
     }
-    if (sh && res_req > 0) {  // a slab of a multi-process run: its coordinator has sized the packed local arrays for exactly this
+    if (sh && sh->local_rows && res_req > 0) {  // a slab of a multi-process run: its coordinator has sized the packed local arrays for exactly this
         TVDN_REQUIRE(!want_mse && res_req <= rm.e1 - rm.e0, "a slab cannot keep %lld rows resident (%lld interior rows; none with an MSE trace)",
                      (long long)res_req, (long long)(rm.e1 - rm.e0));
         const size_t need_b = dev_bytes_max + (size_t)res_req * (size_t)n_store * plane_b;
@@ -225,11 +225,12 @@ int StreamRun::set_up(bool &nothing_to_do)
         // (all of them: decided above)
     } else if (!periodic && !want_mse && res_req != 0) {
         auto fits = [&](double share) -> int64_t {
-            const size_t lim = (size_t)(share * (double)free_b);
+            const size_t lim = (size_t)(share * (double)free_b / (double)(sh ? std::max(1, sh->same_device) : 1));  // (slabs of a device list share their device)
             return lim > dev_bytes_max ? (int64_t)((lim - dev_bytes_max) / ((size_t)n_store * plane_b)) : 0;
         };
-        rm.res = std::min<int64_t>(N0, res_req < 0 ? fits(0.85) : std::min<int64_t>(res_req, fits(0.92)));
-        if (const char *e = getenv("TVDN_STREAM_RESIDENT")) rm.res = std::max<int64_t>(0, std::min<int64_t>({(int64_t)atoll(e), N0, fits(0.92)}));
+        const int64_t may_keep = sh ? std::max<int64_t>(0, rm.e1 - rm.e0) : N0;  // (a slab: none of the rows its neighbours read)
+        rm.res = std::min<int64_t>(may_keep, res_req < 0 ? fits(0.85) : std::min<int64_t>(res_req, fits(0.92)));
+        if (const char *e = getenv("TVDN_STREAM_RESIDENT")) rm.res = std::max<int64_t>(0, std::min<int64_t>({(int64_t)atoll(e), may_keep, fits(0.92)}));
     }
     RES = rm.res, HR = N0 - RES;  // rows in HBM / rows on the host
     if (getenv("TVDN_RUN_TIMING"))
@@ -413,7 +414,7 @@ int StreamRun::set_up(bool &nothing_to_do)
             return;
         }
         // (a slab of a multi-process run: the caller's array holds its OWN rows only, row g at + (g - first own row))
-        const char *data_rows = sh ? sh->own_data - (size_t)sh->g0 * row_bytes : (const char *)a->data;
+        const char *data_rows = !sh ? (const char *)a->data : (sh->local_rows ? sh->own_data - (size_t)sh->g0 * row_bytes : sh->orig);
         const int64_t piece = std::max<int64_t>(1, (int64_t)((size_t(1) << 30) / row_bytes));
         for (int64_t g = 0; g < N0 && RES > 0;) {
             if (!resident(g)) {
@@ -588,7 +589,8 @@ int StreamRun::finish()
         }
         int64_t e = g + 1;
         while (e < N0 && resident(e)) ++e;
-        char *home = sh ? sh->own_recon - (size_t)sh->g0 * row_bytes : (char *)a->recon_out;  // (a slab: the caller's own-row array)
+        // (a rank: the caller's own-row array; a slab of a device list: the set of the shared arrays its last pass wrote)
+        char *home = !sh ? (char *)a->recon_out : (sh->local_rows ? sh->own_recon - (size_t)sh->g0 * row_bytes : (h_old ? sh->recon[1] : sh->recon[0]));
         rc = tvdn_copy_to_host(home + (size_t)g * row_bytes, store_row(1, g), (size_t)(e - g) * row_bytes, device);
         if (rc) return rc;
         g = e;

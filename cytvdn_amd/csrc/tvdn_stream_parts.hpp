@@ -393,6 +393,10 @@ struct SlabShare {
     // between passes and have NO slot in the local arrays (those are packed: local slot of virtual row v = v - local_v0 -
     // resident rows below it); their data term comes from / their result goes to the caller's own-row arrays directly
     int64_t resident_rows = 0;
+    // A slab of a device list (shared arrays indexed by cube row): interior rows may stay in HBM as far as they fit beside the rings
+    // in this slab's share of its device (`same_device` slabs of the list sit on it); their host rows simply go unused.
+    bool keep_rows = false;
+    int same_device = 1;
     const char *own_data = nullptr;
     char *own_recon = nullptr;
     bool exact_wrap = false;                             // Jia-Zhao, first row of the cube not finite (the same on every slab)

@@ -133,7 +133,8 @@ struct StreamRun {
     char *hrow(const HostArr &h, int64_t g, int64_t v) const { return local_rows ? h.p + (size_t)local_slot(v) * row_bytes : host_row(h, g); }
     char *srow(int set, int arr, int64_t g, int64_t v) const
     {
-        return local_rows ? sb[set].flat[(size_t)arr] + (size_t)local_slot(v) * row_bytes : sb[set].row(arr, rm.host_below(g));
+        // (a slab of a device list: the shared arrays are indexed by cube row, kept rows or not)
+        return local_rows ? sb[set].flat[(size_t)arr] + (size_t)local_slot(v) * row_bytes : sb[set].row(arr, sh ? g : rm.host_below(g));
     }
     int sse_row(const char *x, const char *y, int slot, int64_t g)
     {

@@ -140,6 +140,11 @@ int run_streamed_slabs(const tvdn_run_args *a, int64_t R, int64_t K)
         x.phase_iters = &phases[(size_t)2 * r];
         x.stats = &stats[(size_t)r];
         x.stream_resident = 0;
+        // interior rows of a slab stay in HBM between the passes as far as they fit its share of its device (none with an MSE trace,
+        // periodic boundaries, or when told not to: stream_resident == 0)
+        sh.keep_rows = a->stream_resident != 0 && !want_mse && !periodic;
+        sh.same_device = 0;
+        for (int q = 0; q < world; ++q) sh.same_device += a->devices[q] == a->devices[r] ? 1 : 0;
         if (r != 0) x.progress = nullptr;
     }
     const auto t_threads = std::chrono::steady_clock::now();
@@ -195,6 +200,7 @@ int run_streamed_slabs(const tvdn_run_args *a, int64_t R, int64_t K)
         for (int r = 0; r < world; ++r) {
             o.h2d_bytes += stats[(size_t)r].h2d_bytes;
             o.d2h_bytes += stats[(size_t)r].d2h_bytes;
+            o.resident_rows += stats[(size_t)r].resident_rows;  // (interior rows the slabs kept in HBM between the passes)
         }
         o.setup_s = std::chrono::duration<double>(t_threads - t_start).count();
         o.loop_s = std::chrono::duration<double>(t_done - t_threads).count();

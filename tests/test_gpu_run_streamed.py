@@ -611,3 +611,37 @@ def test_rows_come_down_the_same_whichever_way(oracle, monkeypatch, shape, dtype
         assert (r[2], r[3]) == (results[0][2], results[0][3])
     ref = _oracle_bc(oracle, x, mu, n_f, n_p, bc)
     assert bits_equal(results[0][0], ref["recon"])
+
+
+@pytest.mark.parametrize("shape,dtype,n_f,n_p,rows,k,slabs,stop,bad", [
+    ((40, 4, 8, 16), np.float32, 9, 0, 3, 3, 2, None, False),     # two slabs of 20 rows: 17 + 17 interior rows may be kept
+    ((40, 4, 8, 16), np.float32, 7, 6, 2, 4, 3, None, False),     # hybrid schedule over four passes, three slabs
+    ((41, 6, 16), np.float64, 0, 9, 4, 3, 2, None, False),        # unaccelerated, 3-D, f64
+    ((40, 4, 8, 16), np.float32, 8, 0, 3, 2, 4, None, True),      # a non-finite first row: the exact wrap's planes handed between the slabs
+    ((30, 3, 5, 7), np.float32, 0, 40, 4, 6, 3, 0.02, False),     # the global stopping rule: one level per pass
+])
+def test_streamed_device_list_keeps_interior_rows(oracle, shape, dtype, n_f, n_p, rows, k, slabs, stop, bad):
+    """Slabs of a streamed device list keep their interior rows -- none of the k a neighbour reads at a shared face -- in HBM between
+    the passes, as far as they fit their share of their device (stream_resident != 0); the shared host arrays stay indexed by cube
+    row, the kept rows' slots simply go unused.  The oracle's bits, fewer bytes across PCIe than with every row streamed."""
+    from cytvdn_amd import _lib, synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=43, dtype=dt) + dt.type(0.25)
+    if bad:
+        x[0, 1, 2, 3] = np.inf
+    mu = np.array([1.0, 0.8, 0.5, 0.6][:nd], dt)
+    n = n_f + n_p
+    st, st0 = _lib.RunStats(), _lib.RunStats()
+    got = _run(x, mu, n_f, n_p, stop=stop, stream=(rows, k), devices=[0] * slabs, resident=-1, stats=st)
+    none = _run(x, mu, n_f, n_p, stop=stop, stream=(rows, k), devices=[0] * slabs, resident=0, stats=st0)
+    ref = _oracle(oracle, x, mu, n_f, n_p, **({"stopping_relative_change": stop} if stop is not None else {}))
+    assert bits_equal(got[0], ref["recon"]) and bits_equal(none[0], ref["recon"])
+    depth = 1 if stop is not None else k
+    interior = sum(max(0, (r + 1) * shape[0] // slabs - r * shape[0] // slabs - (depth if r > 0 else 0) - (depth if r < slabs - 1 else 0))
+                   for r in range(slabs))
+    assert st.engine == 1 and st.resident_rows == interior > 0 and st0.resident_rows == 0
+    assert st.h2d_bytes < st0.h2d_bytes and st.d2h_bytes < st0.d2h_bytes
+    if stop is None and not bad:
+        assert got[3] == n
+        _check_traces(got[1], ref, n)
