@@ -33,8 +33,10 @@ At N = 1 the line also carries
                 edges, edge rows first, halo rows refreshed by device copies of the size of the RCCL messages) = the per-GPU term
                 of the weak-scaling curve; and the API level, PCIe included (never `value`): cytvdn_amd.denoise4D NumPy -> NumPy
                 at 50 and 200 iterations, and tvdn_run streamed from page-locked host memory (tvdn_run_stats: passes-only rate,
-                h2d / d2h GB/s, set-up and whole-call seconds) -- half a rank slab of BASELINE configs[4] with the library's
-                plan (rows resident in HBM) and with every row streamed, and the config-2 cube from host-resident state
+                h2d / d2h GB/s, set-up and whole-call seconds, kept_in_place) -- half a rank slab of BASELINE configs[4] with the
+                library's plan (every row kept in HBM and swept in place) and with every row streamed, the config-2 cube from
+                host-resident state, and a cube BEYOND the resident engine (88 rows of 256 MiB planes: 330 GiB as resident state)
+                that the streamed engine keeps in HBM as ten arrays and a few rings
   cpu_baseline  the reference's OWN compiled kernels (oracle/_ref: its shipped C built by oracle/Makefile in the build container,
                 travelling as binaries; kind "reference") called in the reference's order on the host cores of the same box, on
                 config 2 itself when the host has the memory for it, in a CHILD process (the thread binding SURVEY 8d asks of
