@@ -35,6 +35,7 @@
 // tvdn_mem_alloc / tvdn_mem_free export the same thing (cytvdn_amd/engine.py puts a slab's state on it).
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <mutex>
 #include <random>
 #include <thread>
@@ -146,6 +147,7 @@ hipError_t vmm_alloc(void **p, size_t bytes, int device, double spread_budget_s,
         return e != hipSuccess ? e : hipErrorOutOfMemory;
     }
     (void)hipGetLastError();  // a refusal among the extras only ends the pool
+    const double t_created = since();
     // a random subset in random order (a fixed sequence per process: runs repeat)
     static std::mt19937_64 rng(0x7476646eULL);
     {
@@ -166,11 +168,13 @@ hipError_t vmm_alloc(void **p, size_t bytes, int device, double spread_budget_s,
         release_block(b, 0);
         return e;
     }
+    const double t_reserved = since();
     size_t mapped = 0;
     for (size_t i = 0; i < need && e == hipSuccess; ++i) {
         e = hipMemMap(b.va + i * G, G, 0, b.handles[i], 0);
         if (e == hipSuccess) ++mapped;
     }
+    const double t_mapped = since();
     if (e == hipSuccess) {
         hipMemAccessDesc acc;
         std::memset(&acc, 0, sizeof acc);
@@ -184,7 +188,11 @@ hipError_t vmm_alloc(void **p, size_t bytes, int device, double spread_budget_s,
         tlb_flush();
         return e;
     }
+    const double t_access = since();
     tlb_flush();
+    if (getenv("TVDN_RUN_TIMING"))
+        fprintf(stderr, "tvdn_devmem: %zu granules of %zu MiB (pool %zu): created %.3f s, extras released + range reserved %.3f s, mapped %.3f s, access set %.3f s, flush %.3f s\n",
+                need, G / kMiB, pool_size, t_created, t_reserved - t_created, t_mapped - t_reserved, t_access - t_mapped, since() - t_access);
     if (info) {
         info->granule_bytes = (int64_t)G;
         info->granules = (int32_t)need;
