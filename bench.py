@@ -750,7 +750,8 @@ def main():
         try:
             big = (88, 1024, 256, 256)
             if mem_available_gib() >= 60.0:
-                _lib.lib().tvdn_release_cache()
+                # (the device block the last entry kept is re-dealt at this run's size: the granules it has stay, the few
+                #  missing ones are created -- csrc/tvdn_devmem.hip dev_resize)
                 torch.cuda.empty_cache()
                 api.append(api_streamed(big, -1, -1, 80, "88x1024x256x256 (22 GiB per array: 330 GiB of resident state, more than the HBM) with "
                                                          "the library's own plan: every row kept in HBM (10 arrays + rings), swept in place",

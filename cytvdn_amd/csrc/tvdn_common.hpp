@@ -243,6 +243,7 @@ struct DevAllocInfo {  // what a block of granules was made from (all zero for a
 };
 hipError_t dev_alloc(void **p, size_t bytes, int device, int *kind, double spread_budget_s = 0.25, DevAllocInfo *info = nullptr);
 hipError_t dev_free(void *p);
+hipError_t dev_resize(void **p, size_t bytes, int device);  // a block on granules, re-dealt at another size (contents undefined); hipErrorNotSupported: free and allocate
 int dev_kind(const void *p);
 // Entry points that select a device put the calling thread's current device back before they return: a library that leaves
 // hipSetDevice(3) behind changes where the caller's next allocation (torch's, say) lands.

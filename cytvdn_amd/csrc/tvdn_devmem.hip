@@ -106,13 +106,54 @@ double env_double(const char *name, double dflt)
     return end == e ? dflt : v;
 }
 
+size_t granule_for(size_t bytes)
+{
+    size_t G = 1024 * kMiB;
+    while (G > 64 * kMiB && G > bytes / 8) G /= 2;
+    return env_mib("TVDN_GRANULE_MIB", G / kMiB) * kMiB;
+}
+
+// the granules of `b`, dealt out in a fresh random order, as one range the device may read and write
+hipError_t map_block(VmmBlock &b, size_t G, int device)
+{
+    {
+        static std::mt19937_64 rng(0x7476646eULL);  // a fixed sequence per process: runs repeat
+        std::lock_guard<std::mutex> lk(g_mu);
+        std::shuffle(b.handles.begin(), b.handles.end(), rng);
+    }
+    const size_t need = b.handles.size();
+    b.device = device;
+    b.sizes.assign(need, G);
+    b.va_bytes = need * G;
+    hipError_t e = hipMemAddressReserve((void **)&b.va, b.va_bytes, G, nullptr, 0);
+    if (e != hipSuccess) {
+        b.va = nullptr;
+        release_block(b, 0);
+        return e;
+    }
+    size_t mapped = 0;
+    for (size_t i = 0; i < need && e == hipSuccess; ++i) {
+        e = hipMemMap(b.va + i * G, G, 0, b.handles[i], 0);
+        if (e == hipSuccess) ++mapped;
+    }
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc;
+        std::memset(&acc, 0, sizeof acc);
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = device;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(b.va, b.va_bytes, &acc, 1);
+    }
+    if (e != hipSuccess) release_block(b, mapped);
+    tlb_flush();
+    return e;
+}
+
 hipError_t vmm_alloc(void **p, size_t bytes, int device, double spread_budget_s, DevAllocInfo *info)
 {
     const auto t0 = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-    size_t G = 1024 * kMiB;
-    while (G > 64 * kMiB && G > bytes / 8) G /= 2;
-    G = env_mib("TVDN_GRANULE_MIB", G / kMiB) * kMiB;
+    const size_t G = granule_for(bytes);
     hipMemAllocationProp prop;
     std::memset(&prop, 0, sizeof prop);
     prop.type = hipMemAllocationTypePinned;
@@ -148,9 +189,9 @@ hipError_t vmm_alloc(void **p, size_t bytes, int device, double spread_budget_s,
     }
     (void)hipGetLastError();  // a refusal among the extras only ends the pool
     const double t_created = since();
-    // a random subset in random order (a fixed sequence per process: runs repeat)
-    static std::mt19937_64 rng(0x7476646eULL);
+    // a random subset in random order: shuffle, keep the first `need`, give the rest back, deal the kept ones out again
     {
+        static std::mt19937_64 rng(0x9e3779b97f4a7c15ULL);
         std::lock_guard<std::mutex> lk(g_mu);
         std::shuffle(pool.begin(), pool.end(), rng);
     }
@@ -158,41 +199,12 @@ hipError_t vmm_alloc(void **p, size_t bytes, int device, double spread_budget_s,
     const size_t pool_size = pool.size();
     pool.resize(need);
     VmmBlock b;
-    b.device = device;
     b.handles = std::move(pool);
-    b.sizes.assign(need, G);
-    b.va_bytes = need * G;
-    e = hipMemAddressReserve((void **)&b.va, b.va_bytes, G, nullptr, 0);
-    if (e != hipSuccess) {
-        b.va = nullptr;
-        release_block(b, 0);
-        return e;
-    }
-    const double t_reserved = since();
-    size_t mapped = 0;
-    for (size_t i = 0; i < need && e == hipSuccess; ++i) {
-        e = hipMemMap(b.va + i * G, G, 0, b.handles[i], 0);
-        if (e == hipSuccess) ++mapped;
-    }
-    const double t_mapped = since();
-    if (e == hipSuccess) {
-        hipMemAccessDesc acc;
-        std::memset(&acc, 0, sizeof acc);
-        acc.location.type = hipMemLocationTypeDevice;
-        acc.location.id = device;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        e = hipMemSetAccess(b.va, b.va_bytes, &acc, 1);
-    }
-    if (e != hipSuccess) {
-        release_block(b, mapped);
-        tlb_flush();
-        return e;
-    }
-    const double t_access = since();
-    tlb_flush();
+    e = map_block(b, G, device);
+    if (e != hipSuccess) return e;
     if (getenv("TVDN_RUN_TIMING"))
-        fprintf(stderr, "tvdn_devmem: %zu granules of %zu MiB (pool %zu): created %.3f s, extras released + range reserved %.3f s, mapped %.3f s, access set %.3f s, flush %.3f s\n",
-                need, G / kMiB, pool_size, t_created, t_reserved - t_created, t_mapped - t_reserved, t_access - t_mapped, since() - t_access);
+        fprintf(stderr, "tvdn_devmem: %zu granules of %zu MiB (pool %zu): created in %.3f s, dealt out and mapped in %.3f s\n", need, G / kMiB, pool_size, t_created,
+                since() - t_created);
     if (info) {
         info->granule_bytes = (int64_t)G;
         info->granules = (int32_t)need;
@@ -225,6 +237,61 @@ hipError_t dev_alloc(void **p, size_t bytes, int device, int *kind, double sprea
         if (g_vmm_state[device] == 0) g_vmm_state[device] = -1;  // a runtime without virtual-memory management: plain blocks from now on
     }
     return hipMalloc(p, bytes);
+}
+
+// A block on granules changes size instead of being freed and allocated anew (contents undefined afterwards): the granules it
+// has stay -- creating 236 of them takes 2.7 s on a fresh device and 5-7 s behind a big release, mapping them 4 ms --, missing ones
+// are created, surplus ones given back, all dealt out in a new random order.  hipErrorNotSupported: not such a block (or the new
+// size wants another granule size, or plain memory): the caller frees and allocates.
+hipError_t dev_resize(void **p, size_t bytes, int device)
+{
+    if (!p || !*p || !vmm_wanted(bytes, device)) return hipErrorNotSupported;
+    VmmBlock b;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_blocks.find(*p);
+        if (it == g_blocks.end() || it->second.device != device || it->second.sizes.empty() || it->second.sizes[0] != granule_for(bytes)) return hipErrorNotSupported;
+        b = std::move(it->second);
+        g_blocks.erase(it);
+    }
+    const size_t G = b.sizes[0], need = (bytes + G - 1) / G;
+    (void)hipDeviceSynchronize();  // nothing in flight may still touch the range when it is unmapped
+    size_t off = 0;
+    for (size_t i = 0; i < b.handles.size(); ++i, off += G) (void)hipMemUnmap(b.va + off, G);
+    if (b.va) (void)hipMemAddressFree(b.va, b.va_bytes);
+    b.va = nullptr;
+    (void)hipGetLastError();
+    hipMemAllocationProp prop;
+    std::memset(&prop, 0, sizeof prop);
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    hipError_t e = hipSuccess;
+    while (b.handles.size() < need && e == hipSuccess) {
+        hipMemGenericAllocationHandle_t h;
+        e = hipMemCreate(&h, G, &prop, 0);
+        if (e == hipSuccess) b.handles.push_back(h);
+    }
+    if (e != hipSuccess) {  // not enough memory for the larger block: everything goes back
+        for (auto h : b.handles) (void)hipMemRelease(h);
+        (void)hipGetLastError();
+        tlb_flush();
+        *p = nullptr;
+        return e;
+    }
+    while (b.handles.size() > need) {
+        (void)hipMemRelease(b.handles.back());
+        b.handles.pop_back();
+    }
+    e = map_block(b, G, device);
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return e;
+    }
+    *p = b.va;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_blocks.emplace((void *)b.va, std::move(b));
+    return hipSuccess;
 }
 
 hipError_t dev_free(void *p)

@@ -195,3 +195,36 @@ def test_streamed_run_on_granules(oracle, monkeypatch):
         assert stats.engine == 1 and stats.state_mem == want
     _lib.lib().tvdn_release_cache()
     _lib.lib().tvdn_wait_background()
+
+
+def test_a_kept_block_changes_size_with_the_granules_it_has(oracle, monkeypatch):
+    """Runs of different sizes one after the other in one process: the kept block of the last run is not freed and allocated anew
+    but re-dealt at the new size from the granules it has (tvdn_devmem.hip dev_resize: missing ones created, surplus ones given
+    back, a new random order, fresh translations) -- growing, shrinking, growing again, resident and streamed, each the oracle's bits."""
+    import torch
+    from cytvdn_amd import _lib, synth
+    monkeypatch.setenv("TVDN_GRANULE_MIB", "2")        # small cubes on many granules
+    monkeypatch.setenv("TVDN_VMM_MIN_MIB", "1")
+    monkeypatch.setenv("TVDN_VMM", "1")
+    _lib.lib().tvdn_release_cache()
+    mu = np.array([1.0, 0.8, 0.5, 0.6], np.float32)
+    free0 = torch.cuda.mem_get_info(0)[0]
+    kept_before = None
+    for rows, stream in ((10, None), (22, None), (6, None), (30, (3, 3)), (12, None), (40, None)):
+        shape = (rows, 6, 16, 32)
+        x = synth.cube(shape, seed=rows, dtype=np.float32) + np.float32(0.25)
+        ref = oracle.denoise(x, mu, 5, True)
+        recon, sums, stats = np.empty_like(x), np.zeros((5, 3)), _lib.RunStats()
+        a = _run_args(x, mu, 5, 0, recon, sums, stats)
+        if stream:
+            a.stream_rows, a.stream_k, a.stream_resident = stream[0], stream[1], 0
+        _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+        assert bits_equal(recon, ref["recon"]), (rows, stream)
+        assert stats.state_mem == _lib.MEM_GRANULES
+        kept = _lib.state_kept_bytes(0)
+        assert kept > 0 and kept != kept_before           # a block of THIS run's size is what is kept now
+        kept_before = kept
+    _lib.lib().tvdn_release_cache()
+    assert _lib.state_kept_bytes(0) == 0
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(0)[0] >= free0 - (64 << 20)      # every granule went back
