@@ -177,8 +177,9 @@ hipError_t vmm_alloc(void **p, size_t bytes, int device, double spread_budget_s,
     // Twice the block is what a random subset needs to be reliably fast (subsets of a pool of the block's own size: up to 11.72 ms for
     // config 2, of 1.25 x: up to 11.57, of 2 x and more: <= 11.25; profiles/r05_vmm_spread_*.jsonl).  A caller that gives the extras a
     // second or more -- a state someone keeps -- gets that much whatever it takes, within four times its budget (creating a
-    // granule takes ~18 ms when the driver has to clear the memory first: a fresh box built a pool of 1.1 x in 1.5 s once, and the
-    // bench line on it read 91.2 instead of 94.2-95.8).
+    // granule takes ~18 ms when the driver has to clear the memory first, so a fresh box can spend its 1.5 s on little more than
+    // the block itself; one bench line of a fresh box read 91.2 -- 11.76 ms per sweep -- where the twenty others of the round read
+    // 94.2-95.8: it left no record of its pool, but a pool cut short is the one known way to such a time).
     const size_t floor_pool = budget >= 1.0 ? std::min(want, 2 * need) : need;
     while (pool.size() < want) {
         if (pool.size() >= need && since() - t_need > budget && (pool.size() >= floor_pool || since() - t_need > 4.0 * budget)) break;  // the extras have had their time
