@@ -406,6 +406,8 @@ int StreamRun::set_up(bool &nothing_to_do)
     }
     for (int h = 0; h < 2; ++h)
         if ((rc = evs.make(&in_ready[h])) || (rc = evs.make(&in_free[h])) || (rc = evs.make(&out_ready[h])) || (rc = evs.make(&out_free[h]))) return rc;
+    for (hipEvent_t &e : pump_ready)
+        if ((rc = evs.make(&e))) return rc;
 
     stager = std::thread([this] {  // resident rows of the data term: pageable `data` -> store, through the library's pinned lanes
         if (sh && RES <= 0) {

@@ -482,7 +482,7 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
             DownPump::Job job;
             if (pump) {
                 job.id = t;
-                if ((rc2 = evs.make(&job.ready))) return rc2;
+                job.ready = pump_ready[t & 3];  // (the job of chunk t - 4 is long done: the box of chunk t - 2 has been waited for)
                 TVDN_HIP(hipEventRecord(job.ready, st.main));
             } else {
                 TVDN_HIP(hipEventRecord(out_ready[h], st.main));

@@ -263,7 +263,7 @@ int StreamRun::pass(const double *ratios /* kk entries, NAN = unaccelerated */, 
                 DownPump::Job job;
                 if (pump) {
                     job.id = c;
-                    if ((rc2 = evs.make(&job.ready))) return rc2;
+                    job.ready = pump_ready[c & 3];  // (the job of chunk c - 4 is long done: the box of chunk c - 2 has been waited for)
                     TVDN_HIP(hipEventRecord(job.ready, st.main));
                 } else {
                     TVDN_HIP(hipEventRecord(out_ready[h], st.main));

@@ -102,6 +102,7 @@ struct StreamRun {
     int64_t bytes_up = 0, bytes_down = 0, n_passes = 0;  // across PCIe (tvdn_run_stats)
     std::vector<void *> cdst, csrc;
     int down_blocks = 0;
+    hipEvent_t pump_ready[4] = {nullptr, nullptr, nullptr, nullptr};  // "this chunk's rows are gathered", by chunk index mod 4 (two jobs are in flight at most)
     bool down_pump = false;  // downloads by the runtime's copies, one at a time from a helper thread (DownPump, tvdn_stream_parts.hpp)
     bool recon_direct = false, recon_direct_decided = false;  // the last pass sends the resident rows' results home itself
     bool lean_layout = false;  // every row kept, rings for the levels 1 .. K-1 only, no boxes (tvdn_stream.hip set_up)
