@@ -31,7 +31,9 @@ EXPORTS = (
     "tvdn_synth_fill", "tvdn_run", "tvdn_pipeline_plan", "tvdn_run_workspace_bytes", "tvdn_release_cache", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many", "tvdn_plan", "tvdn_copy_many", "tvdn_stream_mix", "tvdn_stream_mix_march",
     "tvdn_stream_host_need", "tvdn_stream_plan", "tvdn_wait_background", "tvdn_slab_host_need", "tvdn_slab_row_map", "tvdn_fista_ratios", "tvdn_iter_mode", "tvdn_roles_bind", "tvdn_roles_advance",
     "tvdn_mem_alloc", "tvdn_mem_free", "tvdn_state_kept_bytes", "tvdn_recon_from_state",
+    "tvdn_mem_alloc_shared", "tvdn_mem_status", "tvdn_mem_selftest",
 )
+CANARY_NOT_RUN, CANARY_PASSED, CANARY_STALE, CANARY_FAILED = 0, 1, -1, -2
 MEM_PLAIN, MEM_GRANULES, MEM_CALLER = 0, 1, 2
 
 
@@ -73,19 +75,31 @@ class PlanOut(C.Structure):
 
 
 class RunStats(C.Structure):
-    """struct tvdn_run_stats (include/tvdn.h, ABI 8)."""
+    """struct tvdn_run_stats (include/tvdn.h, ABI 9)."""
     _fields_ = [
         ("engine", C.c_int32), ("pipelined", C.c_int32), ("stream_rows", C.c_int32), ("stream_k", C.c_int32),
         ("resident_rows", C.c_int64), ("n_passes", C.c_int64), ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64),
         ("setup_s", C.c_double), ("loop_s", C.c_double), ("total_s", C.c_double),
         ("audition_n", C.c_int32), ("audition_kept", C.c_int32), ("audition_ms", C.c_double * 8),
         ("first_pass_s", C.c_double), ("first_pass_iters", C.c_int32), ("results_under_last_pass", C.c_int32),
-        ("state_mem", C.c_int32), ("kept_in_place", C.c_int32),
+        ("state_mem", C.c_int32), ("kept_in_place", C.c_int32), ("peer_check", C.c_int32), ("first_call", C.c_int32),
     ]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "audition_ms"}
         d["audition_ms"] = [round(v, 4) for v in self.audition_ms[:max(0, min(8, self.audition_n))]]
+        return d
+
+
+class MemStatus(C.Structure):
+    """struct tvdn_mem_status_out (include/tvdn.h, ABI 9): what the allocator of device blocks knows about a device."""
+    _fields_ = [("vmm_state", C.c_int32), ("canary", C.c_int32), ("canary_runs", C.c_int32), ("faults", C.c_int32),
+                ("flushes", C.c_int64), ("blocks", C.c_int64), ("granules", C.c_int64), ("bytes", C.c_int64),
+                ("last_granules", C.c_int32), ("last_pool", C.c_int32), ("first_fault", C.c_char * 200)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["first_fault"] = self.first_fault.decode("utf-8", "replace")
         return d
 
 
@@ -192,11 +206,14 @@ def lib():
                                         C.POINTER(C.c_double), C.c_double, C.c_int64, C.c_int64, C.c_void_p]
     L.tvdn_mem_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int, C.POINTER(C.c_int32)]
     L.tvdn_mem_free.argtypes = [C.c_void_p]
+    L.tvdn_mem_alloc_shared.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]
+    L.tvdn_mem_status.argtypes = [C.c_int, C.POINTER(MemStatus)]
+    L.tvdn_mem_selftest.argtypes = [C.c_int]
     L.tvdn_state_kept_bytes.argtypes = [C.c_int]
     L.tvdn_state_kept_bytes.restype = C.c_int64
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header and library out of step
-    if L.tvdn_abi_version() != 8:
+    if L.tvdn_abi_version() != 9:
         raise TvdnError("libtvdn_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -283,9 +300,11 @@ class DeviceBlock:
     does not -- csrc/tvdn_devmem.hip).  `tensor(dtype)` views it as a 1-D torch tensor (no copy, no
     ownership: the block lives as long as this object, which the tensor's users must keep)."""
 
-    def __init__(self, nbytes: int, device: int):
+    def __init__(self, nbytes: int, device: int, peers=()):
+        """`peers`: other devices that read and write the block (tvdn_mem_alloc_shared: one access descriptor per device)."""
         p, k = C.c_void_p(), C.c_int32()
-        check(lib().tvdn_mem_alloc(C.byref(p), int(nbytes), int(device), C.byref(k)))
+        pl = (C.c_int32 * max(1, len(peers)))(*[int(d) for d in peers])
+        check(lib().tvdn_mem_alloc_shared(C.byref(p), int(nbytes), int(device), pl, len(peers), C.byref(k)))
         self.ptr, self.nbytes, self.device, self.kind = int(p.value), int(nbytes), int(device), int(k.value)
 
     def tensor(self, dtype: "torch.dtype"):
@@ -310,6 +329,21 @@ class DeviceBlock:
             self.free()
         except Exception:
             pass
+
+
+def mem_status(device: int = 0) -> dict:
+    """The allocator's view of `device` (tvdn_mem_status): whether big blocks come from granules (vmm_state 1) or plain
+    hipMalloc (-1: TVDN_VMM=0, refused by the runtime, or the remap canary tripped), the canary's verdict, the HIP calls of the
+    allocator that failed so far (`faults`, `first_fault`), and the granule blocks alive."""
+    st = MemStatus()
+    check(lib().tvdn_mem_status(int(device), C.byref(st)))
+    return st.as_dict()
+
+
+def mem_selftest(device: int = 0) -> bool:
+    """Run the remap canary on `device` now (tvdn_mem_selftest); False when it tripped or could not run -- the device then
+    serves plain blocks for the rest of the process and tvdn_last_error() says what was seen."""
+    return lib().tvdn_mem_selftest(int(device)) == 0
 
 
 def state_kept_bytes(device: int) -> int:

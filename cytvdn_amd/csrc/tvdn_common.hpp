@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -34,6 +35,24 @@ void set_error(const char *fmt, ...);
             return TVDN_ERR_INVALID;           \
         }                                      \
     } while (0)
+
+// "64G" / "512M" / plain bytes from the environment; 0 = not set (TVDN_HBM_LIMIT, TVDN_HOST_LIMIT, ...)
+inline size_t env_bytes(const char *name)
+{
+    const char *e = getenv(name);
+    if (!e) return 0;
+    char *end = nullptr;
+    double v = strtod(e, &end);
+    if (end == e || v <= 0) return 0;
+    switch (*end) {
+    case 'K': case 'k': v *= 1024.0; break;
+    case 'M': case 'm': v *= 1024.0 * 1024.0; break;
+    case 'G': case 'g': v *= 1024.0 * 1024.0 * 1024.0; break;
+    case 'T': case 't': v *= 1024.0 * 1024.0 * 1024.0 * 1024.0; break;
+    default: break;
+    }
+    return (size_t)v;
+}
 
 // ---- canonical 4-D geometry ------------------------------------------------------------------
 // A 3-D reference array (N0,N1,N2) is handled as (N0,1,N1,N2): the marching axis M stays the
@@ -233,7 +252,7 @@ hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, 
 void state_release(void *p, size_t bytes, int device);
 size_t state_kept_bytes(int device);  // counts as free: the next run takes it over or releases it
 // the state's allocation itself (granules unless told otherwise: tvdn_devmem.hip), and the shape of a resident run's pipelined transfers
-hipError_t state_malloc(void **p, size_t bytes, int device, bool granules = true, double spread_budget_s = 0.25);
+hipError_t state_malloc(void **p, size_t bytes, int device, bool granules = true, double spread_budget_s = 0.25, const int *peers = nullptr, int n_peers = 0);
 void pipeline_plan(int64_t n0, int64_t n_total, int64_t cube_bytes, int32_t out[3]);
 // tvdn_devmem.hip: device memory composed from physical granules (big blocks) or plain hipMalloc; dev_free takes either
 struct DevAllocInfo {  // what a block of granules was made from (all zero for a plain block)
@@ -241,9 +260,11 @@ struct DevAllocInfo {  // what a block of granules was made from (all zero for a
     int32_t granules, pool;  // granules mapped / created to choose them from
     double seconds;
 };
-hipError_t dev_alloc(void **p, size_t bytes, int device, int *kind, double spread_budget_s = 0.25, DevAllocInfo *info = nullptr);
-hipError_t dev_free(void *p);
-hipError_t dev_resize(void **p, size_t bytes, int device);  // a block on granules, re-dealt at another size (contents undefined); hipErrorNotSupported: free and allocate
+hipError_t dev_alloc(void **p, size_t bytes, int device, int *kind, double spread_budget_s = 0.25, DevAllocInfo *info = nullptr, const int *peers = nullptr,
+                     int n_peers = 0);
+hipError_t dev_free(void *p);  // the first error of the release, if any (everything is attempted whatever fails; stderr says which call)
+// a block on granules, re-dealt at another size (contents undefined); hipErrorNotSupported: free and allocate
+hipError_t dev_resize(void **p, size_t bytes, int device, double spread_budget_s = 0.25);
 int dev_kind(const void *p);
 // Entry points that select a device put the calling thread's current device back before they return: a library that leaves
 // hipSetDevice(3) behind changes where the caller's next allocation (torch's, say) lands.

@@ -103,6 +103,53 @@ struct RunClock {
     }
 };
 
+// Several slabs whose blocks are made of granules: does a peer copy out of such a block arrive intact?  For every slab and
+// each neighbour whose rows it will pull: a pattern goes into the neighbour's block where its outermost own row of recon[1]
+// lies (the runtime's host-to-device copy), is pulled across with the run's own call (hipMemcpyPeerAsync on the copy stream)
+// into this slab's halo row, and read back (device-to-host).  64 KiB per pair, at the END of the row -- in a block of several
+// granules that is as far from the block's first granule as the rows a run moves.  Leaves the touched bytes zero.
+static bool slab_peer_copy_check(Slab *sl, int world, size_t row_bytes, int nd, int per_axis, char *why, size_t why_len)
+{
+    const size_t n = std::min<size_t>(row_bytes, 65536);
+    std::vector<unsigned char> pat(n), got(n);
+    auto fail = [&](const char *what, hipError_t e, int r, int d) {
+        (void)hipGetLastError();
+        snprintf(why, why_len, "%s, slab %d (device %d) <- slab %d (device %d): %s", what, r, sl[r].device, d, sl[d].device, e == hipSuccess ? "bytes differ" : hipGetErrorString(e));
+        return false;
+    };
+    for (int r = 0; r < world; ++r) {
+        Slab &s = sl[r];
+        const size_t s_stride = ((size_t)s.rows() * row_bytes + 255) / 256 * 256 + 4096;
+        char *s_recon1 = (char *)s.state.p + s_stride * (size_t)(nd * per_axis);  // Slab::assign: recon[1] follows the rotating arrays
+        for (int side = 0; side < 2; ++side) {
+            if (side == 0 ? !s.halo_lo : !s.halo_hi) continue;
+            const int d = side == 0 ? (r + world - 1) % world : (r + 1) % world;
+            Slab &o = sl[d];
+            const size_t o_stride = ((size_t)o.rows() * row_bytes + 255) / 256 * 256 + 4096;
+            char *o_recon1 = (char *)o.state.p + o_stride * (size_t)(nd * per_axis);
+            char *src = o_recon1 + (size_t)(side == 0 ? o.row_hi() - 1 : o.row_lo()) * row_bytes + (row_bytes - n);
+            char *dst = s_recon1 + (size_t)(side == 0 ? s.row_lo() - 1 : s.row_hi()) * row_bytes + (row_bytes - n);
+            for (size_t i = 0; i < n; ++i) pat[i] = (unsigned char)(0x5b + 131 * i + 17 * r + 3 * side);
+            hipError_t e = hipSetDevice(o.device);
+            if (e == hipSuccess) e = hipMemcpy(src, pat.data(), n, hipMemcpyHostToDevice);
+            if (e != hipSuccess) return fail("writing the pattern", e, r, d);
+            e = hipSetDevice(s.device);
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(dst, s.device, src, o.device, n, s.copy);
+            if (e == hipSuccess) e = hipStreamSynchronize(s.copy);
+            if (e != hipSuccess) return fail("the peer copy", e, r, d);
+            std::fill(got.begin(), got.end(), 0);
+            e = hipMemcpy(got.data(), dst, n, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return fail("reading the copy back", e, r, d);
+            if (got != pat) return fail("the peer copy", hipSuccess, r, d);
+            e = hipMemset(dst, 0, n);
+            if (e == hipSuccess) e = hipSetDevice(o.device);
+            if (e == hipSuccess) e = hipMemset(src, 0, n);
+            if (e != hipSuccess) return fail("clearing the pattern", e, r, d);
+        }
+    }
+    return true;
+}
+
 static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats)
 {
     const auto t_entry = std::chrono::steady_clock::now();
@@ -177,21 +224,75 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
             }
             s.state.p = a->workspace;
             s.state.owned = false;
-        } else {
+        } else if (world == 1) {
             // one slab: the block the last run of this device left behind, if it fits (StateCache above)
-            if (world == 1) {
-                // what a well-placed state is worth: 5 % of the time the run's sweeps will take (at 5.5 TB/s), at least 0.25 s
-                const double sweeps_s = (double)n_total * (double)(stride * (size_t)n_arr) / 5.5e12;
-                TVDN_HIP(state_acquire(&s.state.p, stride * (size_t)n_arr, &s.state.bytes, s.device, &state_reused, false, std::max(0.25, 0.05 * sweeps_s)));
-                s.state.keep = true;
-            } else {
-                // several slabs: granules when they all share one device (logical slabs), a plain block when neighbours on
-                // other devices pull rows out of it peer to peer
-                bool one_device = true;
-                for (int q = 0; q < world; ++q) one_device = one_device && (a->n_devices == 0 || a->devices[q] == a->devices[0]);
-                TVDN_HIP(state_malloc(&s.state.p, stride * (size_t)n_arr, s.device, one_device));
-            }
+            // what a well-placed state is worth: 5 % of the time the run's sweeps will take (at 5.5 TB/s), at least 0.25 s
+            const double sweeps_s = (double)n_total * (double)(stride * (size_t)n_arr) / 5.5e12;
+            TVDN_HIP(state_acquire(&s.state.p, stride * (size_t)n_arr, &s.state.bytes, s.device, &state_reused, false, std::max(0.25, 0.05 * sweeps_s)));
+            s.state.keep = true;
+            stats.first_call = state_reused ? 0 : 1;
         }
+    }
+    // several slabs: every state on granules (tvdn_devmem.hip) -- also where neighbours on OTHER devices pull rows out of it
+    // peer to peer: such a block grants every device of the list access (one descriptor each; since ABI 9).  That path has
+    // not met a second GPU yet, so it proves itself before it is used: a row-sized peer copy out of every block that a
+    // neighbour on another device will read is compared with what was written there (slab_peer_copy_check); a mismatch or a
+    // refusal puts every slab on a plain hipMalloc block, whose peer access hipDeviceEnablePeerAccess governs, and says so on
+    // stderr.  TVDN_VMM_PEER=0 takes the plain blocks at once (round 5's behaviour).
+    if (world > 1) {
+        bool one_device = true;
+        for (int q = 0; q < world; ++q) one_device = one_device && sl[q].device == sl[0].device;
+        const char *ep = getenv("TVDN_VMM_PEER");
+        bool on_granules = one_device || !(ep && atoi(ep) == 0);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            for (int r = 0; r < world; ++r) {
+                Slab &s = sl[r];
+                TVDN_HIP(hipSetDevice(s.device));
+                const size_t stride = ((size_t)s.rows() * row_bytes + 255) / 256 * 256 + 4096;
+                int peers[TVDN_MAX_DEVICES], n_peers = 0;
+                for (int q = 0; q < world; ++q) {
+                    bool seen = sl[q].device == s.device;
+                    for (int j = 0; j < n_peers; ++j) seen = seen || peers[j] == sl[q].device;
+                    if (!seen) peers[n_peers++] = sl[q].device;
+                }
+                TVDN_HIP(state_malloc(&s.state.p, stride * (size_t)(3 + nd * per_axis), s.device, on_granules, 0.25, peers, n_peers));
+            }
+            // let every device address its neighbours' memory (no-op when they are the same device)
+            for (int r = 0; r < world; ++r)
+                for (int d : {(r + 1) % world, (r + world - 1) % world})
+                    if (sl[d].device != sl[r].device) {
+                        TVDN_HIP(hipSetDevice(sl[r].device));
+                        (void)hipDeviceEnablePeerAccess(sl[d].device, 0);  // direct xGMI copies where the link exists;
+                        (void)hipGetLastError();                            // without it the peer copy is staged, still correct
+                    }
+            bool granule_blocks = false;
+            for (int r = 0; r < world; ++r) granule_blocks = granule_blocks || dev_kind(sl[r].state.p) == TVDN_MEM_GRANULES;
+            const char *force = getenv("TVDN_PEER_CHECK");  // 1: also between slabs of ONE device (tests: the only kind a one-GPU box has)
+            if (!granule_blocks || (one_device && !(force && atoi(force) == 1))) break;
+            char why[200] = "";
+            if (slab_peer_copy_check(sl.get(), world, row_bytes, nd, per_axis, why, sizeof why)) {
+                stats.peer_check = 1;
+                break;
+            }
+            stats.peer_check = -1;
+            if (attempt == 1 || !on_granules) {
+                set_error("peer copies between the slabs' device blocks do not arrive intact (%s)", why);
+                return TVDN_ERR_HIP;
+            }
+            fprintf(stderr, "tvdn_run: peer copies out of blocks on granules failed their check (%s): the slabs go on plain hipMalloc blocks (TVDN_VMM_PEER=0)\n", why);
+            for (int r = 0; r < world; ++r) {
+                TVDN_HIP(hipSetDevice(sl[r].device));
+                (void)dev_free(sl[r].state.p);
+                sl[r].state.p = nullptr;
+            }
+            on_granules = false;
+        }
+    }
+    for (int r = 0; r < world; ++r) {
+        Slab &s = sl[r];
+        TVDN_HIP(hipSetDevice(s.device));
+        const size_t stride = ((size_t)s.rows() * row_bytes + 255) / 256 * 256 + 4096;
+        const int n_arr = 3 + nd * per_axis;
         TVDN_HIP(hipMemsetAsync(s.state.p, 0, stride * (size_t)(n_arr - 2), s.main));
         std::memset(&s.roles, 0, sizeof s.roles);
         roles_reset(s.roles, fista);
@@ -200,14 +301,6 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
         TVDN_HIP(hipMalloc(&s.sums.p, sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1)));
         TVDN_HIP(hipMemsetAsync(s.sums.p, 0, sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1), s.main));
     }
-    if (world > 1)  // let every device address its neighbours' memory (no-op when they are the same device)
-        for (int r = 0; r < world; ++r)
-            for (int d : {(r + 1) % world, (r + world - 1) % world})
-                if (sl[d].device != sl[r].device) {
-                    TVDN_HIP(hipSetDevice(sl[r].device));
-                    (void)hipDeviceEnablePeerAccess(sl[d].device, 0);  // direct xGMI copies where the link exists;
-                    (void)hipGetLastError();                            // without it the peer copy is staged, still correct
-                }
 
     clk.mark("contexts, state allocated");
     // ---- upload: own rows + halo rows, straight from the caller's array ---------------------------------------

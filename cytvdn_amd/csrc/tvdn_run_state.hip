@@ -30,7 +30,7 @@ static bool keep_state()
 // fast the sweep runs on it, that of a hipMalloc block does).  `granules` false: a plain hipMalloc block
 // (slabs on several devices, whose neighbours copy rows out of it peer to peer).  TVDN_MALLOC=contiguous | uncached |
 // finegrained asks the runtime for another kind of device memory (measurement, round 3: they draw from the same lottery).
-hipError_t state_malloc(void **p, size_t bytes, int device, bool granules, double spread_budget_s)
+hipError_t state_malloc(void **p, size_t bytes, int device, bool granules, double spread_budget_s, const int *peers, int n_peers)
 {
     const char *e = getenv("TVDN_MALLOC");
     if (e && !strcmp(e, "contiguous")) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous);
@@ -38,7 +38,7 @@ hipError_t state_malloc(void **p, size_t bytes, int device, bool granules, doubl
     if (e && !strcmp(e, "finegrained")) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
     if (!granules) return hipMalloc(p, bytes);
     DevAllocInfo info;
-    const hipError_t rc = dev_alloc(p, bytes, device, nullptr, spread_budget_s, &info);
+    const hipError_t rc = dev_alloc(p, bytes, device, nullptr, spread_budget_s, &info, peers, n_peers);
     if (rc == hipSuccess && getenv("TVDN_RUN_TIMING") && info.granules)
         fprintf(stderr, "tvdn_run:   state on %d granules of %lld MiB, a random subset of %d created, in %.3f s (budget for the extra ones %.2f s)\n", info.granules,
                 (long long)(info.granule_bytes >> 20), info.pool, info.seconds, spread_budget_s);
@@ -65,7 +65,7 @@ hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, 
         if (c) {  // the wrong size: a block on granules keeps the granules it has and is dealt out anew at the right one (creating
                   // them is what a big block's set-up consists of: 2.7 s for 236 GiB, 5-7 s behind a release); else make room first
             void *q = c;
-            const hipError_t er = dev_resize(&q, bytes, device);
+            const hipError_t er = dev_resize(&q, bytes, device, spread_budget_s);
             c = nullptr;
             cb = 0;
             if (er == hipSuccess) {

@@ -24,7 +24,6 @@ namespace tvdn {
 
 constexpr int kHostThreads = 8;
 constexpr size_t kPinInPlaceMinDefault = size_t(256) << 20;  // bytes from which a caller's array is page-locked in place
-inline size_t env_bytes(const char *name);
 
 inline void parallel_copy(void *dst, const void *src, size_t bytes)  // src == nullptr: zero fill
 {
@@ -268,24 +267,6 @@ struct DevMem {
     }
     ~DevMem() { release(); }
 };
-
-// "64G" / "512M" / bytes from the environment; 0 = not set
-inline size_t env_bytes(const char *name)
-{
-    const char *e = getenv(name);
-    if (!e) return 0;
-    char *end = nullptr;
-    double v = strtod(e, &end);
-    if (end == e || v <= 0) return 0;
-    switch (*end) {
-    case 'K': case 'k': v *= 1024.0; break;
-    case 'M': case 'm': v *= 1024.0 * 1024.0; break;
-    case 'G': case 'g': v *= 1024.0 * 1024.0 * 1024.0; break;
-    case 'T': case 't': v *= 1024.0 * 1024.0 * 1024.0 * 1024.0; break;
-    default: break;
-    }
-    return (size_t)v;
-}
 
 // Host memory a streamed run may count on: what the kernel calls available, never more than the machine has, and
 // never more than the memory limit of the process's control group (the limit itself, not limit minus usage: the

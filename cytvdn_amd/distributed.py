@@ -114,25 +114,38 @@ def denoise_slabs(my_rows, global_shape, mu, iterations=10, FISTA=True, stopping
             exact_wrap = bool(int(flag.item()))
         return _denoise_slabs_staged(my_rows, lay, dtype, mu, lam, FISTA, unacc, n_f, n_p, stopping_relative_change,
                                      group, device, staged, rank, world, exact_wrap)
-    be = (backend_factory or (lambda l: HipBackend(l, dtype, FISTA, device=device, max_iters=n)))(lay)
+    # The overlapped exchange (edge rows first, transfer on a side stream) is used only on a process group on which it has
+    # reproduced a single-GPU run bit for bit in this process (selfcheck_exchange, cached per group); otherwise the blocking
+    # exchange, loudly.  The same goes for WHAT the rows are sent out of and received into: a slab's state of 2 GiB or more
+    # lives on granules of HIP virtual memory (csrc/tvdn_devmem.hip), which RCCL is handed only after the self-check has also
+    # passed with its states on granules -- else this rank's state is a plain hipMalloc block, loudly as well.
+    overlap_ok, granules_ok = True, None
+    if world > 1 and backend_factory is None and dist.get_backend(group) == "nccl":
+        import warnings
+        ok = exchange_verified(group, device)
+        if not ok["blocking"]:
+            raise RuntimeError(f"halo exchange over {ok['transport']} does not reproduce the single-GPU result: {ok}")
+        if not ok["overlap"]:
+            warnings.warn(f"overlapped halo exchange failed its self-check on this process group ({ok}); "
+                          "using the blocking exchange", RuntimeWarning)
+            overlap_ok = False
+        g = ok.get("granules")
+        if g is not None:
+            granules_ok = bool(g["blocking"])
+            if not granules_ok:
+                warnings.warn(f"halo exchange straight out of / into device memory on granules failed its self-check ({g}); "
+                              "this run keeps its state on plain hipMalloc blocks (as TVDN_VMM=0 would)", RuntimeWarning)
+            elif not g["overlap"]:
+                overlap_ok = False
+    be = (backend_factory or (lambda l: HipBackend(l, dtype, FISTA, device=device, max_iters=n,
+                                                   granules=None if granules_ok is not False else False)))(lay)
     be.set_params(1.0 / lam, (lam / mu).astype(dtype))
     # own rows in, halo rows from the neighbours
     block = torch.zeros(lay.local_shape, dtype=torch.float32 if dtype == np.float32 else torch.float64)
     block[lay.row_lo:lay.row_hi] = my_rows.cpu() if is_t else torch.from_numpy(np.ascontiguousarray(my_rows))
     be.set_input(block)
     run = SlabRunner(be, group)
-    # the overlapped exchange (edge rows first, transfer on a side stream) is used only on a process group on which it
-    # has reproduced a single-GPU run bit for bit in this process (selfcheck_exchange, cached per group); otherwise
-    # the blocking exchange, loudly
-    if world > 1 and backend_factory is None and run.transport == "rccl":
-        ok = exchange_verified(group, device)
-        if not ok["overlap"]:
-            import warnings
-            warnings.warn(f"overlapped halo exchange failed its self-check on this process group ({ok}); "
-                          "using the blocking exchange", RuntimeWarning)
-            run.overlap = False
-        if not ok["blocking"]:
-            raise RuntimeError(f"halo exchange over {ok['transport']} does not reproduce the single-GPU result: {ok}")
+    run.overlap = overlap_ok
     run.exchange_halos()
     dt = dtype.type
 
@@ -384,21 +397,33 @@ _VERIFIED = {}
 
 
 def exchange_verified(group=None, device=None) -> dict:
-    """selfcheck_exchange, run once per process group and remembered."""
+    """selfcheck_exchange, run once per process group and remembered: the check on plain device memory, and under
+    "granules" the same check with its states on granules of HIP virtual memory (what a slab of 2 GiB or more lives on;
+    None when granules are off anyway: TVDN_VMM=0, a runtime without virtual-memory management, a tripped remap canary)."""
     key = id(group) if group is not None else 0
     if key not in _VERIFIED:
-        _VERIFIED[key] = selfcheck_exchange(group=group, device=device)
+        res = selfcheck_exchange(group=group, device=device)
+        res["granules"] = None
+        if res["blocking"] and os.environ.get("TVDN_VMM", "1") != "0":
+            g = selfcheck_exchange(group=group, device=device, on_granules=True)
+            res["granules"] = {k: g[k] for k in ("overlap", "blocking", "error", "state_mem")}
+        _VERIFIED[key] = res
     return _VERIFIED[key]
 
 
-def selfcheck_exchange(group=None, device=None, iterations: int = 6, dtype=np.float32, plane=(6, 16, 32)):
+def selfcheck_exchange(group=None, device=None, iterations: int = 6, dtype=np.float32, plane=(6, 16, 32), on_granules: bool = False):
     """Pre-flight check of the multi-GPU exchange on THIS process group: a small cube (4 rows per rank) is
     denoised three ways -- one slab on this rank's own GPU (no communication), the slab runner with the halo
     exchange overlapped under the interior sweep (`step_overlapped`), and the slab runner with a blocking
     exchange after every sweep -- and this rank's rows must come out bit-identical in all three.  The verdicts are
     combined over all ranks (minimum), so every rank returns the same dict:
         {"overlap": bool, "blocking": bool, "transport": "rccl" | "gloo", "error": str | None}
-    A failing transport shows up as False (an exception is caught and reported), never as a silent fallback."""
+    A failing transport shows up as False (an exception is caught and reported), never as a silent fallback.
+
+    `on_granules=True` puts the slab runs' states on granules of HIP virtual memory (csrc/tvdn_devmem.hip; the threshold is
+    lowered to 0 for the duration), the memory a slab of 2 GiB or more lives on and that a transport must prove it can send out
+    of and receive into.  "state_mem" says what the states really were ("granules" / "plain", the worst over all ranks); a
+    check that was asked for granules and ran on anything else counts as FAILED, not as green."""
     import torch.distributed as dist
     from . import synth
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -411,8 +436,12 @@ def selfcheck_exchange(group=None, device=None, iterations: int = 6, dtype=np.fl
     lam = mu / dt.type(32.0 if nd == 4 else 16.0)
     x = synth.cube(shape, seed=4242, dtype=dt) + dt.type(0.25)
 
+    mems = []
+
     def run(lay, overlap, grp):
-        be = HipBackend(lay, dt, True, device=device, max_iters=iterations)
+        be = HipBackend(lay, dt, True, device=device, max_iters=iterations, granules=True if (on_granules and grp is not None) else None)
+        if grp is not None:
+            mems.append(be.state_mem)
         be.set_params(1.0 / lam, (lam / mu).astype(dt))
         be.set_input(x[lay.local_rows_global()])
         r = SlabRunner(be, grp)
@@ -450,11 +479,16 @@ def selfcheck_exchange(group=None, device=None, iterations: int = 6, dtype=np.fl
                                         want.view(torch.int32 if dt == np.float32 else torch.int64)))
         except Exception as e:  # report, do not hide
             res["error"] = f"{key}: {e!r}"
-    flags = torch.tensor([int(res["overlap"]), int(res["blocking"])], dtype=torch.int32)
+    on_gr = int(bool(mems) and all(m == "granules" for m in mems))
+    if on_granules and not on_gr:
+        res["overlap"] = res["blocking"] = False
+        res["error"] = res["error"] or f"the self-check's states were asked for on granules and came as {sorted(set(mems)) or 'nothing'}"
+    flags = torch.tensor([int(res["overlap"]), int(res["blocking"]), on_gr], dtype=torch.int32)
     if dist.get_backend(group) == "nccl":
         flags = flags.to(torch.device("cuda", device))
     dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=group)
     res["overlap"], res["blocking"] = bool(flags[0].item()), bool(flags[1].item())
+    res["state_mem"] = "granules" if int(flags[2].item()) else "plain"
     return res
 
 

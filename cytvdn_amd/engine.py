@@ -50,6 +50,27 @@ def vmm_min_bytes() -> int:
     return int(os.environ.get("TVDN_VMM_MIN_MIB", "2048")) << 20
 
 
+class _vmm_threshold:
+    """For the duration of one allocation: TVDN_VMM_MIN_MIB = `mib` (None: leave it alone).  The library reads the variable
+    when it allocates; 0 puts every block on granules (csrc/tvdn_devmem.hip env_mib)."""
+
+    def __init__(self, mib):
+        self.mib = mib
+
+    def __enter__(self):
+        if self.mib is not None:
+            self.prev = os.environ.get("TVDN_VMM_MIN_MIB")
+            os.environ["TVDN_VMM_MIN_MIB"] = str(int(self.mib))
+
+    def __exit__(self, *exc):
+        if self.mib is not None:
+            if self.prev is None:
+                os.environ.pop("TVDN_VMM_MIN_MIB", None)
+            else:
+                os.environ["TVDN_VMM_MIN_MIB"] = self.prev
+        return False
+
+
 def fista_ratios(n: int) -> np.ndarray:
     """(tk-1)/tk_new for iterations 0..n-1, float64 on the host (reference cyTVDN.py:153-156): the library's own
     recurrence (_lib.fista_ratios), so that this schedule is defined once for every engine."""
@@ -178,9 +199,12 @@ class HipBackend:
     supports_partial_sweeps = True
 
     def __init__(self, layout: SlabLayout, dtype, fista: bool, device: int = 0, max_iters: int = 1,
-                 state: str = None, private_ctx: bool = False, slab=None):
+                 state: str = None, private_ctx: bool = False, slab=None, granules=None):
         """`slab` (measurement, tools/layout_probe.py): a 1-D device tensor of the data dtype to carve the arrays from
-        instead of a fresh allocation -- several layouts of the state timed on the very same pages."""
+        instead of a fresh allocation -- several layouts of the state timed on the very same pages.
+        `granules`: None = the library's rule (states of 2 GiB and more on granules of HIP virtual memory, csrc/tvdn_devmem.hip);
+        False = a plain block whatever the size (a transport that failed its self-check on granules: distributed.denoise_slabs);
+        True = granules whatever the size (the self-check itself) -- `state_mem` says what it became."""
         state = DEFAULT_STATE if state is None else state
         if state not in ("compact", "reference"):
             raise ValueError("state must be 'compact' or 'reference'")
@@ -233,10 +257,12 @@ class HipBackend:
                 if slab.dtype != tdt or slab.numel() < n_arr * stride_el:
                     raise ValueError(f"slab must hold {n_arr * stride_el} elements of {tdt}")
                 self._slab = slab[:n_arr * stride_el]
-            elif n_arr * stride_el * item >= vmm_min_bytes() and os.environ.get("TVDN_VMM", "1") != "0":
+            elif granules is not False and os.environ.get("TVDN_VMM", "1") != "0" \
+                    and (granules is True or n_arr * stride_el * item >= vmm_min_bytes()):
                 # a big state: the library's allocator (granules; how fast the sweep runs on a hipMalloc block of this size
                 # is decided by where it landed -- csrc/tvdn_devmem.hip).  The block outlives the tensor views below.
-                self._block = _lib.DeviceBlock(n_arr * stride_el * item, self.device)
+                with _vmm_threshold(0 if granules is True else None):
+                    self._block = _lib.DeviceBlock(n_arr * stride_el * item, self.device)
                 self._slab = self._block.tensor(tdt)
             else:
                 self._slab = torch.empty(n_arr * stride_el, dtype=tdt, device=dev)

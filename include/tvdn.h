@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TVDN_ABI_VERSION 8
+#define TVDN_ABI_VERSION 9
 
 typedef enum tvdn_dtype { TVDN_F32 = 0, TVDN_F64 = 1 } tvdn_dtype;
 
@@ -291,6 +291,10 @@ typedef struct tvdn_run_stats {
                               wherever the rows next to them are kept too; 2 = all rows kept, every pass but the first
                               without a copy; 3 = all rows kept on the lean layout (rings for the levels between the
                               first and the last only, no boxes): no copy at all                                      */
+    int32_t peer_check;    /* ABI 9.  a device list whose slabs sit on granules: 1 = a peer copy out of every block a
+                              neighbour reads arrived intact before the run started, -1 = it did not and the slabs went on
+                              plain hipMalloc blocks instead, 0 = nothing to check (one device, plain blocks)             */
+    int32_t first_call;    /* ABI 9.  resident, one device: 1 when this run created its state block (no kept block fitted) */
 } tvdn_run_stats;
 
 /* ABI 6.  One slab of a cube that several PROCESSES denoise together, each streaming ITS slab through its GPU from its own
@@ -417,6 +421,40 @@ int tvdn_run(const tvdn_run_args *args);
 #define TVDN_MEM_CALLER 2
 int tvdn_mem_alloc(void **ptr, int64_t bytes, int device, int32_t *kind);
 int tvdn_mem_free(void *ptr);
+
+/* ABI 9.  The same, for a block that OTHER devices read and write as well (the slabs of a tvdn_run device list pull halo rows
+ * out of their neighbours' blocks peer to peer): `peers` lists those devices, and a block on granules grants each of them
+ * access (hipMemSetAccess with one descriptor per device).  A runtime that refuses the grant gets a plain hipMalloc block
+ * (whose peer access hipDeviceEnablePeerAccess governs, as before ABI 9); *kind says which it was. */
+int tvdn_mem_alloc_shared(void **ptr, int64_t bytes, int device, const int32_t *peers, int32_t n_peers, int32_t *kind);
+
+/* ABI 9.  What the allocator knows about `device`.  Blocks on granules lean on two work-arounds for silent defects of ROCm
+ * 7.2's virtual-memory path (csrc/tvdn_devmem.hip: stale GPU translations after a remap, flushed by a hipFree; equal granule
+ * sizes), so the allocator proves them at run time: before a device hands out its first granule block a CANARY plays the
+ * product's own unmap / map / flush sequence on two small granules and reads them back by kernel and by hipMemcpy.  A stale
+ * word marks the device (vmm_state -1): plain hipMalloc blocks from then on, a line on stderr, results unaffected.  Every
+ * hipMem* call's return is checked; `faults` counts the failures since the process started and `first_fault` keeps the first
+ * one's text (call, address, size, HIP error).  The reference has no counterpart: it trusts np.zeros_like
+ * (cyTVDN/cyTVDN.py:131-145); this is how its replacement earns the same trust. */
+#define TVDN_CANARY_NOT_RUN 0
+#define TVDN_CANARY_PASSED 1
+#define TVDN_CANARY_STALE (-1)  /* a stale translation was seen: granules are off for this process */
+#define TVDN_CANARY_FAILED (-2) /* the virtual-memory calls themselves failed: granules are off */
+typedef struct tvdn_mem_status_out {
+    int32_t vmm_state;   /* 0 no big block asked for yet, 1 granules in use, -1 plain blocks only (TVDN_VMM=0, refused, canary) */
+    int32_t canary;      /* TVDN_CANARY_* */
+    int32_t canary_runs; /* how often it ran (once per device unless TVDN_VMM_CANARY=always or tvdn_mem_selftest) */
+    int32_t faults;      /* hipMem* / flush calls that returned an error, all devices */
+    int64_t flushes;     /* TLB flushes done, all devices */
+    int64_t blocks, granules, bytes; /* granule blocks alive on this device */
+    int32_t last_granules, last_pool; /* the last draw on this device: granules kept / created to choose them from (the pool is
+                            bounded by 90 % of the free HBM, a floor of max(4 GiB, 5 %) left free, and TVDN_HBM_LIMIT) */
+    char first_fault[200];
+} tvdn_mem_status_out;
+int tvdn_mem_status(int device, tvdn_mem_status_out *out);
+/* Runs the canary now.  TVDN_OK; TVDN_ERR_UNSUPPORTED: a stale translation was seen; TVDN_ERR_HIP: the calls failed
+ * (either way the device is marked and tvdn_last_error() says what was seen). */
+int tvdn_mem_selftest(int device);
 
 /* ABI 7.  Bytes of the block the last one-device tvdn_run on `device` kept for the next one (0: none): device memory that
  * hipMemGetInfo reports as used but that the next tvdn_run takes over or releases, i.e. free for planning purposes

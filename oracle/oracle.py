@@ -14,7 +14,7 @@ Contents
   psutil parts left out.
 * ``load_reference_kernels()``: imports the reference's OWN compiled kernels from
   ``oracle/_ref`` (built by ``oracle/Makefile`` from the C the reference ships).  These
-  binaries travel to the GPU box; the reference's Python sources do not.
+  binaries stay in the build container (git-ignored and gpurun-ignored), as the reference's sources do.
 * ``load_reference_driver()``: imports the reference's own ``cyTVDN/cyTVDN.py`` from
   ``/root/reference`` (build container only) -- used by ``oracle/make_golden.py``.
 
@@ -322,7 +322,7 @@ def denoise3D(datacube, mu, iterations=7500, stopping_relative_change=None, BC_m
     return t + (r["MSE"],) if reference_data is not None else t
 
 
-# ---- the real reference (binaries travel in oracle/_ref; sources never do) ----
+# ---- the real reference (build container only: oracle/_ref is git-ignored and gpurun-ignored) ----
 
 _REF_DIR = os.path.join(_HERE, "_ref")
 

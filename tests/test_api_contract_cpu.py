@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/tvdn.h but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert _lib.lib().tvdn_abi_version() == 8
+    assert _lib.lib().tvdn_abi_version() == 9
 
 
 def test_iter_args_struct_matches_header_layout():

@@ -96,7 +96,7 @@ def test_rccl_halo_exchange_matches_oracle(oracle, world, shape, dtype, bc, n_f,
     np.testing.assert_allclose(parts[0]["sums"][:, 1], ref["delta64"], rtol=1e-12)
 
 
-def _selfcheck_worker(rank, world, port, backend, outdir):
+def _selfcheck_worker(rank, world, port, backend, outdir, on_granules=False):
     import json
     import torch
     import torch.distributed as dist
@@ -110,7 +110,7 @@ def _selfcheck_worker(rank, world, port, backend, outdir):
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        res = selfcheck_exchange(device=dev)
+        res = selfcheck_exchange(device=dev, on_granules=on_granules)
         json.dump(res, open(os.path.join(outdir, f"r{rank}.json"), "w"))
     finally:
         dist.destroy_process_group()
@@ -131,6 +131,27 @@ def test_exchange_selfcheck(backend):
     assert res[0] == res[1]
     assert res[0]["blocking"] and res[0]["overlap"] and res[0]["error"] is None
     assert res[0]["transport"] == ("rccl" if backend == "nccl" else "gloo")
+    assert res[0]["state_mem"] == "plain"            # a few hundred KiB of state: below the granule threshold
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_exchange_selfcheck_on_granules(backend, monkeypatch):
+    """the pre-flight on granules must really run on granules -- its states forced there (threshold 0), `state_mem`
+    reported, anything else counted as a failure -- because that is the memory a slab of 2 GiB or more hands to the transport.
+    Over gloo (two ranks sharing this GPU) always; over RCCL with two GPUs.  With granules switched off the same call FAILS."""
+    import json
+    import torch.multiprocessing as mp
+    if backend == "nccl" and _ngpu() < 2:
+        pytest.skip("needs 2 GPUs")
+    monkeypatch.setenv("TVDN_GRANULE_MIB", "2")
+    for vmm, want in (("1", True), ("0", False)):
+        monkeypatch.setenv("TVDN_VMM", vmm)          # (the spawned ranks inherit it)
+        with tempfile.TemporaryDirectory() as tmp:
+            mp.start_processes(_selfcheck_worker, args=(2, _free_port(), backend, tmp, True), nprocs=2, join=True, start_method="spawn")
+            res = [json.load(open(os.path.join(tmp, f"r{r}.json"))) for r in range(2)]
+        assert res[0]["blocking"] == res[1]["blocking"] == want and res[0]["overlap"] == want, res
+        assert res[0]["state_mem"] == ("granules" if want else "plain")
+        assert (res[0]["error"] is None) == want
 
 
 def _mixed_groups_worker(rank, world, port, outdir):

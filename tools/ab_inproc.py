@@ -34,9 +34,12 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--audition", type=int, default=1)
+    ap.add_argument("--shape", default=None, help="e.g. 1024x512x512: overrides the config's shape (dtype and FISTA stay)")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     shape, dt, fista = CONFIGS[a.config]
+    if a.shape:
+        shape = tuple(int(v) for v in a.shape.lower().split("x"))
     dt = np.dtype(dt)
     nd = len(shape)
     mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
@@ -120,7 +123,7 @@ def main():
     base = np.mean(res[variants[0][0]])
     for label, env in variants:
         v = res[label]
-        print(json.dumps({"config": a.config, "variant": label, "env": {k: v for k, v in env.items() if v is not None}, "mean_ms": round(float(np.mean(v)), 4),
+        print(json.dumps({"config": a.config, "shape": list(shape), "variant": label, "env": {k: v for k, v in env.items() if v is not None}, "mean_ms": round(float(np.mean(v)), 4),
                           "min_ms": round(float(np.min(v)), 4), "vs_first": round(float(np.mean(v)) / base, 4),
                           "rounds": [round(x, 4) for x in v], "audition": getattr(be, "audition", [])}), flush=True)
 

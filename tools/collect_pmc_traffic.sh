@@ -3,9 +3,9 @@
 # WRITE_SIZE do not fit one pass; rocprofv3 gets the program itself after `--`), so that every fused_iter_kernel row of a CSV
 # belongs to the workload the JSON line of that process names.  tools/make_traffic_json.py turns the CSVs it leaves under
 # profiles/ into profiles/traffic.json, byte for byte reproducibly.
-#   bash tools/collect_pmc_traffic.sh r05      (on the GPU box; writes gpurun_out/pmc_r04/, then copy the condensed CSVs)
+#   bash tools/collect_pmc_traffic.sh r06      (on the GPU box; writes gpurun_out/pmc_<tag>/, then copy the condensed CSVs)
 set -u -o pipefail
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/pmc_$TAG
 rm -rf "$O"; mkdir -p "$O"

@@ -5,7 +5,7 @@
 (cyTVDN/cyTVDN.py:153-184), alternating rounds, best of N per side.  Nothing built from the reference's sources travels to
 the GPU box, so this ratio is measured here and committed:
 
-    python tools/port_vs_reference.py > profiles/r03_port_vs_reference.json
+    python tools/port_vs_reference.py > profiles/r06_port_vs_reference.json      (bench.py quotes the ratio from there)
 """
 import json
 import os
