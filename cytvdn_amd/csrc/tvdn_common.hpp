@@ -265,6 +265,8 @@ hipError_t dev_alloc(void **p, size_t bytes, int device, int *kind, double sprea
 hipError_t dev_free(void *p);  // the first error of the release, if any (everything is attempted whatever fails; stderr says which call)
 // a block on granules, re-dealt at another size (contents undefined); hipErrorNotSupported: free and allocate
 hipError_t dev_resize(void **p, size_t bytes, int device, double spread_budget_s = 0.25);
+// a kept granule block chosen from a short pool, topped up and re-drawn when a run can afford `spread_budget_s` (contents undefined, new address)
+hipError_t dev_upgrade(void **p, int device, double spread_budget_s);
 int dev_kind(const void *p);
 // Entry points that select a device put the calling thread's current device back before they return: a library that leaves
 // hipSetDevice(3) behind changes where the caller's next allocation (torch's, say) lands.
@@ -299,6 +301,8 @@ struct RebuildArgs {
     int64_t ring_rows, orig_ring_rows;
 };
 int recon_rebuild(const RebuildArgs &a, hipStream_t s);
+bool io_is_warm(int device);
+void io_warm(int device);  // tvdn_hostio.hip: the pinned staging lanes of `device` set up now instead of inside the first transfer
 void io_cap_lanes(int n);  // tvdn_hostio.hip: n > 0 holds a cap of n staging lanes per transfer, 0 drops that hold (counted)
 // A non-blocking stream in a hardware-queue class of its own.  The runtime multiplexes streams onto a few hardware queues
 // per PRIORITY level; two streams that share one execute in submission order, so a transfer's completion marker can sit

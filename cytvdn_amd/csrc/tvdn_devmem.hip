@@ -63,6 +63,7 @@ struct VmmBlock {
     int device = 0;
     std::vector<hipMemGenericAllocationHandle_t> handles;
     std::vector<int> peers;  // other devices that may read and write the range (slabs of a device list: tvdn_run.hip)
+    size_t pool = 0;         // how many granules its own were chosen from (dev_upgrade tops a short pool up when a run can afford it)
 };
 
 struct DevVmm {
@@ -446,6 +447,7 @@ hipError_t vmm_alloc(void **p, size_t bytes, int device, double spread_budget_s,
     size_t pool_size = 0;
     hipError_t e = draw_granules(need, b.G, device, spread_budget_s, b.handles, &pool_size);
     if (e != hipSuccess) return e;
+    b.pool = pool_size;
     const double t_created = since();
     e = map_block(b);
     if (e != hipSuccess) return e;
@@ -537,7 +539,12 @@ hipError_t dev_resize(void **p, size_t bytes, int device, double spread_budget_s
         if (e == hipSuccess) e = ef;
     }
     b.va = nullptr;
-    if (e == hipSuccess && b.handles.size() < need) e = draw_granules(need - b.handles.size(), G, device, spread_budget_s, b.handles, nullptr);
+    if (e == hipSuccess && b.handles.size() < need) {
+        size_t drawn_from = 0;
+        const size_t missing = need - b.handles.size();
+        e = draw_granules(missing, G, device, spread_budget_s, b.handles, &drawn_from);
+        b.pool = b.handles.size() - missing + drawn_from;  // (what the whole was chosen from: its own granules and the new ones' pool)
+    }
     if (e != hipSuccess) {  // (not enough memory for the larger block, or the runtime refused a step): everything goes back
         (void)release_block(b, 0);
         (void)tlb_flush();
@@ -548,10 +555,98 @@ hipError_t dev_resize(void **p, size_t bytes, int device, double spread_budget_s
         (void)fault(hipMemRelease(b.handles.back()), "hipMemRelease", nullptr, G);
         b.handles.pop_back();
     }
+    b.pool = std::max(b.pool, need);
     e = map_block(b);
     if (e != hipSuccess) {
         *p = nullptr;
         return e;
+    }
+    *p = b.va;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_blocks.emplace((void *)b.va, std::move(b));
+    return hipSuccess;
+}
+
+// A kept block whose granules were chosen from a SHORT pool -- the first run of a process was a short one and gave the extras
+// 5 % of its sweep time, i.e. next to nothing -- is topped up when a run that can afford it takes the block over: up to
+// `spread_budget_s` seconds of further granules, a fresh random subset of its own and the new ones, the rest given back, a new
+// random order at a new address (contents undefined, as after dev_resize).  Nothing happens (hipSuccess, *p unchanged) when the
+// pool was already twice the block, the budget is below 50 ms, or the block is not on granules.  On an error everything has been
+// given back and *p is nullptr.
+hipError_t dev_upgrade(void **p, int device, double spread_budget_s)
+{
+    const double budget = env_double("TVDN_SPREAD_S", spread_budget_s);
+    if (!p || !*p || budget < 0.05) return hipSuccess;
+    VmmBlock b;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_blocks.find(*p);
+        if (it == g_blocks.end() || it->second.device != device || !it->second.peers.empty()) return hipSuccess;
+        const size_t need = it->second.handles.size();
+        if (it->second.pool >= 2 * need) return hipSuccess;
+        b = std::move(it->second);
+        g_blocks.erase(it);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t G = b.G, need = b.handles.size(), pool_before = b.pool;
+    // the extras first, while the block is still whole: a draw that fails leaves it as it was
+    const double factor = std::max(1.0, env_double("TVDN_SPREAD", 3.0));
+    const size_t target = std::max(need, (size_t)(factor * (double)need + 0.5));
+    const size_t want_extra = std::min(target - need, pool_room(G));
+    const hipMemAllocationProp prop = granule_prop(device);
+    std::vector<hipMemGenericAllocationHandle_t> extra;
+    while (extra.size() < want_extra && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < budget) {
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, G, &prop, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        extra.push_back(h);
+    }
+    if (extra.empty()) {  // nothing to choose from: the block stays as it is
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_blocks.emplace((void *)b.va, std::move(b));
+        return hipSuccess;
+    }
+    hipError_t e = fault(hipDeviceSynchronize(), "hipDeviceSynchronize", b.va, b.va_bytes);
+    for (size_t i = 0; i < need; ++i) {
+        const hipError_t eu = fault(hipMemUnmap(b.va + i * G, G), "hipMemUnmap", b.va + i * G, G);
+        if (e == hipSuccess) e = eu;
+    }
+    {
+        const hipError_t ef = fault(hipMemAddressFree(b.va, b.va_bytes), "hipMemAddressFree", b.va, b.va_bytes);
+        if (e == hipSuccess) e = ef;
+    }
+    b.va = nullptr;
+    b.handles.insert(b.handles.end(), extra.begin(), extra.end());
+    if (e != hipSuccess) {
+        (void)release_block(b, 0);
+        (void)tlb_flush();
+        *p = nullptr;
+        return e;
+    }
+    {
+        static std::mt19937_64 rng(0x75706772ULL);
+        std::lock_guard<std::mutex> lk(g_mu);
+        std::shuffle(b.handles.begin(), b.handles.end(), rng);
+    }
+    while (b.handles.size() > need) {
+        (void)fault(hipMemRelease(b.handles.back()), "hipMemRelease", nullptr, G);
+        b.handles.pop_back();
+    }
+    b.pool = need + extra.size();
+    e = map_block(b);
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return e;
+    }
+    if (getenv("TVDN_RUN_TIMING"))
+        fprintf(stderr, "tvdn_devmem: kept block of %zu granules re-drawn from its own and %zu new ones (pool %zu -> %zu) in %.3f s\n", need, extra.size(), pool_before, b.pool,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_dev[device].last_granules = (int)need;
+        g_dev[device].last_pool = (int)b.pool;
     }
     *p = b.va;
     std::lock_guard<std::mutex> lk(g_mu);
@@ -626,6 +721,24 @@ extern "C" int tvdn_mem_free(void *ptr)
     if (e != hipSuccess) {
         (void)hipGetLastError();
         set_error("releasing device memory %p: %s (the first failing call is on stderr and in tvdn_mem_status)", ptr, hipGetErrorString(e));
+        return TVDN_ERR_HIP;
+    }
+    return TVDN_OK;
+}
+
+extern "C" int tvdn_mem_resize(void **ptr, int64_t bytes, int device)
+{
+    TVDN_REQUIRE(ptr != nullptr && *ptr != nullptr && bytes > 0, "bad argument");
+    DeviceRestore restore;
+    TVDN_HIP(hipSetDevice(device));
+    const hipError_t e = dev_resize(ptr, (size_t)bytes, device, 1.5);
+    if (e == hipErrorNotSupported) {
+        set_error("%p is not a block on granules of device %d that %lld bytes would fit the granule size of: free it and allocate", *ptr, device, (long long)bytes);
+        return TVDN_ERR_UNSUPPORTED;
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("re-dealing a block at %lld bytes on device %d: %s (the block has been given back)", (long long)bytes, device, hipGetErrorString(e));
         return TVDN_ERR_HIP;
     }
     return TVDN_OK;

@@ -15,7 +15,7 @@
 #include <mutex>
 #include <thread>
 
-#include "tvdn_common.hpp"
+#include "tvdn_stream_parts.hpp"  // PinnedBuf: page-locked host memory by registration of touched huge pages
 
 namespace tvdn {
 
@@ -30,8 +30,9 @@ struct Lane {
 
 struct HostIo {
     int device = -1;
-    bool ready = false;
+    std::atomic<bool> ready{false};
     Lane lane[kLanes];
+    PinnedBuf pinned;  // the lanes' bounce buffers: ONE registration (never released: the process's staging for good)
 };
 
 static std::mutex g_io_mutex;       // one transfer at a time per process: the bounce buffers are shared
@@ -88,21 +89,42 @@ static int lanes_wanted()
     return std::max(1, std::min(n, kLanes));
 }
 
+// The bounce buffers of all lanes are ONE piece of anonymous memory with huge pages asked for, touched by many threads and
+// page-locked with one hipHostRegister (PinnedBuf): 256 MiB in a few ms where sixteen hipHostMalloc calls of 16 MiB took ~100 ms
+// of the first transfer of a process -- a third of what the first denoise4D of a process paid over the second (round 6,
+// profiles/r06_first_call.jsonl).  Same PCIe rate either way (profiles/r04_pin_probe.jsonl).  (g_io_mutex held.)
 static int io_init(HostIo &io, int device)
 {
     if (io.ready) return TVDN_OK;
     TVDN_HIP(hipSetDevice(device));
+    if (!io.pinned.p) {
+        const int rc = io.pinned.alloc((size_t)kLanes * 2 * kChunk);
+        if (rc) return rc;
+    }
     for (int l = 0; l < kLanes; ++l) {
         Lane &L = io.lane[l];
         for (int b = 0; b < 2; ++b) {
-            TVDN_HIP(hipHostMalloc(&L.pin[b], kChunk, hipHostMallocDefault));
-            TVDN_HIP(hipEventCreateWithFlags(&L.ev[b], hipEventDisableTiming));
+            L.pin[b] = io.pinned.p + ((size_t)l * 2 + (size_t)b) * kChunk;
+            if (!L.ev[b]) TVDN_HIP(hipEventCreateWithFlags(&L.ev[b], hipEventDisableTiming));
         }
-        TVDN_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        if (!L.stream) TVDN_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
     }
     io.device = device;
     io.ready = true;
     return TVDN_OK;
+}
+
+// The staging of `device` made ready ahead of the first transfer (tvdn_run starts this on a helper thread while it allocates
+// its state: two set-up costs of a process's first call that have nothing to do with each other).  Errors are left for the
+// first transfer to report.
+bool io_is_warm(int device) { return device >= 0 && device < 16 && g_io[device].ready.load(); }
+
+void io_warm(int device)
+{
+    if (device < 0 || device >= 16 || g_io[device].ready.load()) return;
+    DeviceRestore restore;
+    std::lock_guard<std::mutex> lock(g_io_mutex);
+    if (io_init(g_io[device], device) != TVDN_OK) (void)hipGetLastError();
 }
 
 // One lane of an upload: chunks l, l+n, l+2n, ... of the array.

@@ -171,6 +171,15 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
     TVDN_REQUIRE(world <= TVDN_MAX_DEVICES, "n_devices = %d exceeds %d", world, TVDN_MAX_DEVICES);
     TVDN_REQUIRE(N0 >= world, "axis 0 (%lld rows) cannot be cut into %d slabs", (long long)N0, world);
     std::unique_ptr<Slab[]> sl(new Slab[world]);
+    // the first call of a process: its staging lanes (pinned memory, streams) are set up beside the state's allocation, not after it
+    struct Warm {
+        std::thread t;
+        ~Warm() { if (t.joinable()) t.join(); }
+    } warm;
+    {
+        const int dev0 = a->n_devices > 0 ? a->devices[0] : a->device;
+        if (!io_is_warm(dev0)) warm.t = std::thread([dev0] { io_warm(dev0); });
+    }
     const bool ring = world > 1 && periodic;
     // Jia-Zhao across several slabs: the last slab closes the wrap of the reconstruction update with the axis-0
     // accumulator of global row 0, which is zero for finite data (TVDN_EDGE_ZERO).  If the cube's first row holds an
@@ -226,9 +235,14 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
             s.state.owned = false;
         } else if (world == 1) {
             // one slab: the block the last run of this device left behind, if it fits (StateCache above)
-            // what a well-placed state is worth: 5 % of the time the run's sweeps will take (at 5.5 TB/s), at least 0.25 s
+            // What a well-placed state is worth: 5 % of the time the run's sweeps will take (at 5.5 TB/s).  No floor since round 6:
+            // with one of 0.25 s the first 50-iteration call of a process spent 0.25 s on spare granules to save at most 0.03 s of
+            // sweeps (53 Gvoxel-iters/s where the second call does 88; without the extras 75: profiles/r06_first_call_by_budget.jsonl).
+            // A block chosen from a short pool is topped up by the first run that can afford it (state_acquire -> dev_upgrade).
             const double sweeps_s = (double)n_total * (double)(stride * (size_t)n_arr) / 5.5e12;
-            TVDN_HIP(state_acquire(&s.state.p, stride * (size_t)n_arr, &s.state.bytes, s.device, &state_reused, false, std::max(0.25, 0.05 * sweeps_s)));
+            clk.mark("contexts, streams");
+            TVDN_HIP(state_acquire(&s.state.p, stride * (size_t)n_arr, &s.state.bytes, s.device, &state_reused, false, std::max(0.02, 0.05 * sweeps_s)));
+            clk.mark("state acquired");
             s.state.keep = true;
             stats.first_call = state_reused ? 0 : 1;
         }

@@ -60,7 +60,11 @@ hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, 
             c = nullptr;
             cb = 0;
             *reused = true;
-            return hipSuccess;
+            // a block whose granules a short first run chose from next to nothing: this run may be able to afford better
+            const hipError_t eu = dev_upgrade(p, device, spread_budget_s);
+            if (eu == hipSuccess) return hipSuccess;
+            (void)hipGetLastError();  // (the block has been given back: allocate below)
+            *reused = false;
         }
         if (c) {  // the wrong size: a block on granules keeps the granules it has and is dealt out anew at the right one (creating
                   // them is what a big block's set-up consists of: 2.7 s for 236 GiB, 5-7 s behind a release); else make room first

@@ -438,9 +438,9 @@ def selfcheck_exchange(group=None, device=None, iterations: int = 6, dtype=np.fl
 
     mems = []
 
-    def run(lay, overlap, grp):
-        be = HipBackend(lay, dt, True, device=device, max_iters=iterations, granules=True if (on_granules and grp is not None) else None)
-        if grp is not None:
+    def run(lay, overlap, grp, slab=True):
+        be = HipBackend(lay, dt, True, device=device, max_iters=iterations, granules=True if (on_granules and slab) else None)
+        if slab:
             mems.append(be.state_mem)
         be.set_params(1.0 / lam, (lam / mu).astype(dt))
         be.set_input(x[lay.local_rows_global()])
@@ -470,7 +470,7 @@ def selfcheck_exchange(group=None, device=None, iterations: int = 6, dtype=np.fl
     except Exception as e:
         res["error"] = f"census: {e!r}"
     lay = SlabLayout(shape, rank, world, 2)
-    want, _ = run(SlabLayout(shape, 0, 1, 2), False, None)
+    want, _ = run(SlabLayout(shape, 0, 1, 2), False, None, slab=False)
     want = want[lay.g0:lay.g1]
     for key, overlap in (("blocking", False), ("overlap", True)):
         try:

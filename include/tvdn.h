@@ -428,6 +428,15 @@ int tvdn_mem_free(void *ptr);
  * (whose peer access hipDeviceEnablePeerAccess governs, as before ABI 9); *kind says which it was. */
 int tvdn_mem_alloc_shared(void **ptr, int64_t bytes, int device, const int32_t *peers, int32_t n_peers, int32_t *kind);
 
+/* ABI 9.  A block on granules changes size -- or, at the size it has, only its arrangement -- without being freed and
+ * allocated anew: the granules it has stay (creating them is what a big block's set-up consists of), missing ones are drawn
+ * like a new block's, surplus ones go back, and all of them are dealt out in a fresh random order at a NEW address (*ptr is
+ * updated; contents are undefined afterwards; the device is synchronised first).  What tvdn_run does with the block it keeps
+ * between runs of different sizes; tools/arrangement_search.py times one state on arrangement after arrangement with it.
+ * TVDN_ERR_UNSUPPORTED: not a granule block, or the new size wants another granule size (free and allocate instead);
+ * TVDN_ERR_HIP: the runtime refused a step -- the block has been given back and *ptr is NULL. */
+int tvdn_mem_resize(void **ptr, int64_t bytes, int device);
+
 /* ABI 9.  What the allocator knows about `device`.  Blocks on granules lean on two work-arounds for silent defects of ROCm
  * 7.2's virtual-memory path (csrc/tvdn_devmem.hip: stale GPU translations after a remap, flushed by a hipFree; equal granule
  * sizes), so the allocator proves them at run time: before a device hands out its first granule block a CANARY plays the

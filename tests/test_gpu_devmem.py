@@ -228,3 +228,44 @@ def test_a_kept_block_changes_size_with_the_granules_it_has(oracle, monkeypatch)
     assert _lib.state_kept_bytes(0) == 0
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info(0)[0] >= free0 - (64 << 20)      # every granule went back
+
+
+def test_a_short_first_run_takes_few_spare_granules_and_a_longer_one_tops_the_block_up(oracle, monkeypatch):
+    """Round 6: tvdn_run gives the spare granules 5 % of its expected sweep time and no longer a floor of
+    0.25 s -- the first 50-iteration call of a process is not worth a quarter of a second of pool -- and the kept block, chosen from
+    a short pool, is re-drawn from its own and new granules by the first run that can afford it (dev_upgrade in state_acquire):
+    `first_call` tells the two apart, the bits are the oracle's either way, and nothing leaks."""
+    import torch
+    from cytvdn_amd import _lib, synth
+    monkeypatch.setenv("TVDN_GRANULE_MIB", "2")
+    monkeypatch.setenv("TVDN_VMM_MIN_MIB", "1")
+    monkeypatch.setenv("TVDN_VMM", "1")
+    _lib.lib().tvdn_release_cache()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    shape, n_f = (30, 6, 16, 32), 5
+    x = synth.cube(shape, seed=47, dtype=np.float32) + np.float32(0.25)
+    mu = np.array([1.0, 0.8, 0.5, 0.6], np.float32)
+    ref = oracle.denoise(x, mu, n_f, True)
+    seen = []
+    for budget in ("0", "0", "0.5", "0.5"):
+        monkeypatch.setenv("TVDN_SPREAD_S", budget)       # (what the run's length would otherwise decide)
+        recon, sums, stats = np.empty_like(x), np.zeros((n_f, 3)), _lib.RunStats()
+        a = _run_args(x, mu, n_f, 0, recon, sums, stats)
+        _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+        assert bits_equal(recon, ref["recon"]), budget
+        st = _lib.mem_status(0)
+        seen.append((stats.first_call, st["last_granules"], st["last_pool"]))
+    need = seen[0][1]
+    assert seen[0] == (1, need, need) and seen[1] == (0, need, need)          # no spare granules, and the kept block taken as it is
+    assert seen[2][0] == 0 and seen[2][1] == need and seen[2][2] >= 2 * need    # topped up by the run that could afford it ...
+    assert seen[3] == seen[2]                                                   # ... once
+    assert _lib.mem_status(0)["faults"] == 0
+    _lib.lib().tvdn_release_cache()
+    torch.cuda.synchronize()
+    import time
+    for _ in range(100):
+        if torch.cuda.mem_get_info(0)[0] >= free0 - (64 << 20):
+            break
+        time.sleep(0.05)
+    assert torch.cuda.mem_get_info(0)[0] >= free0 - (64 << 20)
