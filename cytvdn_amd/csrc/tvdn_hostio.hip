@@ -119,6 +119,11 @@ static int io_init(HostIo &io, int device)
 // first transfer to report.
 bool io_is_warm(int device) { return device >= 0 && device < 16 && g_io[device].ready.load(); }
 
+// (Round 6 also tried to spend the wait on a warm-up: 16 MiB uploads into a scratch block until the state was allocated -- DMA
+// traffic beside the driver creating granules slowed the allocation by more than the upload gained, 0.87-0.90 s against 0.82-0.84 s
+// for the whole first call -- and the lane threads copying between their bounce buffers -- no difference, 0.805-0.81 s either
+// way; profiles/r06_first_call_prime.jsonl.  The first five 512 MiB chunks of a process's first upload stay at 12-40 ms each where
+// every later one takes 10.5.)
 void io_warm(int device)
 {
     if (device < 0 || device >= 16 || g_io[device].ready.load()) return;

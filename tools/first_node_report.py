@@ -53,5 +53,13 @@ def main():
               f"PCIe all devices {d.get('h2d_GBps_all')} + {d.get('d2h_GBps_all')} GB/s, bit-identical to one device: {d.get('bit_identical_to_one_device_resident')}")
 
 
+    for name in ("device_list_resident", "device_list_resident_plain"):
+        d = last_json(os.path.join(o, name + ".out"))
+        if d:
+            print(f"{name} (one process, peer copies): {d.get('value')} {d.get('unit')} on {d.get('distinct_devices')} GPUs, shape {d.get('shape')}, "
+                  f"peer_check {d.get('peer_check')} (1 = a peer copy out of every granule block arrived intact, -1 = fell back to plain blocks, 0 = plain blocks), "
+                  f"allocator faults {sum(m.get('faults', 0) for m in (d.get('mem') or {}).values())}, bit-identical to one device: {d.get('bit_identical_to_one_device')}")
+
+
 if __name__ == "__main__":
     main()

@@ -9,7 +9,11 @@
 #                                        memory (needs 40 GiB of host memory per rank at the default shape)
 #   4. tools/device_list_streamed.py     the same structure inside ONE process: tvdn_run with the node's GPUs as a device list,
 #                                        every slab streamed from host arrays the slabs share (no launcher, no messages)
-#   5. tools/first_node_report.py        one page: what ran, what it gave, scaling efficiency against the 1-GPU line
+#   5. tools/device_list_resident.py     resident slabs inside ONE process (tvdn_run with a device list, halo rows by peer copies),
+#                                        twice: slabs on granules with every device of the list granted access (ABI 9; the run
+#                                        checks a peer copy out of every block first: peer_check) and TVDN_VMM_PEER=0 (plain
+#                                        hipMalloc blocks) -- the A/B of placement under peer copies
+#   6. tools/first_node_report.py        one page: what ran, what it gave, scaling efficiency against the 1-GPU line
 # Since round 5 a state of 2 GiB or more lives on 1 GiB granules of HIP virtual memory (csrc/tvdn_devmem.hip) -- memory RCCL has
 # never been handed on hardware either.  The 2-GPU bench therefore runs twice, the second time with TVDN_VMM=0 (plain hipMalloc):
 # if only the first fails, the granules are the cause and TVDN_VMM=0 is the way round it; if both run, the pair is the first
@@ -49,9 +53,14 @@ done
 if [ -n "${REHEARSE_SHAPE:-}" ]; then
   step staged_slabs 300 python3 tools/bench_staged_slabs.py --shape 32x64x64x64 --ranks 2 --rows 4 --k 4 --iters 8
   step device_list_streamed 300 python3 tools/device_list_streamed.py --shape 32x64x64x64 --devices 0,0,0 --rows 4 --k 4 --iters 8 --check
+  TVDN_PEER_CHECK=1 TVDN_VMM_MIN_MIB=1 TVDN_GRANULE_MIB=2 step device_list_resident 300 python3 tools/device_list_resident.py --shape 32x64x64x64 --devices 0,0,0 --iters 8 --check
+  TVDN_VMM_PEER=0 TVDN_PEER_CHECK=1 TVDN_VMM_MIN_MIB=1 TVDN_GRANULE_MIB=2 step device_list_resident_plain 300 python3 tools/device_list_resident.py --shape 32x64x64x64 --devices 0,0,0 --iters 8 --check
 elif [ "$NGPU" -ge 2 ]; then
   # config 5 in structure at a size every node can pin: the config-2 planes, 32 rows per rank, one GPU per rank
   step staged_slabs 1200 python3 tools/bench_staged_slabs.py --shape $((32 * NGPU))x256x128x128 --ranks "$NGPU" --gpu-per-rank --rows 8 --k 24 --iters 48
   step device_list_streamed 1200 python3 tools/device_list_streamed.py --shape $((32 * NGPU))x256x128x128 --devices "$(seq -s, 0 $((NGPU - 1)))" --rows 8 --k 24 --iters 48
+  # resident slabs in one process: 32 rows of config-4 planes per GPU (62 GiB of state each), granules with peer access vs plain blocks
+  step device_list_resident 900 python3 tools/device_list_resident.py --shape $((32 * NGPU))x512x256x256 --devices "$(seq -s, 0 $((NGPU - 1)))" --iters 20 --check
+  TVDN_VMM_PEER=0 step device_list_resident_plain 900 python3 tools/device_list_resident.py --shape $((32 * NGPU))x512x256x256 --devices "$(seq -s, 0 $((NGPU - 1)))" --iters 20
 fi
 python3 tools/first_node_report.py "$O" | tee "$O/report.txt"
