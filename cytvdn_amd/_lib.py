@@ -23,6 +23,7 @@ LIB_PATH = os.environ.get("TVDN_LIB") or os.path.join(_HERE, "libtvdn_hip.so")
 TVDN_F32, TVDN_F64 = 0, 1
 EDGE_BC, EDGE_HALO, EDGE_ZERO, EDGE_WRAP = 0, 1, 2, 3
 ITER_PLAIN, ITER_FISTA, ITER_FISTA_D, ITER_FISTA_D_TO_PLAIN = 0, 1, 2, 3
+SWEEP_CHAIN_LO, SWEEP_STORE_AHEAD = 1, 2
 
 EXPORTS = (
     "tvdn_abi_version", "tvdn_last_error", "tvdn_device_count", "tvdn_ctx_create", "tvdn_ctx_destroy",
@@ -51,7 +52,7 @@ class IterArgs(C.Structure):
         ("orig", C.c_void_p), ("recon_in", C.c_void_p), ("recon_out", C.c_void_p),
         ("b_in", C.c_void_p * 4), ("b_out", C.c_void_p * 4), ("d_in", C.c_void_p * 4), ("d_out", C.c_void_p * 4),
         ("dprev_in", C.c_void_p * 4),
-        ("sweep_lo", C.c_int64), ("sweep_hi", C.c_int64), ("accumulate", C.c_int32), ("reserved", C.c_int32),
+        ("sweep_lo", C.c_int64), ("sweep_hi", C.c_int64), ("accumulate", C.c_int32), ("chain", C.c_int32),
         ("wrap_recon", C.c_void_p),
         ("ring_rows", C.c_int64), ("orig_ring_rows", C.c_int64),
         ("recon_in_ring_rows", C.c_int64), ("cur_ring_rows", C.c_int64), ("prev_ring_rows", C.c_int64),

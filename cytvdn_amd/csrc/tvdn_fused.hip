@@ -77,6 +77,7 @@ struct FusedParams {
     // ring_in2, of r_out at m % ring_rout, of the out1 / out2 arrays at m % ring_out, of orig at m % ring_orig (one ring size for
     // all of them but orig in a plain streamed pass; a "ring" longer than the cube is an array: rows kept in HBM, swept in place)
     unsigned ring, ring_in1, ring_in2, ring_rout, ring_out, ring_orig;
+    int chain_lo, store_ahead;  // RING only (tvdn.h TVDN_SWEEP_*): the axis-0 accumulator handed across the cut between two launches
     double *partials;
 };
 
@@ -359,7 +360,22 @@ __global__ void __launch_bounds__(BLOCK) TVDN_OCCUPANCY fused_iter_kernel(FusedP
         // ---- prologue: M-axis accumulator of row m0 -----------------------------------------------
         P r_cur = ldb<T, VEC, false>(p.r_in + row_slot<RING>(m0, p.ring) * SM, e0);
         P bM_cur;
-        {
+        if (RING && p.chain_lo && m0 == p.sweep_lo) {  // (the launch's first march only: its other marches start inside the launch)
+            // The launch before this one (same iteration, rows ending at m0) stored the axis-0 output state of row m0 ahead
+            // (store_ahead, below): b_new(m0) is that value itself, or -- where d' is what is stored -- d' + tk * (d' - d_k),
+            // the expression that formed it (acc_new): same operands, same roundings, one plane read instead of three, no store.
+            const long long row0_o = row_slot<RING>(m0, p.ring_out) * SM;
+            if (MODE == TVDN_ITER_FISTA_D) {
+                const P dn = ldb<T, VEC, false>(sM.out2 + row0_o, e0);
+                const P v2 = ldb<T, VEC, kNtLoads>(sM.in2 + row_slot<RING>(m0, p.ring_in2) * SM, e0);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) bM_cur.v[j] = dn.v[j] + tk * (dn.v[j] - v2.v[j]);
+            } else {
+                bM_cur = ldb<T, VEC, false>(sM.out1 + row0_o, e0);  // PLAIN / D_TO_PLAIN: b' = d'; FISTA: b' is stored as such
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[0] += fabs((double)bM_cur.v[j]);
+        } else {
             long long mp;  // the row that precedes m0
             if (m0 > p.row_lo || p.lo_mode == TVDN_EDGE_HALO)
                 mp = m0 - 1;
@@ -440,8 +456,9 @@ __global__ void __launch_bounds__(BLOCK) TVDN_OCCUPANCY fused_iter_kernel(FusedP
                 for (int j = 0; j < VEC; ++j)
                     bM_next.v[j] = acc_new<T, MODE>(r_next.v[j], self ? r_next.v[j] : r_cur.v[j], mv1.v[j],
                                                     MT::kIn2 ? mv2.v[j] : (T)0, tk, tkp, clM, o1.v[j], o2.v[j]);
-                // rows inside the chunk are owned here, and so is a halo row sitting at row_hi
-                if (!last || (at_end && p.hi_mode == TVDN_EDGE_HALO)) {
+                // rows inside the chunk are owned here, and so is a halo row sitting at row_hi -- and, between two launches of one
+                // iteration that hand the accumulator across their cut (store_ahead), the first row of the next launch
+                if (!last || (at_end && p.hi_mode == TVDN_EDGE_HALO) || (RING && p.store_ahead && m1 == p.sweep_hi && !at_end)) {
                     if (MT::kOut1) stb<T, VEC>(sM.out1 + rown_o, e0, o1);
                     if (MT::kOut2) stb<T, VEC>(sM.out2 + rown_o, e0, o2);
                 }
@@ -556,6 +573,8 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
     p.ring_rout = (unsigned)(a->recon_out_ring_rows ? a->recon_out_ring_rows : a->ring_rows);
     p.ring_out = (unsigned)(a->out_ring_rows ? a->out_ring_rows : a->ring_rows);
     p.ring_orig = (unsigned)(a->ring_rows ? (a->orig_ring_rows ? a->orig_ring_rows : a->shape[0]) : 0);
+    p.chain_lo = (a->ring_rows > 0 && (a->chain & TVDN_SWEEP_CHAIN_LO)) ? 1 : 0;
+    p.store_ahead = (a->ring_rows > 0 && (a->chain & TVDN_SWEEP_STORE_AHEAD)) ? 1 : 0;
     if (!p.ring && getenv("TVDN_FORCE_RING") && a->shape[0] < (1LL << 31))  // measurement knob: the ring instantiation on
         p.ring = p.ring_in1 = p.ring_in2 = p.ring_rout = p.ring_out = p.ring_orig = (unsigned)a->shape[0];  // resident arrays (same rows, same bits)
     p.partials = ctx->partials;
@@ -709,6 +728,9 @@ extern "C" int tvdn_iterate_fused(tvdn_ctx *ctx, const tvdn_iter_args *a, double
                      (long long)a->ring_rows, need);
         TVDN_REQUIRE(a->orig_ring_rows == 0 || a->orig_ring_rows >= s1 - s0, "orig ring shorter than the sweep");
         TVDN_REQUIRE(!(a->hi_mode == TVDN_EDGE_WRAP && !a->wrap_recon), "hi_mode WRAP on a ring needs wrap_recon");
+        TVDN_REQUIRE((a->chain & ~(TVDN_SWEEP_CHAIN_LO | TVDN_SWEEP_STORE_AHEAD)) == 0, "unknown bits in chain: %d", a->chain);
+        TVDN_REQUIRE(!(a->chain & TVDN_SWEEP_CHAIN_LO) || s0 > a->row_lo, "TVDN_SWEEP_CHAIN_LO needs a launch of this iteration that ended at sweep_lo");
+        TVDN_REQUIRE(!(a->chain & TVDN_SWEEP_STORE_AHEAD) || s1 < a->row_hi, "TVDN_SWEEP_STORE_AHEAD needs a row after the sweep inside the own rows");
     }
     TVDN_REQUIRE(a->orig && a->recon_in && a->recon_out, "NULL state pointer");
     TVDN_REQUIRE(a->recon_in != a->recon_out, "the fused sweep is not in-place: recon_in == recon_out");

@@ -213,6 +213,19 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
         return TVDN_OK;
     };
 
+    // The launches of a level follow each other row by row, chunk after chunk: each hands the axis-0 accumulator of the row
+    // after its last to the next one (tvdn.h TVDN_SWEEP_STORE_AHEAD / _CHAIN_LO) instead of that one forming it again from
+    // recon of the row before and the input state -- one plane less to read per launch, which is 19 -> 18 plane moves where a
+    // launch is ONE row (the regime of a cube that streams every row: R 1, K 45-49).  Where every array of a level is a ring
+    // for the whole pass, i.e. not where kept rows are swept in place (the store and the rings alternate there by launch).
+    // ahead[j]: the running row whose axis-0 output state level j has stored ahead (-1: none).  TVDN_STREAM_HANDOVER=0: off.
+    const char *e_chain = getenv("TVDN_STREAM_HANDOVER");
+    const bool chainable = !inplace && !(e_chain && atoi(e_chain) == 0);
+    std::vector<int64_t> ahead((size_t)kmax, -1);
+    struct ChainOff {  // `it` outlives the call: leave it as it was found
+        tvdn_iter_args &it;
+        ~ChainOff() { it.chain = 0; }
+    } chain_off{it};
     int rc2 = upload(0, 0);
     if (rc2) return rc2;
     for (int64_t t = 0; t < n_chunks; ++t) {
@@ -359,6 +372,25 @@ int StreamRun::chain(std::vector<PassDesc> &ps)
                 it.orig = Ow.base;
                 it.orig_ring_rows = ocap;
                 it.recon_in_ring_rows = it.cur_ring_rows = it.prev_ring_rows = it.recon_out_ring_rows = it.out_ring_rows = 0;
+                it.chain = 0;
+                if (chainable) {
+                    if (ahead[(size_t)j] == v_lo && v_lo > it.row_lo) it.chain |= TVDN_SWEEP_CHAIN_LO;
+                    // The row stored ahead takes the ring slot of row v_hi - cap of level j + 1's axis-0 state.  A ring of R + 2 rows
+                    // is sized for exactly what is read: level j + 2 reads that array as its d_k-1, and the one row of it that a
+                    // full launch of level j would overwrite early is the first row of level j + 2's launch of THIS chunk -- read
+                    // only by a prologue that is not chained (the first launch of a pass: rows from a face or a seam).  Then this
+                    // launch keeps to its own rows, and the next one of the level forms its accumulator itself.
+                    bool clobbers = false;
+                    const int64_t w = v_hi - cap, jj = j + 2;
+                    if (w >= 0 && w == t * R - (jj + 1)) {
+                        const int qq = (int)(w / N0);
+                        if (qq < P && jj < ps[(size_t)qq].kk && is_d_mode(ps[(size_t)qq].modes[(size_t)jj]))
+                            clobbers = !(ahead[(size_t)jj] == w && w > (int64_t)qq * N0);
+                    }
+                    const bool store = v_hi < it.row_hi && !clobbers;
+                    if (store) it.chain |= TVDN_SWEEP_STORE_AHEAD;
+                    ahead[(size_t)j] = store ? v_hi : -1;
+                }
                 bool out_kept = false;
                 if (inplace) {  // (P == 1: v == g)
                     const int64_t g_in = std::max<int64_t>(v_lo - 1, 0);

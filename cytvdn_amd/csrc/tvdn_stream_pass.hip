@@ -114,6 +114,15 @@ int StreamRun::pass(const double *ratios /* kk entries, NAN = unaccelerated */, 
         pump_holder->start(device, st.down);
     }
     DownPump *pump = pump_holder.get();
+    // consecutive launches of a level hand the axis-0 accumulator across their cut (as in chain(); every array of this pass is a
+    // ring): ahead[j] = the row whose axis-0 output state level j has stored ahead, -1 = none.  TVDN_STREAM_HANDOVER=0: off.
+    const char *e_chain = getenv("TVDN_STREAM_HANDOVER");
+    const bool chainable = !(e_chain && atoi(e_chain) == 0);
+    std::vector<int64_t> ahead((size_t)kk, -1);
+    struct ChainOff {  // `it` outlives the pass: leave it as it was found
+        tvdn_iter_args &it;
+        ~ChainOff() { it.chain = 0; }
+    } chain_off{it};
     int rc2 = upload(0);
     if (rc2) return rc2;
     for (int64_t c = 0; c < n_chunks; ++c) {
@@ -206,6 +215,21 @@ int StreamRun::pass(const double *ratios /* kk entries, NAN = unaccelerated */, 
                 if (p0 >= p1) continue;
                 it.sweep_lo = p0;
                 it.sweep_hi = p1;
+                it.chain = 0;
+                if (chainable) {
+                    if (ahead[(size_t)j] == p0 && p0 > it.row_lo) it.chain |= TVDN_SWEEP_CHAIN_LO;
+                    // (the row stored ahead must not take the ring slot of the one row of this array that level j + 2 still reads as
+                    // its d_k-1 in this chunk: the first row of its launch, when that launch is not chained -- see chain())
+                    bool clobbers = false;
+                    const int jj = j + 2;
+                    if (jj < kk && (modes[(size_t)jj] == TVDN_ITER_FISTA_D || modes[(size_t)jj] == TVDN_ITER_FISTA_D_TO_PLAIN)) {
+                        const int64_t s_lo = std::max(lo_bound(jj + 1), E0 + c * R - (jj + 1)), s_hi = std::min(hi_bound(jj + 1), E0 + (c + 1) * R - (jj + 1));
+                        if (s_lo < s_hi && p1 - cap == s_lo) clobbers = !(ahead[(size_t)jj] == s_lo && s_lo > it.row_lo);
+                    }
+                    const bool store = p1 < it.row_hi && !clobbers;
+                    if (store) it.chain |= TVDN_SWEEP_STORE_AHEAD;
+                    ahead[(size_t)j] = store ? p1 : -1;
+                }
                 const int slot = part == 1 ? done + j : discard;
                 rc2 = tvdn_iterate_fused(ctx.c, &it, (double *)sums_d.p + 3 * (size_t)slot, st.main);
                 if (rc2) return rc2;

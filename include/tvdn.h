@@ -150,6 +150,9 @@ int tvdn_sum_square_error(tvdn_ctx *ctx, int dtype, int ndim, const int64_t *sha
 #define TVDN_ITER_FISTA_D 2
 #define TVDN_ITER_FISTA_D_TO_PLAIN 3
 
+#define TVDN_SWEEP_CHAIN_LO 1
+#define TVDN_SWEEP_STORE_AHEAD 2
+
 typedef struct tvdn_iter_args {
     int32_t dtype;        /* tvdn_dtype                                            */
     int32_t ndim;         /* 3 or 4                                                */
@@ -179,7 +182,16 @@ typedef struct tvdn_iter_args {
     int64_t sweep_lo;
     int64_t sweep_hi;
     int32_t accumulate;
-    int32_t reserved;
+    /* ABI 9 (the field was `reserved`, always 0).  Consecutive partial sweeps of ONE iteration over adjacent rows -- the launches
+     * of a level of the streamed engine, one row each when nothing is kept in HBM -- hand the axis-0 accumulator across the cut
+     * instead of forming it twice.  TVDN_SWEEP_STORE_AHEAD: the launch also stores the axis-0 output state of row sweep_hi (its
+     * look-ahead computes it anyway; needs sweep_hi < row_hi and room for that row in the output ring).  TVDN_SWEEP_CHAIN_LO: the
+     * launch takes the axis-0 accumulator of row sweep_lo from that stored output (b' itself, or d' and this level's d_in: the
+     * very expression that formed it, anisotropic.pyx:128) instead of re-reading recon of row sweep_lo - 1 and the input state,
+     * and does not store it again (needs sweep_lo > row_lo, and the previous launch of this iteration to have ended at sweep_lo
+     * with STORE_AHEAD).  One plane less to read per launch: 19 -> 18 plane moves for a one-row launch of a 4-D FISTA level,
+     * same bits.  Row rings only (ring_rows > 0); ignored on contiguous arrays. */
+    int32_t chain;
     const void *wrap_recon; /* TVDN_EDGE_WRAP: one plane, current recon of global row 0 (NULL: row row_hi) */
     /* Row rings (ABI 3; 0 = rows are contiguous, the normal case).  With ring_rows > 0 every recon / accumulator
      * pointer is the base of a ring buffer of ring_rows row-planes in which row m of the block lives at slot

@@ -36,10 +36,14 @@ def _fill(a, tensors, mode, _lib, ptr_of):
 
 @pytest.mark.parametrize("shape,dtype,bc,R", [
     ((23, 4, 6, 16), np.float32, 2, 4), ((17, 5, 8), np.float64, 2, 3), ((19, 3, 5, 7), np.float32, 2, 5),
-    ((16, 4, 6, 8), np.float64, 0, 4), ((21, 6, 12), np.float32, 0, 2),
+    ((16, 4, 6, 8), np.float64, 0, 4), ((21, 6, 12), np.float32, 0, 2), ((13, 3, 6, 16), np.float32, 2, 1), ((11, 4, 8), np.float64, 0, 1),
 ])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
-def test_ring_sweeps_equal_the_resident_sweep(shape, dtype, bc, R, mode):
+@pytest.mark.parametrize("chained", [False, True], ids=["independent launches", "accumulator handed across the cut"])
+def test_ring_sweeps_equal_the_resident_sweep(shape, dtype, bc, R, mode, chained):
+    """`chained` (ABI 9, tvdn.h TVDN_SWEEP_*): every launch but the last also stores the axis-0 output state of the row after its
+    last, every launch but the first takes the axis-0 accumulator of its first row from there instead of re-reading recon of the
+    row before and the input state -- recon of that row is POISONED in the ring to prove it is not read.  Same bits."""
     import torch
     from cytvdn_amd import _lib
     L, ctx = _lib.lib(), _lib.ctx(0)
@@ -100,6 +104,10 @@ def test_ring_sweeps_equal_the_resident_sweep(shape, dtype, bc, R, mode):
         a = args()
         a.sweep_lo, a.sweep_hi = c0, c1
         a.ring_rows, a.orig_ring_rows = cap, ocap
+        if chained:
+            a.chain = (_lib.SWEEP_CHAIN_LO if c0 > lo else 0) | (_lib.SWEEP_STORE_AHEAD if c1 < hi else 0)
+            if c0 > lo:
+                rings["r_in"][(c0 - 1) % cap].fill_(float("nan"))      # a chained launch has no use for the row before its first
         if bc == 2:
             a.hi_mode = _lib.EDGE_ZERO            # what a Jia-Zhao cube whose first row is finite has at its top face
         _fill(a, rings, mode, _lib, lambda t: t.data_ptr())
