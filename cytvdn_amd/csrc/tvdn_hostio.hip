@@ -181,7 +181,15 @@ static int transfer(bool up, void *dst, const void *src, size_t bytes, int devic
     if (bytes == 0) return TVDN_OK;
     DeviceRestore restore;
     std::lock_guard<std::mutex> lock(g_io_mutex);
-    if (bytes < (size_t(4) << 20)) {  // small: the runtime's own path is as good
+    // Only copies of a few hundred bytes go through the runtime's own path for pageable memory.  For anything larger the runtime
+    // PINS THE CALLER'S PAGES IN PLACE for the transfer and keeps the pinned object in a small cache keyed by address and size
+    // (DmaBlitManager::hsaCopyStagedOrPinned); when the memory behind that address has meanwhile been given back and mapped anew
+    // -- a NumPy array freed, the heap trimmed and grown again -- the next copy from the same address finds the stale entry and the
+    // GPU reads pages that are no longer mapped for it: "Memory access fault by GPU ... on address 0x56..." and SIGABRT.  That is
+    // the one native abort of round 5 (one in nine suites) and of round 6's first whole suite, both inside the 2.6 MB copies of
+    // the same test (profiles/r06_abort_found.txt).  Everything of the caller's therefore crosses through the library's own
+    // pinned lanes, which the runtime has no reason to look up: one lane for what fits one bounce buffer.
+    if (bytes <= 512) {
         TVDN_HIP(hipSetDevice(device));
         TVDN_HIP(hipMemcpy(dst, src, bytes, up ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
         return TVDN_OK;

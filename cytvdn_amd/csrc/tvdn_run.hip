@@ -131,14 +131,14 @@ static bool slab_peer_copy_check(Slab *sl, int world, size_t row_bytes, int nd, 
             char *dst = s_recon1 + (size_t)(side == 0 ? s.row_lo() - 1 : s.row_hi()) * row_bytes + (row_bytes - n);
             for (size_t i = 0; i < n; ++i) pat[i] = (unsigned char)(0x5b + 131 * i + 17 * r + 3 * side);
             hipError_t e = hipSetDevice(o.device);
-            if (e == hipSuccess) e = hipMemcpy(src, pat.data(), n, hipMemcpyHostToDevice);
+            if (e == hipSuccess && tvdn_copy_to_device(src, pat.data(), n, o.device) != TVDN_OK) e = hipErrorUnknown;  // (pinned lanes: tvdn_hostio.hip)
             if (e != hipSuccess) return fail("writing the pattern", e, r, d);
             e = hipSetDevice(s.device);
             if (e == hipSuccess) e = hipMemcpyPeerAsync(dst, s.device, src, o.device, n, s.copy);
             if (e == hipSuccess) e = hipStreamSynchronize(s.copy);
             if (e != hipSuccess) return fail("the peer copy", e, r, d);
             std::fill(got.begin(), got.end(), 0);
-            e = hipMemcpy(got.data(), dst, n, hipMemcpyDeviceToHost);
+            if (tvdn_copy_to_host(got.data(), dst, n, s.device) != TVDN_OK) e = hipErrorUnknown;
             if (e != hipSuccess) return fail("reading the copy back", e, r, d);
             if (got != pat) return fail("the peer copy", hipSuccess, r, d);
             e = hipMemset(dst, 0, n);
@@ -899,11 +899,13 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
                                                 (size_t)(s.g1 - s.g0) * row_bytes, s.device);
         if (rc) return rc;
         if (n_total > 0) {
-            TVDN_HIP(hipMemcpy(tmp.get(), s.sums.p, sizeof(double) * 3 * (size_t)n_total, hipMemcpyDeviceToHost));
+            rc = tvdn_copy_to_host(tmp.get(), s.sums.p, sizeof(double) * 3 * (size_t)n_total, s.device);  // (never the runtime's path for pageable memory: tvdn_hostio.hip)
+            if (rc) return rc;
             for (int i = 0; i < 3 * n_total; ++i) a->sums_out[i] += tmp[i];
         }
         if (want_mse) {
-            TVDN_HIP(hipMemcpy(tmp.get(), s.mse.p, sizeof(double) * (size_t)(n_total + 1), hipMemcpyDeviceToHost));
+            rc = tvdn_copy_to_host(tmp.get(), s.mse.p, sizeof(double) * (size_t)(n_total + 1), s.device);
+            if (rc) return rc;
             for (int i = 0; i <= n_total; ++i) a->mse_out[i] += tmp[i];
         }
     }

@@ -604,10 +604,11 @@ int StreamRun::finish()
         if (last.owned) pack_host_rows(last.p, (char *)a->recon_out, false);
         else if (last.p != (char *)a->recon_out) parallel_copy(a->recon_out, last.p, cube_bytes);
     }
-    TVDN_HIP(hipMemcpy(a->sums_out, sums_d.p, sizeof(double) * 3 * (size_t)n_total, hipMemcpyDeviceToHost));
+    // (the caller's arrays and the heap never through the runtime's path for pageable memory: tvdn_hostio.hip transfer)
+    if (n_total > 0 && (rc = tvdn_copy_to_host(a->sums_out, sums_d.p, sizeof(double) * 3 * (size_t)n_total, device))) return rc;
     if (want_mse) {
         std::vector<double> per_row((size_t)(n_total + 1) * (size_t)N0);
-        TVDN_HIP(hipMemcpy(per_row.data(), mse_d.p, sizeof(double) * per_row.size(), hipMemcpyDeviceToHost));
+        if ((rc = tvdn_copy_to_host(per_row.data(), mse_d.p, sizeof(double) * per_row.size(), device))) return rc;
         for (int s = 0; s <= n_total; ++s) {
             double t = 0.0;
             for (int64_t g = 0; g < N0; ++g) t += per_row[(size_t)s * (size_t)N0 + (size_t)g];

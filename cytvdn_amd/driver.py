@@ -190,7 +190,10 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
     calculate_MSE = reference_data is not None
     mse_dev = ref_dev = None
     if calculate_MSE:
-        ref_dev = torch.from_numpy(np.ascontiguousarray(reference_data)).to(be.orig.device)
+        ref_dev = torch.empty_like(be.orig)          # (host arrays cross through the library's pinned lanes: engine.set_input)
+        torch.cuda.current_stream(device).synchronize()
+        from . import _lib
+        _lib.copy_to_device(np.ascontiguousarray(reference_data, dtype=dtype), ref_dev)
         mse_dev = torch.zeros(n_total + 1, dtype=torch.float64, device=be.orig.device)
         be.sse(ref_dev, mse_dev[0:1])          # MSE[0] = input vs reference (cyTVDN.py:124-125)
 
@@ -233,7 +236,9 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
     if unaccelerated:
         phase(n_plain, False, "Unaccelerated TV Denoising")
 
-    sums = be.sums.cpu().numpy()[:n_total] if n_total else np.zeros((0, 3))
+    from . import _lib
+    torch.cuda.current_stream(device).synchronize()
+    sums = _lib.copy_to_host(be.sums, np.float64)[:n_total] if n_total else np.zeros((0, 3))
     ran = np.zeros(n_total, dtype=bool)
     ran[runner.ran] = True
     # slots of iterations that never ran keep the reference's zero tail (cyTVDN.py:127-128)
@@ -250,7 +255,7 @@ def _run(nd, datacube, mu, lam, iterations, FISTA, stopping_relative_change, ref
         print(f"Stopping condition reached after {int(np.nonzero(ran)[0][-1])} iterations, stopping.")
 
     if calculate_MSE:
-        return recon, b_norm, delta_recon, mse_dev.cpu().numpy().astype(dtype)
+        return recon, b_norm, delta_recon, _lib.copy_to_host(mse_dev, np.float64).astype(dtype)
     return recon, b_norm, delta_recon
 
 

@@ -354,14 +354,17 @@ class HipBackend:
 
     def set_input(self, local_block):
         """local_block: torch tensor or NumPy array of layout.local_shape (halo rows included)."""
-        if isinstance(local_block, np.ndarray) and local_block.dtype == self.dtype \
-                and tuple(local_block.shape) == tuple(self.orig.shape):
-            # pageable host memory at PCIe speed: pinned multi-lane staging inside the library
-            torch.cuda.current_stream(self.device).synchronize()
-            _lib.copy_to_device(np.ascontiguousarray(local_block), self.orig)
+        if isinstance(local_block, torch.Tensor) and local_block.is_cuda:
+            self.orig.copy_(local_block, non_blocking=False)
         else:
-            t = local_block if isinstance(local_block, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local_block))
-            self.orig.copy_(t, non_blocking=False)
+            # Host memory -- NumPy or a CPU tensor -- always through the library's own pinned lanes (tvdn_hostio.hip): PCIe speed
+            # from pageable memory, and the runtime never gets to pin the caller's pages in place (its cache of such pins outlives
+            # the memory: the GPU fault of profiles/r06_abort_found.txt).
+            h = local_block.detach().numpy() if isinstance(local_block, torch.Tensor) else np.asarray(local_block)
+            if tuple(h.shape) != tuple(self.orig.shape):
+                raise ValueError(f"set_input: block of shape {tuple(h.shape)}, the slab holds {tuple(self.orig.shape)}")
+            torch.cuda.current_stream(self.device).synchronize()
+            _lib.copy_to_device(np.ascontiguousarray(h, dtype=self.dtype), self.orig)
         self.recon[self.cur].copy_(self.orig)
 
     def recon_to_host(self):
