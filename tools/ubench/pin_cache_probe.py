@@ -1,52 +1,52 @@
 #!/usr/bin/env python3
-"""GPU box, harmless: does the runtime keep a caller's PAGEABLE array pinned after a host <-> device copy?  (The mechanism behind the
-GPU memory-access fault of profiles/r06_abort_found.txt: the runtime pins pageable memory in place for copies above a few KiB and
-caches the pinned object by address and size; memory freed, unmapped and mapped anew behind such an entry is a fault waiting for
-the next copy from that address.)  hipPointerGetAttributes on the array before / after a copy by the runtime (torch's `copy_` =
-hipMemcpy from pageable memory) and after a copy through the library's pinned lanes (tvdn_copy_to_device).  Nothing is freed
-under the runtime's feet here: no fault is provoked."""
-import ctypes as C, json, os, sys
+"""GPU box, harmless: how does the runtime move a caller's PAGEABLE array?  Run under AMD_LOG_LEVEL=4 and filter the runtime's own
+log for its two paths -- "HSA Async Copy staged H2D / D2H" (through its staging buffer) and "HSA Copy Using Pinned resource size N"
+(the caller's pages pinned IN PLACE, the pinned object kept in a cache by address and size) -- per copy size, for torch's copies
+(hipMemcpy from / to pageable memory) and for the library's (tvdn_copy_to_device / _to_host: its own pinned lanes).  The mechanism
+behind the GPU memory-access fault of profiles/r06_abort_found.txt; nothing is freed under the runtime's feet: no fault is provoked.
+
+    AMD_LOG_LEVEL=4 python3 tools/ubench/pin_cache_probe.py 2> log; python3 tools/ubench/pin_cache_probe.py --digest log"""
+import json, os, re, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+if len(sys.argv) > 2 and sys.argv[1] == "--digest":
+    cur, out = None, {}
+    for line in open(sys.argv[2], errors="replace"):
+        m = re.search(r"PROBE (\S+) (\d+)", line)
+        if m:
+            cur = f"{m.group(1)} {m.group(2)} bytes"
+            out[cur] = {"staged": 0, "pinned_in_place": 0, "pinned_sizes": []}
+            continue
+        if cur is None:
+            continue
+        if "Copy staged" in line:
+            out[cur]["staged"] += 1
+        m = re.search(r"Copy Using Pinned resource size (\d+)", line)
+        if m:
+            out[cur]["pinned_in_place"] += 1
+            out[cur]["pinned_sizes"].append(int(m.group(1)))
+    for k, v in out.items():
+        v["pinned_sizes"] = sorted(set(v["pinned_sizes"]))[:6]
+        print(json.dumps({"copy": k, **v}))
+    sys.exit(0)
+
 import numpy as np
 import torch
 from cytvdn_amd import _lib
 
-
-class Attr(C.Structure):
-    _fields_ = [("type", C.c_int), ("device", C.c_int), ("devicePointer", C.c_void_p), ("hostPointer", C.c_void_p), ("isManaged", C.c_int),
-                ("allocationFlags", C.c_uint)]
-
-
-hip = None
-for line in open("/proc/self/maps"):
-    if "libamdhip64" in line:
-        hip = C.CDLL(line.split()[-1])
-        break
-hip.hipPointerGetAttributes.argtypes = [C.POINTER(Attr), C.c_void_p]
-hip.hipGetLastError.restype = C.c_int
-
-
-def known(ptr):
-    a = Attr()
-    rc = hip.hipPointerGetAttributes(C.byref(a), C.c_void_p(ptr))
-    hip.hipGetLastError()
-    return {"rc": rc, "type": a.type if rc == 0 else None}      # rc 0 + type 1 (hipMemoryTypeHost): the runtime holds this range
-
-
 _lib.ctx(0)
 for nbytes in (2048, 64 << 10, 2600 << 10, 40 << 20):
     dev = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    x_rt = np.full(nbytes, 7, np.uint8)
-    x_lib = np.full(nbytes, 9, np.uint8)
-    out = {"bytes": nbytes, "heap_or_mmap": "heap" if x_rt.ctypes.data < (1 << 46) else "mmap", "before": known(x_rt.ctypes.data)}
-    dev.copy_(torch.from_numpy(x_rt))
+    x = np.full(nbytes, 7, np.uint8)
     torch.cuda.synchronize()
-    out["after_runtime_copy_h2d"] = known(x_rt.ctypes.data)
+    print(f"PROBE runtime_h2d {nbytes}", file=sys.stderr, flush=True)
+    dev.copy_(torch.from_numpy(x))
+    torch.cuda.synchronize()
+    print(f"PROBE runtime_d2h {nbytes}", file=sys.stderr, flush=True)
     back = dev.cpu()
-    out["after_runtime_copy_d2h_fresh_tensor"] = known(back.data_ptr())
-    _lib.copy_to_device(x_lib, dev)
-    out["after_library_copy_h2d"] = known(x_lib.ctypes.data)
+    print(f"PROBE library_h2d {nbytes}", file=sys.stderr, flush=True)
+    _lib.copy_to_device(x, dev)
+    print(f"PROBE library_d2h {nbytes}", file=sys.stderr, flush=True)
     y = _lib.copy_to_host(dev, np.uint8)
-    out["after_library_copy_d2h"] = known(y.ctypes.data)
-    assert int(y[0]) == 9 and int(back[0]) == 7
-    print(json.dumps(out), flush=True)
+    print(f"PROBE end {nbytes}", file=sys.stderr, flush=True)
+    assert int(y[0]) == 7 and int(back[0]) == 7
