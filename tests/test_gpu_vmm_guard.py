@@ -186,3 +186,50 @@ def test_the_sequence_of_round_5s_abort_in_a_loop(oracle, monkeypatch, cycles):
     assert res["mismatches"] == 0 and res["faults"] == 0, res
     _lib.lib().tvdn_release_cache()
     assert _lib.mem_status(0)["blocks"] == 0
+
+
+_PIN_CHILD = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import torch
+import cytvdn_amd as tv
+from cytvdn_amd import synth
+x = synth.cube((40, 8, 32, 64), seed=5, dtype=np.float32) + np.float32(0.25)       # 2.6 MB: the size of the abort
+ref = synth.cube((40, 8, 32, 64), seed=6, dtype=np.float32)
+mu = np.array([1.0, 1.0, 0.5, 0.5], np.float32)
+tv.denoise4D(x, mu, 2, quiet=True)                                                # (first use: module load, lanes)
+print("PRODUCT BEGIN", file=sys.stderr, flush=True)
+tv.denoise4D(x, mu, [5, 3], FISTA=True, quiet=True)                               # tvdn_run, resident, torch workspace
+tv.denoise4D(x, mu, 200, FISTA=True, quiet=True)                                  # traces of 200 x 3 doubles come home
+tv.denoise4D(x, mu, 6, FISTA=True, reference_data=ref, quiet=True)                # MSE trace: the reference cube goes up too
+os.environ["TVDN_LOOP"] = "python"
+tv.denoise4D(x, mu, 6, FISTA=True, reference_data=ref, stopping_relative_change=1e-9, quiet=True)   # the loop in Python
+os.environ.pop("TVDN_LOOP")
+os.environ["TVDN_HBM_LIMIT"] = "24M"
+tv.denoise4D(x, mu, [5, 3], FISTA=True, quiet=True)                               # streamed
+tv.denoise3D(x[0].copy(), mu[:3], 5, quiet=True)
+print("PRODUCT END", file=sys.stderr, flush=True)
+t = torch.from_numpy(x).cuda()                                                    # the runtime's own path, for comparison
+print("RUNTIME END", file=sys.stderr, flush=True)
+"""
+
+
+def test_the_library_never_lets_the_runtime_pin_the_callers_memory():
+    """The abort of profiles/r06_abort_found.txt: for a copy from / to pageable memory above a few KiB the ROCm runtime pins the
+    caller's pages IN PLACE and caches the pin by address and size; the cache outlives the memory, and a later copy from a new
+    array on the same address faults on the GPU.  The library must never make that kind of call: under AMD_LOG_LEVEL=4 the
+    runtime says "HSA Copy Using Pinned resource size N" whenever it does, and between the markers -- resident, streamed, MSE,
+    Python-loop and 3-D calls on a 2.6 MB cube, the very size of the abort -- that line must not appear (torch's own copy
+    after the markers shows that the check can see it)."""
+    env = dict(os.environ)
+    env["AMD_LOG_LEVEL"] = "4"
+    p = subprocess.run([sys.executable, "-c", _PIN_CHILD.format(root=ROOT)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       errors="replace", timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    err = p.stderr
+    a, b, c = err.index("PRODUCT BEGIN"), err.index("PRODUCT END"), err.index("RUNTIME END")
+    inside = [l for l in err[a:b].splitlines() if "Copy Using Pinned resource" in l]
+    after = [l for l in err[b:c].splitlines() if "Copy Using Pinned resource" in l]
+    assert after, "the runtime no longer reports its pinned-in-place copies at this log level: the check above proves nothing"
+    assert not inside, inside[:3]
