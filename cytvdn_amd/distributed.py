@@ -164,14 +164,26 @@ def denoise_slabs(my_rows, global_shape, mu, iterations=10, FISTA=True, stopping
         run.iter = n_f
     if unacc:
         run.run(0, n_p, on_iter)
-    sums = run.global_sums().cpu().numpy()[:n]
+    gs = run.global_sums()
+    # (device memory comes home through the library's pinned lanes, never through the runtime's path for pageable memory, which pins
+    # the destination in place and caches the pin beyond the array's life: profiles/r06_abort_found.txt; test backends are host-side)
+    sums = (_to_host(gs, np.float64, device) if gs.is_cuda else gs.numpy())[:n]
     ran = np.zeros(n, dtype=bool)
     ran[run.ran] = True
     b_norm = np.where(ran, sums[:, 0], 0.0).astype(dtype)
     with np.errstate(divide="ignore", invalid="ignore"):
         delta = np.where(ran, sums[:, 1].astype(dtype) / sums[:, 2].astype(dtype), dt(0)).astype(dtype)
     own = be.recon_tensor()[lay.row_lo:lay.row_hi]
-    return (own if is_t and my_rows.is_cuda else own.cpu().numpy()), b_norm, delta
+    if is_t and my_rows.is_cuda:
+        return own, b_norm, delta
+    return (_to_host(own, dtype, device) if own.is_cuda else own.numpy()), b_norm, delta
+
+
+def _to_host(t, dtype, device):
+    """A device tensor as a fresh NumPy array, through the library's pinned lanes (csrc/tvdn_hostio.hip)."""
+    from . import _lib
+    torch.cuda.current_stream(int(device) if not isinstance(device, torch.device) else device).synchronize()
+    return _lib.copy_to_host(t.contiguous(), dtype)
 
 
 class _RankHooks:

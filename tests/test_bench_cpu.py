@@ -59,5 +59,5 @@ def test_traffic_json_is_what_the_script_makes_of_the_committed_csvs(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_traffic_json
     out = tmp_path / "traffic.json"
-    make_traffic_json.write_traffic("r05", str(out))
+    make_traffic_json.write_traffic("r06", str(out))
     assert out.read_bytes() == open(os.path.join(ROOT, "profiles", "traffic.json"), "rb").read()
