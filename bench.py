@@ -89,6 +89,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of each timed CPU leg")
     ap.add_argument("--no-preflight", action="store_true", help="N > 1: skip the bit-exactness check of the exchange")
+    ap.add_argument("--watchdog-s", type=float, default=1500.0,
+                    help="N > 1: seconds after which a run that is stuck (a collective that never returns) says where, as a JSON line with "
+                         "\"error\", and ends every rank -- instead of hanging until someone kills it and leaving no record (0: off)")
     ap.add_argument("--cpu-child", type=str, default=None, metavar="NPY",
                     help="internal: run ONLY the CPU baseline on the cube saved at NPY ('' = the 1/16 sample) and print its JSON")
     return ap.parse_args()
@@ -558,6 +561,33 @@ def init_groups(local_rank):
     return None, "gloo", True
 
 
+class Watchdog:
+    """N > 1 only.  RCCL has not met a second GPU in any round: if a collective never returns, every rank is stuck in C++ with no way
+    out and the run leaves nothing behind.  A timer thread (it runs while the main thread waits with the GIL released) then prints
+    ONE JSON line from rank 0 -- the metric's name, value null, the stage the run was in -- on the real stdout and ends the process."""
+
+    def __init__(self, seconds, rank, world, a):
+        import threading
+        self.stage, self.rank, self.world, self.a, self.fd = "start", rank, world, a, None
+        self.timer = threading.Timer(seconds, self.fire) if seconds > 0 and world > 1 else None
+        if self.timer:
+            self.timer.daemon = True
+            self.timer.start()
+
+    def fire(self):
+        if self.rank == 0:
+            line = json.dumps({"metric": "Gvoxel-iters/s (4D aniso FISTA)", "value": None, "unit": "Gvoxel-iters/s", "n_gpus": self.world,
+                               "steps": self.a.steps, "warmup": self.a.warmup, "higher_is_better": True, "scaling": "weak",
+                               "error": f"watchdog: no result after {self.a.watchdog_s:.0f} s; the run was in stage '{self.stage}' "
+                                        "(a collective that never returned?); TVDN_DIST_BACKEND=gloo measures with host-staged halo rows"})
+            os.write(self.fd if self.fd is not None else 1, (line + "\n").encode())
+        os._exit(4)
+
+    def done(self):
+        if self.timer:
+            self.timer.cancel()
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -599,13 +629,17 @@ def main():
     torch.cuda.set_device(local_rank)
     group, transport, fallback, preflight = None, None, False, None
     overlap = True
+    dog = Watchdog(a.watchdog_s, rank, world, a)
     if world > 1:
         # libraries chat on stdout while the groups come up ("[Gloo] Rank 0 is connected to ..."): stdout is for the
         # one JSON line, so file descriptor 1 points at stderr until the measurement starts
         sys.stdout.flush()
         saved_stdout = os.dup(1)
+        dog.fd = saved_stdout
         os.dup2(2, 1)
+        dog.stage = "process groups (gloo control plane, RCCL data plane)"
         group, transport, fallback = init_groups(local_rank)
+        dog.stage = "pre-flight: exchange self-check on plain memory"
         if not a.no_preflight:
             from cytvdn_amd.distributed import selfcheck_exchange
             preflight = selfcheck_exchange(group=group, device=local_rank)
@@ -619,6 +653,7 @@ def main():
             if preflight["blocking"] and os.environ.get("TVDN_VMM", "1") != "0":
                 # (on_granules=True: the check's states are forced onto granules, says what they really were -- "state_mem" --
                 # and counts anything else as failed: a check that ran on plain memory proves nothing about granules)
+                dog.stage = "pre-flight: exchange self-check with the states on granules"
                 pg = selfcheck_exchange(group=group, device=local_rank, on_granules=True)
                 preflight["on_granules"] = {k: pg[k] for k in ("overlap", "blocking", "error", "state_mem")}
                 if not pg["blocking"]:
@@ -631,6 +666,7 @@ def main():
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
+        dog.fd = None
 
     dtype_name = a.dtype
     if a.shape:
@@ -645,8 +681,10 @@ def main():
     except Exception:
         traffic_table = None
 
+    dog.stage = f"measurement ({a.warmup} + {a.steps} steps, transport {transport}, overlap {overlap})"
     main_res = measure(shape, dtype_name, fista, a.state, a.steps, a.warmup, local_rank, rank, world, group,
                        a.slab_of, overlap, traffic_table, a.audition)
+    dog.stage = "after the measurement"
 
     also = None
     headline = world == 1 and not a.slab_of and not a.shape and dtype_name == "f32" and fista
@@ -791,7 +829,9 @@ def main():
             out["also"] = (also or []) + (api or [])
         print(json.dumps(out), flush=True)
     if world > 1:
+        dog.stage = "final barrier"
         dist.barrier()
+        dog.done()
         dist.destroy_process_group()
 
 

@@ -255,6 +255,16 @@ size_t state_kept_bytes(int device);  // counts as free: the next run takes it o
 // the state's allocation itself (granules unless told otherwise: tvdn_devmem.hip), and the shape of a resident run's pipelined transfers
 hipError_t state_malloc(void **p, size_t bytes, int device, bool granules = true, double spread_budget_s = 0.25, const int *peers = nullptr, int n_peers = 0);
 void pipeline_plan(int64_t n0, int64_t n_total, int64_t cube_bytes, int32_t out[3]);
+// tvdn_run_state.hip: before a device list runs on granule blocks that neighbours on other devices read -- does a peer copy out of
+// every such block arrive intact?  (one entry per slab: its block, device, local rows, own rows, halo rows held, copy stream)
+struct PeerSlab {
+    void *state;
+    int device;
+    int64_t rows, row_lo, row_hi;
+    bool halo_lo, halo_hi;
+    hipStream_t copy;
+};
+bool slab_peer_copy_check(const PeerSlab *sl, int world, size_t row_bytes, int nd, int per_axis, char *why, size_t why_len);
 // tvdn_devmem.hip: device memory composed from physical granules (big blocks) or plain hipMalloc; dev_free takes either
 struct DevAllocInfo {  // what a block of granules was made from (all zero for a plain block)
     int64_t granule_bytes;

@@ -1,8 +1,10 @@
 // What a tvdn_run keeps and what it costs: the state block kept between runs (one per device), the arithmetic of check_memory for
 // HBM (tvdn_plan), the shape of a resident run's pipelined transfers, and the small C entries around them (include/tvdn.h).
 // Split from tvdn_run.hip in round 5 (no file of csrc/ above 1000 lines).
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
+#include <vector>
 
 #include "tvdn_common.hpp"
 
@@ -130,6 +132,54 @@ void pipeline_plan(int64_t n0, int64_t n_total, int64_t cube_bytes, int32_t out[
     out[1] = (int32_t)std::min<int64_t>(8, n_total / 2);
     out[2] = (int32_t)std::min<int64_t>(8, n_total - out[1]);
 }
+
+// Several slabs whose blocks are made of granules: does a peer copy out of such a block arrive intact?  For every slab and
+// each neighbour whose rows it will pull: a pattern goes into the neighbour's block where its outermost own row of recon[1]
+// lies (the runtime's host-to-device copy), is pulled across with the run's own call (hipMemcpyPeerAsync on the copy stream)
+// into this slab's halo row, and read back (device-to-host).  64 KiB per pair, at the END of the row -- in a block of several
+// granules that is as far from the block's first granule as the rows a run moves.  Leaves the touched bytes zero.
+bool slab_peer_copy_check(const PeerSlab *sl, int world, size_t row_bytes, int nd, int per_axis, char *why, size_t why_len)
+{
+    const size_t n = std::min<size_t>(row_bytes, 65536);
+    std::vector<unsigned char> pat(n), got(n);
+    auto fail = [&](const char *what, hipError_t e, int r, int d) {
+        (void)hipGetLastError();
+        snprintf(why, why_len, "%s, slab %d (device %d) <- slab %d (device %d): %s", what, r, sl[r].device, d, sl[d].device, e == hipSuccess ? "bytes differ" : hipGetErrorString(e));
+        return false;
+    };
+    for (int r = 0; r < world; ++r) {
+        const PeerSlab &s = sl[r];
+        const size_t s_stride = ((size_t)s.rows * row_bytes + 255) / 256 * 256 + 4096;
+        char *s_recon1 = (char *)s.state + s_stride * (size_t)(nd * per_axis);  // Slab::assign: recon[1] follows the rotating arrays
+        for (int side = 0; side < 2; ++side) {
+            if (side == 0 ? !s.halo_lo : !s.halo_hi) continue;
+            const int d = side == 0 ? (r + world - 1) % world : (r + 1) % world;
+            const PeerSlab &o = sl[d];
+            const size_t o_stride = ((size_t)o.rows * row_bytes + 255) / 256 * 256 + 4096;
+            char *o_recon1 = (char *)o.state + o_stride * (size_t)(nd * per_axis);
+            char *src = o_recon1 + (size_t)(side == 0 ? o.row_hi - 1 : o.row_lo) * row_bytes + (row_bytes - n);
+            char *dst = s_recon1 + (size_t)(side == 0 ? s.row_lo - 1 : s.row_hi) * row_bytes + (row_bytes - n);
+            for (size_t i = 0; i < n; ++i) pat[i] = (unsigned char)(0x5b + 131 * i + 17 * r + 3 * side);
+            hipError_t e = hipSetDevice(o.device);
+            if (e == hipSuccess && tvdn_copy_to_device(src, pat.data(), n, o.device) != TVDN_OK) e = hipErrorUnknown;  // (pinned lanes: tvdn_hostio.hip)
+            if (e != hipSuccess) return fail("writing the pattern", e, r, d);
+            e = hipSetDevice(s.device);
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(dst, s.device, src, o.device, n, s.copy);
+            if (e == hipSuccess) e = hipStreamSynchronize(s.copy);
+            if (e != hipSuccess) return fail("the peer copy", e, r, d);
+            std::fill(got.begin(), got.end(), 0);
+            if (tvdn_copy_to_host(got.data(), dst, n, s.device) != TVDN_OK) e = hipErrorUnknown;
+            if (e != hipSuccess) return fail("reading the copy back", e, r, d);
+            if (got != pat) return fail("the peer copy", hipSuccess, r, d);
+            e = hipMemset(dst, 0, n);
+            if (e == hipSuccess) e = hipSetDevice(o.device);
+            if (e == hipSuccess) e = hipMemset(src, 0, n);
+            if (e != hipSuccess) return fail("clearing the pattern", e, r, d);
+        }
+    }
+    return true;
+}
+
 
 }  // namespace tvdn
 

@@ -59,3 +59,19 @@ def test_two_rank_rehearsal_line():
     assert d["config"]["transport"] == "gloo" and d["transport_fallback"] is False
     assert d["preflight"]["blocking"] is True and d["preflight"]["overlap"] is True and d["preflight"]["error"] is None
     assert d["config"]["parallelism"] == "slab2" and d["cpu_baseline"] is None
+
+
+def test_a_stuck_multi_rank_run_leaves_a_line_behind():
+    """RCCL has not met a second GPU in any round.  Should a collective never return there, bench.py's watchdog (a timer thread:
+    it runs while the main thread waits in C++) prints ONE JSON line from rank 0 -- value null, the stage the run was in -- and
+    ends every rank, instead of hanging until the driver kills it with nothing on stdout.  Rehearsed over gloo with a watchdog
+    far shorter than the run: the line must come, well-formed, and name a stage."""
+    e = dict(os.environ)
+    e["TVDN_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shape", "16x16x32x64", "--steps", "3", "--warmup", "1",
+                        "--watchdog-s", "0.05"], capture_output=True, text=True, env=e, timeout=600)
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, (p.stdout[:500], p.stderr[-800:])
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and "watchdog" in d["error"] and "stage" in d["error"]
+    assert p.returncode != 0
