@@ -488,7 +488,9 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
         // ---- start: chunks go up on a helper thread; the first k0 iterations follow them ---------------------------------
         Slab &s = sl[0];
         TVDN_HIP(hipSetDevice(s.device));
-        TVDN_HIP(hipStreamSynchronize(s.main));  // the fills of the state are done before rows land beside them
+        // (No wait for the fill of the state here, since round 6: it covers the arrays BEFORE `orig` -- the rotating arrays and
+        // recon[1] -- and the rows that go up land in `orig` alone; whatever reads or writes the filled arrays is queued behind the
+        // fill on s.main.  52 GiB of zeros take 10 ms: as long as the first chunk's way up, which now runs beside them.)
         const int64_t n_up = (N0 + pipe_R - 1) / pipe_R;
         std::mutex mu;
         std::condition_variable cv;
