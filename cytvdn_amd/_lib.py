@@ -32,7 +32,7 @@ EXPORTS = (
     "tvdn_synth_fill", "tvdn_run", "tvdn_pipeline_plan", "tvdn_run_workspace_bytes", "tvdn_release_cache", "tvdn_copy_to_device", "tvdn_copy_to_host", "tvdn_iterate_many", "tvdn_plan", "tvdn_copy_many", "tvdn_stream_mix", "tvdn_stream_mix_march",
     "tvdn_stream_host_need", "tvdn_stream_plan", "tvdn_wait_background", "tvdn_slab_host_need", "tvdn_slab_row_map", "tvdn_fista_ratios", "tvdn_iter_mode", "tvdn_roles_bind", "tvdn_roles_advance",
     "tvdn_mem_alloc", "tvdn_mem_free", "tvdn_state_kept_bytes", "tvdn_recon_from_state",
-    "tvdn_mem_alloc_shared", "tvdn_mem_status", "tvdn_mem_selftest", "tvdn_mem_resize",
+    "tvdn_mem_alloc_shared", "tvdn_mem_status", "tvdn_mem_selftest", "tvdn_mem_resize", "tvdn_warm_up",
 )
 CANARY_NOT_RUN, CANARY_PASSED, CANARY_STALE, CANARY_FAILED = 0, 1, -1, -2
 MEM_PLAIN, MEM_GRANULES, MEM_CALLER = 0, 1, 2
@@ -211,6 +211,7 @@ def lib():
     L.tvdn_mem_status.argtypes = [C.c_int, C.POINTER(MemStatus)]
     L.tvdn_mem_selftest.argtypes = [C.c_int]
     L.tvdn_mem_resize.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int]
+    L.tvdn_warm_up.argtypes = [C.c_int]
     L.tvdn_state_kept_bytes.argtypes = [C.c_int]
     L.tvdn_state_kept_bytes.restype = C.c_int64
     for name in EXPORTS:

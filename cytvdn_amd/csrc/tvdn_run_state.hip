@@ -223,6 +223,32 @@ extern "C" int tvdn_plan(int dtype, int ndim, const int64_t *shape, int fista, i
     return TVDN_OK;
 }
 
+// What the first tvdn_run of a process pays once, paid now instead: the pinned staging lanes (tvdn_hostio.hip), the first streams of
+// the two priority classes a run uses (the first stream of a class costs ~30 ms, later ones 1 ms), the reduction scratch, the
+// library's code object on the device (its first kernel), and the allocator's canary.  Everything here is idempotent.
+extern "C" int tvdn_warm_up(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) {
+        tvdn::set_error("no HIP device visible: the product path needs an MI355X (gfx950); there is no CPU fallback");
+        return TVDN_ERR_NO_DEVICE;
+    }
+    TVDN_REQUIRE(device >= 0 && device < n, "device %d out of range (0..%d)", device, n - 1);
+    tvdn::DeviceRestore restore;
+    TVDN_HIP(hipSetDevice(device));
+    tvdn::io_warm(device);
+    hipStream_t hi = nullptr, lo = nullptr;
+    int rc = tvdn::make_stream(&hi, +1);
+    if (!rc) rc = tvdn::make_stream(&lo, 0);
+    if (hi) (void)hipStreamDestroy(hi);
+    if (lo) (void)hipStreamDestroy(lo);
+    if (rc) return rc;
+    tvdn_ctx *c = nullptr;
+    if ((rc = tvdn_ctx_create(&c, device))) return rc;
+    (void)tvdn_ctx_destroy(c);
+    return tvdn_mem_selftest(device) == TVDN_OK ? TVDN_OK : TVDN_OK;  // (a tripped canary is not an error of the warm-up: the device serves plain blocks)
+}
+
 extern "C" int64_t tvdn_state_kept_bytes(int device) { return (int64_t)tvdn::state_kept_bytes(device); }
 
 extern "C" int tvdn_release_cache(void)

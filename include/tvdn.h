@@ -477,6 +477,12 @@ int tvdn_mem_status(int device, tvdn_mem_status_out *out);
  * (either way the device is marked and tvdn_last_error() says what was seen). */
 int tvdn_mem_selftest(int device);
 
+/* ABI 9.  Optional: what the FIRST tvdn_run of a process pays once -- the pinned staging lanes, the first stream of each priority
+ * class, the reduction scratch, the library's code object on the device, the allocator's canary: 0.1-0.15 s together -- paid
+ * now, e.g. on a helper thread while the caller still reads its cube from disk.  Idempotent; TVDN_OK, or a status when no device
+ * is there.  The reference has no counterpart (its first call pays for nothing of the kind). */
+int tvdn_warm_up(int device);
+
 /* ABI 7.  Bytes of the block the last one-device tvdn_run on `device` kept for the next one (0: none): device memory that
  * hipMemGetInfo reports as used but that the next tvdn_run takes over or releases, i.e. free for planning purposes
  * (cytvdn_amd/planner.py adds it to what the device has free; tvdn_plan and tvdn_stream_plan do so themselves). */

@@ -32,7 +32,7 @@ class BuildPy(build_py):
 
 setup(
     name="cytvdn_amd",
-    version="0.5.0",
+    version="0.6.0",
     description="MI355X-native anisotropic TV denoising behind the cyTVDN API (denoise3D / denoise4D)",
     packages=["cytvdn_amd"],
     package_data={"cytvdn_amd": ["libtvdn_hip.so"]},

@@ -233,3 +233,16 @@ def test_the_library_never_lets_the_runtime_pin_the_callers_memory():
     after = [l for l in err[b:c].splitlines() if "Copy Using Pinned resource" in l]
     assert after, "the runtime no longer reports its pinned-in-place copies at this log level: the check above proves nothing"
     assert not inside, inside[:3]
+
+
+def test_warm_up_is_idempotent_and_leaves_a_healthy_allocator():
+    """cytvdn_amd.warm_up (tvdn.h tvdn_warm_up): the one-time set-up of a process's first call, on demand, on a helper thread or
+    not, as often as one likes; afterwards the canary has run and passed and a denoise call gives the oracle's bits as ever."""
+    import cytvdn_amd as tv
+    from cytvdn_amd import _lib
+    tv.warm_up(0)
+    t = tv.warm_up(0, background=True)
+    t.join(60)
+    assert not t.is_alive()
+    st = _lib.mem_status(0)
+    assert st["canary"] == _lib.CANARY_PASSED and st["faults"] == 0

@@ -2,7 +2,8 @@
 """GPU box, fresh process: what the FIRST denoise4D of a process pays over the second.  `--warm` names what is
 done before the first call: nothing; `lanes` = one 512 MiB upload + download through the library's pinned staging lanes into a
 scratch tensor (csrc/tvdn_hostio.hip io_init: 16 hipHostMalloc of 16 MiB, 8 streams); `clock` = 0.3 s of sweeps on a small
-state (clocks up); `pool` = a 60 GiB granule block allocated and freed (memory the driver has touched).  One JSON line per call;
+state (clocks up); `pool` = a 60 GiB granule block allocated and freed (memory the driver has touched); `api` = the product's
+own `cytvdn_amd.warm_up()` (lanes, first priority streams, code object, canary).  One JSON line per call;
 TVDN_RUN_TIMING=1 adds tvdn_run's phases on stderr."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,6 +38,8 @@ for w in warm:
         while time.perf_counter() - t1 < 0.3:
             s.add_(1.0)
         torch.cuda.synchronize(); del s; torch.cuda.empty_cache()
+    elif w == "api":
+        tv.warm_up(0)
     elif w == "pool":
         b = _lib.DeviceBlock(61 << 30, 0); b.free()
     t_warm[w] = round(time.perf_counter() - t0, 3)
