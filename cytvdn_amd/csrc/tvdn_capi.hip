@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) fold_kernel(const double *partials, int n
 }
 
 __global__ void __launch_bounds__(1024) finalize_kernel(const double *partials, int nblocks, int nv,
-                                                         double *out, int accumulate)
+                                                         double *out, int accumulate, double *mirror)
 {
     __shared__ double red[kPartialWidth][16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -57,7 +57,9 @@ __global__ void __launch_bounds__(1024) finalize_kernel(const double *partials, 
     if ((int)threadIdx.x < nv) {
         double s = 0.0;
         for (int i = 0; i < 16; ++i) s += red[threadIdx.x][i];
-        out[threadIdx.x] = accumulate ? out[threadIdx.x] + s : s;
+        if (accumulate) s = out[threadIdx.x] + s;
+        out[threadIdx.x] = s;
+        if (mirror) mirror[threadIdx.x] = s;  // (tvdn_ctx::mirror: host memory the device can write)
     }
 }
 
@@ -163,7 +165,7 @@ int launch_finalize(tvdn_ctx *ctx, int nblocks, int nv, double *out, hipStream_t
         src = ctx->partials2;
         nblocks = g1;
     }
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, s, src, nblocks, nv, out, accumulate ? 1 : 0);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, s, src, nblocks, nv, out, accumulate ? 1 : 0, ctx->mirror);
     TVDN_HIP(hipGetLastError());
     return TVDN_OK;
 }
@@ -295,6 +297,7 @@ int tvdn_ctx_create(tvdn_ctx **out, int device)
     c->deferring = false;
     c->n_pend = 0;
     c->timing = false;
+    c->mirror = nullptr;
     hipError_t e = hipMalloc((void **)&c->partials, sizeof(double) * (size_t)kInitPartialBlocks * kPartialWidth);
     if (e == hipSuccess)
         e = hipMalloc((void **)&c->partials2, sizeof(double) * (size_t)(kMaxPartialBlocks / kFoldSegment) * kPartialWidth);

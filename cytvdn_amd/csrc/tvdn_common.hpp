@@ -181,6 +181,9 @@ struct tvdn_ctx {
     double *pend_out[32];
     bool timing;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // pending (start, stop) pairs
+    // Where the NEXT finalize also leaves its sums (device-visible host memory, nullptr: nowhere): a resident tvdn_run with a
+    // stopping rule looks at every iteration's sums while the next iteration already runs (tvdn_run.hip) -- no copy in the stream
+    double *mirror;
 };
 
 namespace tvdn {

@@ -51,6 +51,10 @@ struct Slab {
     tvdn_ctx *ctx = nullptr;
     hipStream_t main = nullptr, copy = nullptr;
     hipEvent_t edge_done = nullptr, halo_done = nullptr;
+    // a run with a stopping rule (run_impl, "speculation by one"): the sums of the last two iterations as the device left them in
+    // host memory (two slots of four doubles), and the event behind each slot's last fold
+    double *peek = nullptr;
+    hipEvent_t summed[2] = {nullptr, nullptr};
     DevBuf state;  // ONE allocation: per axis 2-3 rotating arrays, recon x2, orig
     DevBuf ref, sums, mse;
     tvdn_many_args roles;  // arrays and who plays which role (tvdn_common.hpp roles_bind / roles_advance); .base = the sweep's fixed arguments
@@ -75,6 +79,12 @@ struct Slab {
         (void)hipSetDevice(device);
         if (edge_done) (void)hipEventDestroy(edge_done);
         if (halo_done) (void)hipEventDestroy(halo_done);
+        for (hipEvent_t e : summed)
+            if (e) (void)hipEventDestroy(e);
+        if (peek) {
+            if (main) (void)hipStreamSynchronize(main);  // (an error path: a fold that still writes there)
+            (void)hipHostFree(peek);
+        }
         if (main) (void)hipStreamDestroy(main);
         if (copy) (void)hipStreamDestroy(copy);
         if (ctx) (void)tvdn_ctx_destroy(ctx);
@@ -577,6 +587,7 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
     }
 
     int ran = 0, ran_phase[2] = {0, 0};
+    std::vector<int> void_slots;  // iterations that ran ahead of a stopping rule in vain: their trace entries go home as zeros
     auto cur_of = [&]() { return (int)sl[0].roles.cur; };  // every slab rotates in lockstep
 
     // one launch on slab s over rows [lo, hi) of its own rows (0, 0 = all)
@@ -587,7 +598,10 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
         it.sweep_hi = hi;
         it.accumulate = accumulate ? 1 : 0;
         TVDN_HIP(hipSetDevice(s.device));
-        return tvdn_iterate_fused(s.ctx, &it, (double *)s.sums.p + 3 * (size_t)slot, s.main);
+        s.ctx->mirror = s.peek ? s.peek + 4 * (slot & 1) : nullptr;  // (a stopping rule that looks one iteration behind: below)
+        const int rc = tvdn_iterate_fused(s.ctx, &it, (double *)s.sums.p + 3 * (size_t)slot, s.main);
+        s.ctx->mirror = nullptr;
+        return rc;
     };
 
     auto one = [&](int slot, bool use_fista, double ratio) -> int {
@@ -813,6 +827,89 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
         ran = n_total;
         ran_phase[0] = a->n_fista;
         ran_phase[1] = a->n_plain;
+    } else if (a->use_stop && n_total > 0 && !(getenv("TVDN_STOP_LAG") && atoi(getenv("TVDN_STOP_LAG")) == 0)) {
+        // ---- a stopping rule, looked at one iteration behind ---------------------------------------------------------------
+        // Upstream reads delta_recon[i] after iteration i and breaks (cyTVDN.py:189-195, :231-237).  Done in stream order that is a
+        // round trip per iteration -- launch, sweep, fold, copy of three doubles, wake-up: 27-29 us on top of a sweep of 12 us for a
+        // 64 x 64 x 256 cube and 70 us for BASELINE configs[0]'s shape (profiles/r06_stop_rule.jsonl: 2.7 x and 1.34 x the time of
+        // the same run without a rule).  So iteration i+1 is queued BEFORE the sums of iteration i are looked at: the fold of an
+        // iteration leaves them in host memory as well (tvdn_ctx::mirror), an event behind it says when, and the device never waits
+        // for the host.  If iteration i did satisfy the rule, iteration i+1 has run in vain and is taken back: it read the state
+        // iteration i left and wrote into the buffers that rotate out (recon[cur ^ 1], the oldest array of every axis), so putting
+        // the roles back IS the state after iteration i, bit for bit; its sums and MSE slots are zeroed on the way home, as the
+        // tails upstream leaves.  TVDN_STOP_LAG=0: the blocking form (tests compare the two).
+        for (int r = 0; r < world; ++r) {
+            Slab &s = sl[r];
+            TVDN_HIP(hipSetDevice(s.device));
+            TVDN_HIP(hipHostMalloc((void **)&s.peek, 8 * sizeof(double), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(s.peek, 0, 8 * sizeof(double));
+            for (hipEvent_t &e : s.summed) TVDN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        auto post = [&](int slot) -> int {  // the folds of `slot` are queued on every slab: mark their end
+            for (int r = 0; r < world; ++r) {
+                TVDN_HIP(hipSetDevice(sl[r].device));
+                TVDN_HIP(hipEventRecord(sl[r].summed[slot & 1], sl[r].main));
+            }
+            return TVDN_OK;
+        };
+        auto rule_met = [&](int slot, bool &stop) -> int {
+            double tot[3] = {0.0, 0.0, 0.0};
+            for (int r = 0; r < world; ++r) {  // the global criterion: sums over every slab, in slab order
+                hipEvent_t ev = sl[r].summed[slot & 1];
+                const auto t0 = std::chrono::steady_clock::now();
+                for (;;) {  // short iterations: ask; long ones: sleep on it
+                    const hipError_t e = hipEventQuery(ev);
+                    if (e == hipSuccess) break;
+                    if (e != hipErrorNotReady) TVDN_HIP(e);
+                    (void)hipGetLastError();
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
+                        TVDN_HIP(hipEventSynchronize(ev));
+                        break;
+                    }
+                }
+                const volatile double *pk = sl[r].peek + 4 * (slot & 1);
+                for (int j = 0; j < 3; ++j) tot[j] += pk[j];
+            }
+            const double delta = a->dtype == TVDN_F32 ? (double)delta_in_dtype<float>(tot) : delta_in_dtype<double>(tot);
+            stop = delta < a->stop;
+            return TVDN_OK;
+        };
+        std::vector<tvdn_many_args> before((size_t)world);
+        int slot = 0;
+        int rc = one(0, is_fista(0), ratios[0]);
+        if (!rc) rc = post(0);
+        if (rc) return rc;
+        while (slot >= 0) {
+            const int ahead = slot + 1 < n_total ? slot + 1 : -1;
+            if (ahead >= 0) {
+                for (int r = 0; r < world; ++r) before[(size_t)r] = sl[r].roles;
+                rc = one(ahead, is_fista(ahead), ratios[ahead]);
+                if (!rc) rc = post(ahead);
+                if (rc) return rc;
+            }
+            ++ran_phase[is_fista(slot) ? 0 : 1];
+            tick(slot + 1);
+            bool st;
+            rc = rule_met(slot, st);
+            if (rc) return rc;
+            if (!st) {
+                slot = ahead;
+                continue;
+            }
+            // a FISTA-phase stop falls through to the unaccelerated phase (cyTVDN.py:189-201); a stop there ends the run
+            const int resume = (is_fista(slot) && a->n_plain > 0) ? a->n_fista : -1;
+            if (ahead >= 0 && ahead != resume) {  // iteration `ahead` ran in vain
+                for (int r = 0; r < world; ++r) sl[r].roles = before[(size_t)r];
+                --ran;
+                void_slots.push_back(ahead);
+                if (resume >= 0) {
+                    rc = one(resume, false, 0.0);
+                    if (!rc) rc = post(resume);
+                    if (rc) return rc;
+                }
+            }
+            slot = resume;
+        }
     } else {
         for (int i = 0; i < a->n_fista; ++i) {
             int rc = one(i, true, ratios[i]);
@@ -866,6 +963,10 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
             if (rc) return rc;
             for (int i = 0; i <= n_total; ++i) a->mse_out[i] += tmp[i];
         }
+    }
+    for (int v : void_slots) {
+        for (int j = 0; j < 3; ++j) a->sums_out[3 * (size_t)v + (size_t)j] = 0.0;
+        if (want_mse) a->mse_out[v + 1] = 0.0;
     }
     if (a->iters_run) *a->iters_run = ran;
     if (a->phase_iters) {

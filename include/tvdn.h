@@ -265,7 +265,10 @@ int tvdn_iterate_many(tvdn_ctx *ctx, tvdn_many_args *state, int32_t n_fista, con
  *   mse_out   host, n_fista+n_plain+1 doubles, or NULL; needs `reference` (sum of squared errors)
  *   use_stop  when non-zero a phase ends as soon as delta_recon (formed in the data dtype, as upstream, from
  *             the sums over all slabs) drops below `stop`; a FISTA-phase stop still falls through to the
- *             unaccelerated phase (cyTVDN.py:189-195)
+ *             unaccelerated phase (cyTVDN.py:189-195).  A resident run looks at the sums of iteration i while
+ *             iteration i+1 already runs and takes that one back if the rule was met (same bits as reading them
+ *             in stream order, 7 us instead of 27 us per iteration: profiles/r06_stop_rule.jsonl); TVDN_STOP_LAG=0
+ *             keeps the blocking form
  *   iters_run host, optional: number of iterations executed
  * ---------------------------------------------------------------------------------------- */
 #define TVDN_MAX_DEVICES 16

@@ -1,0 +1,118 @@
+"""A stopping rule looked at one iteration behind (csrc/tvdn_run.hip, "speculation by one"): the resident tvdn_run queues iteration
+i+1 before it reads the sums of iteration i, and takes iteration i+1 back when iteration i satisfied the rule.  Whatever the
+slot the rule fires at -- the first, the last, the last accelerated one of a hybrid run, the middle of either phase -- the result,
+the traces, their zero tails and the iteration counts are the oracle's (cyTVDN.py:189-201: a FISTA-phase break falls through to
+the unaccelerated phase), and the same as the blocking form's (TVDN_STOP_LAG=0)."""
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _thresholds(delta, slots):
+    """for each wanted slot k a threshold that delta first drops below AT k (None where the trace does not allow one)"""
+    out = {}
+    for k in slots:
+        if k >= len(delta) or not np.isfinite(delta[k]) or delta[k] <= 0:
+            continue
+        before = delta[:k]
+        if k == 0:
+            out[k] = float(delta[0]) * 2.0
+        elif before.min() > delta[k] * 1.0001:
+            out[k] = float(np.sqrt(float(before.min()) * float(delta[k])))
+    return out
+
+
+def _call(fn, x, mu, its, fista, thr, refd, bc, devs, lag):
+    kw = {} if devs is None else {"device": devs}
+    prev = os.environ.get("TVDN_STOP_LAG")
+    try:
+        if lag is None:
+            os.environ.pop("TVDN_STOP_LAG", None)
+        else:
+            os.environ["TVDN_STOP_LAG"] = str(lag)
+        return fn(x, mu, its, FISTA=fista, stopping_relative_change=thr, reference_data=refd, BC_mode=bc, quiet=True, **kw)
+    finally:
+        if prev is None:
+            os.environ.pop("TVDN_STOP_LAG", None)
+        else:
+            os.environ["TVDN_STOP_LAG"] = prev
+
+
+@pytest.mark.parametrize("shape,dtype,its,fista,with_ref,bc,devs", [
+    ((9, 6, 8, 12), np.float32, 14, True, False, 2, None),          # FISTA only
+    ((9, 6, 8, 12), np.float32, 14, False, True, 2, None),          # unaccelerated only, MSE trace
+    ((8, 7, 16), np.float64, [8, 7], True, True, 2, None),          # hybrid, 3-D, f64, MSE trace
+    ((10, 5, 8, 8), np.float32, [7, 8], True, False, 0, None),      # hybrid, periodic boundaries
+    ((23, 4, 8, 12), np.float32, [7, 8], True, True, 2, [0, 0, 0]),  # hybrid over three slabs: the global criterion
+    ((16, 6, 16), np.float64, 12, True, False, 0, [0, 0]),          # periodic ring of two slabs
+])
+def test_the_rule_fires_at_every_kind_of_slot(oracle, shape, dtype, its, fista, with_ref, bc, devs):
+    import cytvdn_amd as tv
+    from cytvdn_amd import synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=53, dtype=dt) + dt.type(0.25)
+    refd = synth.cube(shape, seed=53, dtype=dt, kind="mean") if with_ref else None
+    mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
+    fn = tv.denoise4D if nd == 4 else tv.denoise3D
+    n_f, n_p = (its if isinstance(its, list) else ((its, 0) if fista else (0, its)))
+    n = n_f + n_p
+    free = oracle.denoise(x, mu, its, fista, reference_data=refd, BC_mode=bc)
+    d64 = free["delta64"] / free["rnorm64"]
+    # the first slot, the second, the middle of the first phase, its last slot (in a hybrid run the speculated iteration IS the
+    # one to resume with), the last slot of the run (nothing to speculate)
+    first_phase = n_f if n_f else n_p
+    slots = sorted({0, 1, first_phase // 2, first_phase - 1, n - 1})
+    thr = _thresholds(d64, slots)
+    assert len(thr) >= 3, (slots, thr)
+    fired_at = set()
+    for k, t in thr.items():
+        ref = oracle.denoise(x, mu, its, fista, stopping_relative_change=t, reference_data=refd, BC_mode=bc)
+        got = _call(fn, x, mu, its, fista, t, refd, bc, devs, None)
+        blocking = _call(fn, x, mu, its, fista, t, refd, bc, devs, 0)
+        # the two forms: same bits everywhere
+        assert len(got) == len(blocking)
+        for u, v in zip(got, blocking):
+            assert u.dtype == v.dtype and bits_equal(u, v)
+        # the oracle: the result bit for bit, the same slots run, the same zero tails
+        assert bits_equal(got[0], ref["recon"])
+        assert np.array_equal(got[2] != 0, ref["delta_recon"] != 0), (k, got[2], ref["delta_recon"])
+        assert np.array_equal(got[1] != 0, ref["b_norm"] != 0)
+        # (the traces against the oracle's float64 yardsticks: the device sums are float64 trees, the reference's own sums are of
+        #  the data's width and depend on its thread count)
+        tol = 3e-7 if dt == np.float32 else 1e-11
+        ran_mask = ref["delta_recon"] != 0
+        np.testing.assert_allclose(got[1][ran_mask], ref["b_norm64"][ran_mask], rtol=tol)
+        np.testing.assert_allclose(got[2][ran_mask], ref["delta64"][ran_mask] / ref["rnorm64"][ran_mask], rtol=tol)
+        if with_ref:
+            assert np.array_equal(got[3] != 0, ref["MSE"] != 0)
+            np.testing.assert_allclose(got[3], ref["MSE64"], rtol=tol)
+        ran = np.nonzero(ref["delta_recon"])[0]
+        assert ran[0] == 0 and (k in ran)
+        fired_at.add(k)
+        if n_f and n_p and k < n_f - 1:
+            # the accelerated phase stopped early: slots k+1 .. n_f-1 never ran (one of them DID, ahead of the rule, and was taken
+            # back), and the unaccelerated phase started from slot n_f on the state iteration k left
+            assert not got[2][k + 1:n_f].any() and got[2][n_f] != 0
+    assert len(fired_at) >= 3
+
+
+def test_a_rule_that_never_fires_changes_nothing(oracle):
+    """... and the run with a rule nobody meets is the run without one, traces and all."""
+    import cytvdn_amd as tv
+    from cytvdn_amd import synth
+    dt = np.dtype(np.float32)
+    shape = (12, 16, 64)
+    x = synth.cube(shape, seed=59, dtype=dt)
+    mu = np.array([1.0, 1.0, 0.5], dt)
+    plain = tv.denoise3D(x, mu, [9, 6], FISTA=True, quiet=True)
+    ruled = tv.denoise3D(x, mu, [9, 6], FISTA=True, stopping_relative_change=1e-30, quiet=True)
+    for u, v in zip(plain, ruled):
+        assert bits_equal(u, v)
+    ref = oracle.denoise(x, mu, [9, 6], True)
+    assert bits_equal(ruled[0], ref["recon"])
