@@ -569,7 +569,8 @@ class Watchdog:
     def __init__(self, seconds, rank, world, a):
         import threading
         self.stage, self.rank, self.world, self.a, self.fd = "start", rank, world, a, None
-        self.timer = threading.Timer(seconds, self.fire) if seconds > 0 and world > 1 else None
+        # (the other ranks go a little later: a rank that exits first has the launcher end rank 0 before its line is out)
+        self.timer = threading.Timer(seconds + (0.0 if rank == 0 else 15.0), self.fire) if seconds > 0 and world > 1 else None
         if self.timer:
             self.timer.daemon = True
             self.timer.start()

@@ -255,6 +255,18 @@ int run_streamed_rank(const tvdn_run_args *a, int64_t rows, int64_t k);  // one 
 hipError_t state_acquire(void **p, size_t bytes, size_t *got_bytes, int device, bool *reused, bool any_larger, double spread_budget_s = 0.25);
 void state_release(void *p, size_t bytes, int device);
 size_t state_kept_bytes(int device);  // counts as free: the next run takes it over or releases it
+// tvdn_run_state.hip: what a resident run needs beside its state -- reduction context, its two streams, the sums' device buffer -- is
+// kept between runs too (one set per device): creating and destroying them is 1.5-2 ms of hipMalloc / hipFree / stream calls per run,
+// more than the iterations of a short run on a small cube.  tvdn_release_cache() destroys them.
+struct RunKit {
+    tvdn_ctx *ctx = nullptr;
+    hipStream_t main = nullptr, copy = nullptr;
+    int main_level = 0, copy_level = 0;  // make_stream levels the streams were made with
+    void *sums = nullptr;
+    size_t sums_bytes = 0;
+};
+bool kit_acquire(int device, int main_level, int copy_level, RunKit *k);  // true: a kept set with streams of these levels, now the caller's
+void kit_release(int device, RunKit &k);                                  // kept for the next run (idle, reset) or destroyed
 // the state's allocation itself (granules unless told otherwise: tvdn_devmem.hip), and the shape of a resident run's pipelined transfers
 hipError_t state_malloc(void **p, size_t bytes, int device, bool granules = true, double spread_budget_s = 0.25, const int *peers = nullptr, int n_peers = 0);
 void pipeline_plan(int64_t n0, int64_t n_total, int64_t cube_bytes, int32_t out[3]);

@@ -133,15 +133,15 @@ void io_warm(int device)
 }
 
 // One lane of an upload: chunks l, l+n, l+2n, ... of the array.
-static void lane_upload(HostIo *io, int l, int n, char *dst, const char *src, size_t bytes, int *status)
+static void lane_upload(HostIo *io, int l, int n, char *dst, const char *src, size_t bytes, size_t chunk, int *status)
 {
     Lane &L = io->lane[l];
     if (hipSetDevice(io->device) != hipSuccess) { *status = TVDN_ERR_HIP; return; }
-    const size_t nchunks = (bytes + kChunk - 1) / kChunk;
+    const size_t nchunks = (bytes + chunk - 1) / chunk;
     int buf = 0;
     bool used[2] = {false, false};
     for (size_t c = (size_t)l; c < nchunks; c += (size_t)n, buf ^= 1) {
-        const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
+        const size_t off = c * chunk, len = std::min(chunk, bytes - off);
         if (used[buf] && hipEventSynchronize(L.ev[buf]) != hipSuccess) { *status = TVDN_ERR_HIP; return; }
         std::memcpy(L.pin[buf], src + off, len);
         if (hipMemcpyAsync(dst + off, L.pin[buf], len, hipMemcpyHostToDevice, L.stream) != hipSuccess ||
@@ -152,13 +152,13 @@ static void lane_upload(HostIo *io, int l, int n, char *dst, const char *src, si
 }
 
 // One lane of a download: the DMA of the lane's next chunk runs while it copies the current one out.
-static void lane_download(HostIo *io, int l, int n, char *dst, const char *src, size_t bytes, int *status)
+static void lane_download(HostIo *io, int l, int n, char *dst, const char *src, size_t bytes, size_t chunk, int *status)
 {
     Lane &L = io->lane[l];
     if (hipSetDevice(io->device) != hipSuccess) { *status = TVDN_ERR_HIP; return; }
-    const size_t nchunks = (bytes + kChunk - 1) / kChunk;
+    const size_t nchunks = (bytes + chunk - 1) / chunk;
     auto issue = [&](size_t c, int buf) -> bool {
-        const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
+        const size_t off = c * chunk, len = std::min(chunk, bytes - off);
         return hipMemcpyAsync(L.pin[buf], src + off, len, hipMemcpyDeviceToHost, L.stream) == hipSuccess &&
                hipEventRecord(L.ev[buf], L.stream) == hipSuccess;
     };
@@ -169,7 +169,7 @@ static void lane_download(HostIo *io, int l, int n, char *dst, const char *src, 
         const size_t next = c + (size_t)n;
         if (next < nchunks && !issue(next, buf ^ 1)) { *status = TVDN_ERR_HIP; return; }
         if (hipEventSynchronize(L.ev[buf]) != hipSuccess) { *status = TVDN_ERR_HIP; return; }
-        const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
+        const size_t off = c * chunk, len = std::min(chunk, bytes - off);
         std::memcpy(dst + off, L.pin[buf], len);
     }
 }
@@ -197,13 +197,25 @@ static int transfer(bool up, void *dst, const void *src, size_t bytes, int devic
     HostIo &io = g_io[device];
     int rc = io_init(io, device);
     if (rc) return rc;
-    const size_t nchunks = (bytes + kChunk - 1) / kChunk;
+    // Chunks of a whole bounce buffer (16 MiB) for cubes of half a GiB and more; a smaller cube is cut finer, so that every lane
+    // still has four chunks to overlap its memcpy with its DMA: in 16 MiB chunks a 64 MiB cube kept four lanes busy with one
+    // memcpy and one DMA each, one after the other -- 2.0 ms up and 2.8 ms down where the link needs 1.3
+    // (profiles/r06_call_overhead.jsonl).  TVDN_IO_CHUNK_KIB forces a size (measurement).
+    size_t chunk = kChunk;
+    {
+        const size_t lanes = (size_t)lanes_wanted();
+        const size_t fine = (bytes / (lanes * 4) + ((size_t(1) << 20) - 1)) & ~((size_t(1) << 20) - 1);
+        chunk = std::min(kChunk, std::max(size_t(1) << 20, fine));
+        const char *e = getenv("TVDN_IO_CHUNK_KIB");
+        if (e && atoll(e) >= 64) chunk = std::min(kChunk, (size_t)atoll(e) * 1024);
+    }
+    const size_t nchunks = (bytes + chunk - 1) / chunk;
     const int n = (int)std::min<size_t>((size_t)lanes_wanted(), nchunks);
     int status[kLanes] = {0};
     std::thread th[kLanes];
     for (int l = 1; l < n; ++l)
-        th[l] = std::thread(up ? lane_upload : lane_download, &io, l, n, (char *)dst, (const char *)src, bytes, &status[l]);
-    (up ? lane_upload : lane_download)(&io, 0, n, (char *)dst, (const char *)src, bytes, &status[0]);
+        th[l] = std::thread(up ? lane_upload : lane_download, &io, l, n, (char *)dst, (const char *)src, bytes, chunk, &status[l]);
+    (up ? lane_upload : lane_download)(&io, 0, n, (char *)dst, (const char *)src, bytes, chunk, &status[0]);
     for (int l = 1; l < n; ++l) th[l].join();
     for (int l = 0; l < n; ++l)
         if (status[l]) {

@@ -74,6 +74,7 @@ struct Slab {
     int64_t rows() const { return halo_lo + (g1 - g0) + halo_hi; }
     int64_t row_lo() const { return halo_lo; }
     int64_t row_hi() const { return halo_lo + (g1 - g0); }
+    int main_level = 0, copy_level = 0;
     ~Slab()
     {
         (void)hipSetDevice(device);
@@ -85,9 +86,23 @@ struct Slab {
             if (main) (void)hipStreamSynchronize(main);  // (an error path: a fold that still writes there)
             (void)hipHostFree(peek);
         }
-        if (main) (void)hipStreamDestroy(main);
-        if (copy) (void)hipStreamDestroy(copy);
-        if (ctx) (void)tvdn_ctx_destroy(ctx);
+        // context, streams and the sums' buffer go to the next run of this device (tvdn_run_state.hip kit_release), or are destroyed
+        RunKit k;
+        k.ctx = ctx;
+        k.main = main;
+        k.copy = copy;
+        k.main_level = main_level;
+        k.copy_level = copy_level;
+        k.sums = sums.p;
+        k.sums_bytes = sums.bytes;
+        sums.p = nullptr;
+        if (k.ctx) {
+            kit_release(device, k);
+        } else {
+            if (main) (void)hipStreamDestroy(main);
+            if (copy) (void)hipStreamDestroy(copy);
+            if (k.sums) (void)hipFree(k.sums);
+        }
     }
 };
 
@@ -168,14 +183,26 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
         s.halo_lo = (world > 1 && (r > 0 || ring)) ? 1 : 0;
         s.halo_hi = (world > 1 && (r < world - 1 || ring || exact_wrap)) ? 1 : 0;
         TVDN_HIP(hipSetDevice(s.device));
-        int rc = tvdn_ctx_create(&s.ctx, s.device);
-        if (rc) return rc;
+        s.main_level = world == 1 ? +1 : 0;
+        s.copy_level = world == 1 ? 0 : +1;
+        int rc = TVDN_OK;
+        RunKit kit;
+        if (kit_acquire(s.device, s.main_level, s.copy_level, &kit)) {  // what the last run of this device left (tvdn_run_state.hip)
+            s.ctx = kit.ctx;
+            s.main = kit.main;
+            s.copy = kit.copy;
+            s.sums.p = kit.sums;
+            s.sums.bytes = kit.sums_bytes;
+        } else {
+            rc = tvdn_ctx_create(&s.ctx, s.device);
+            if (rc) return rc;
+        }
         // Sweeps and transfers in different hardware-queue classes (tvdn_common.hpp make_stream).  One slab: the transfers
         // are the staging lanes' DMA copies (normal class), the sweeps go high.  Several slabs: the transfers are peer
         // copies of one row under the interior sweep, possibly done by copy kernels -- those go high, so that their few
         // workgroups are dispatched ahead of the sweep's many instead of after them, and the sweeps stay normal.
-        rc = make_stream(&s.main, world == 1 ? +1 : 0);
-        if (!rc) rc = make_stream(&s.copy, world == 1 ? 0 : +1);
+        if (!s.main) rc = make_stream(&s.main, s.main_level);
+        if (!rc && !s.copy) rc = make_stream(&s.copy, s.copy_level);
         if (rc) return rc;
         TVDN_HIP(hipEventCreateWithFlags(&s.edge_done, hipEventDisableTiming));
         TVDN_HIP(hipEventCreateWithFlags(&s.halo_done, hipEventDisableTiming));
@@ -278,8 +305,16 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
         roles_reset(s.roles, fista);
         s.assign((char *)s.state.p, stride, nd, per_axis);
         s.sums.device = s.device;
-        TVDN_HIP(hipMalloc(&s.sums.p, sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1)));
-        TVDN_HIP(hipMemsetAsync(s.sums.p, 0, sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1), s.main));
+        const size_t sums_bytes = sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1);
+        if (s.sums.p && s.sums.bytes < sums_bytes) {  // (the kept buffer of a shorter run)
+            TVDN_HIP(hipFree(s.sums.p));
+            s.sums.p = nullptr;
+        }
+        if (!s.sums.p) {
+            s.sums.bytes = std::max(sums_bytes, (size_t)65536);
+            TVDN_HIP(hipMalloc(&s.sums.p, s.sums.bytes));
+        }
+        TVDN_HIP(hipMemsetAsync(s.sums.p, 0, sums_bytes, s.main));
     }
 
     clk.mark("contexts, state allocated");

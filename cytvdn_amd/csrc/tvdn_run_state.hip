@@ -109,6 +109,66 @@ void state_release(void *p, size_t bytes, int device)
     (void)dev_free(p);
 }
 
+// ---- the kit of a resident run, kept like its state ------------------------------------------------------------------------
+struct KitCache {
+    std::mutex mu;
+    RunKit kit[TVDN_MAX_DEVICES];
+    bool held[TVDN_MAX_DEVICES] = {};
+};
+static KitCache g_kit_cache;
+
+static void kit_destroy(int device, RunKit &k)
+{
+    (void)hipSetDevice(device);
+    if (k.main) (void)hipStreamDestroy(k.main);
+    if (k.copy) (void)hipStreamDestroy(k.copy);
+    if (k.sums) (void)hipFree(k.sums);
+    if (k.ctx) (void)tvdn_ctx_destroy(k.ctx);
+    k = RunKit();
+}
+
+bool kit_acquire(int device, int main_level, int copy_level, RunKit *k)
+{
+    if (!keep_state() || device < 0 || device >= TVDN_MAX_DEVICES) return false;
+    std::lock_guard<std::mutex> lk(g_kit_cache.mu);
+    if (!g_kit_cache.held[device]) return false;
+    RunKit &c = g_kit_cache.kit[device];
+    if (c.main_level != main_level || c.copy_level != copy_level) return false;  // (a device list after one-device runs: its own streams)
+    *k = c;
+    c = RunKit();
+    g_kit_cache.held[device] = false;
+    return true;
+}
+
+void kit_release(int device, RunKit &k)
+{
+    if (!k.ctx) return;
+    // whatever the run left in flight (an error path) is over before anyone else uses these streams or the scratch behind the context
+    bool idle = hipSetDevice(device) == hipSuccess;
+    idle = idle && (!k.main || hipStreamSynchronize(k.main) == hipSuccess) && (!k.copy || hipStreamSynchronize(k.copy) == hipSuccess);
+    if (!idle) (void)hipGetLastError();
+    if (idle && k.main && k.copy && keep_state() && device >= 0 && device < TVDN_MAX_DEVICES) {
+        // as tvdn_ctx_create leaves a context: not deferring, not timing, no mirror
+        k.ctx->deferring = false;
+        k.ctx->n_pend = 0;
+        k.ctx->timing = false;
+        k.ctx->mirror = nullptr;
+        for (auto &ev : k.ctx->events) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        k.ctx->events.clear();
+        std::lock_guard<std::mutex> lk(g_kit_cache.mu);
+        if (!g_kit_cache.held[device]) {
+            g_kit_cache.kit[device] = k;
+            g_kit_cache.held[device] = true;
+            k = RunKit();
+            return;
+        }
+    }
+    kit_destroy(device, k);
+}
+
 // Shape of a resident run's pipelined transfers (see run_impl): out = {rows per chunk, iterations that follow the upload,
 // iterations that run over the download}, {0, 0, 0} = plain order.  Eight chunks (~12 ms of PCIe each for a 4 GiB cube), as
 // many iterations at either end as a chunk's transfer pays for; cubes under 256 MiB move in milliseconds and runs under four
@@ -261,6 +321,12 @@ extern "C" int tvdn_release_cache(void)
             (void)tvdn::dev_free(tvdn::g_state_cache.p[d]);
             tvdn::g_state_cache.p[d] = nullptr;
             tvdn::g_state_cache.bytes[d] = 0;
+        }
+    std::lock_guard<std::mutex> lk2(tvdn::g_kit_cache.mu);
+    for (int d = 0; d < TVDN_MAX_DEVICES; ++d)
+        if (tvdn::g_kit_cache.held[d]) {
+            tvdn::kit_destroy(d, tvdn::g_kit_cache.kit[d]);
+            tvdn::g_kit_cache.held[d] = false;
         }
     return TVDN_OK;
 }
