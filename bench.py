@@ -30,7 +30,7 @@ At N = 1 the line also carries
   sustained     config 2 again for >= 400 steps: what a long run sees
   also          the other single-GPU configurations on the same clock: BASELINE configs[2] (float64, unaccelerated), the
                 configs[0] shape on the GPU (3-D FISTA 128x128x512), the unaccelerated f32 forms (denoise3D's default path on
-                512^3, denoise4D on the config-2 cube), ONE slab of configs[3] (66x512x256x256 local block, halo
+                512^3, denoise4D on the config-2 cube), FISTA in float64 on the config-2 cube, ONE slab of configs[3] (66x512x256x256 local block, halo
                 edges, edge rows first, halo rows refreshed by device copies of the size of the RCCL messages) = the per-GPU term
                 of the weak-scaling curve; and the API level, PCIe included (never `value`): cytvdn_amd.denoise4D NumPy -> NumPy
                 at 50 and 200 iterations, and tvdn_run streamed from page-locked host memory (tvdn_run_stats: passes-only rate,
@@ -696,7 +696,9 @@ def main():
                                            ((512, 512, 256, 256), "f32", True, 10, 2, 8),      # one slab of configs[3]
                                            # the unaccelerated f32 forms (round 6; denoise3D's DEFAULT is FISTA=False, cyTVDN.py:253)
                                            ((512, 512, 512), "f32", False, 100, 10, 0),
-                                           ((256, 256, 128, 128), "f32", False, 20, 3, 0)):
+                                           ((256, 256, 128, 128), "f32", False, 20, 3, 0),
+                                           # the fourth corner of dtype x mode on the config-2 cube: FISTA in float64 (120 GiB of state)
+                                           ((256, 256, 128, 128), "f64", True, 12, 3, 0)):
             try:
                 r = measure(shp, dn, fi, a.state, st_, wu, local_rank, slab_of=slab, traffic_table=traffic_table,
                             audition=a.audition)

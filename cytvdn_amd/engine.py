@@ -435,10 +435,14 @@ class HipBackend:
             self.cur ^= 1
 
     # -- placement audition ------------------------------------------------------------------------------------------
-    def probe_ms(self, sweeps: int = 2) -> float:
-        """Fastest of `sweeps` timed sweeps on THIS allocation with an all-zero state (the sweep is branch-free: its time
-        does not depend on the values), after one untimed sweep.  Leaves the state all-zero with its roles reset, i.e.
-        as freshly constructed; call it before set_input."""
+    def probe_ms(self, sweeps: int = 6) -> float:
+        """MEAN of `sweeps` timed sweeps on THIS allocation with an all-zero state (the sweep is branch-free: its time
+        does not depend on the values -- profiles/r06_data_dependence.jsonl), after one untimed sweep.  Six by default: the
+        arrays rotate through their roles with period 6 (three d arrays per axis x two recon buffers), and which arrays are
+        written decides the time of a sweep by +- 1.5 % (11.14 ... 11.47 ms within one cycle of config 2, same file) --
+        the minimum of two sweeps, which this returned until round 6, is the best arrangement's time, not the block's:
+        the four plain blocks of a bench run probed at 10.93 ... 11.36 ms and the best then RAN at 11.30.
+        Leaves the state all-zero with its roles reset, i.e. as freshly constructed; call it before set_input."""
         for q in range(self.nd):
             self._args.clip[q], self._args.lambda_mu[q] = 1.0, 1.0 / 32.0
         self.orig.zero_()
@@ -459,7 +463,7 @@ class HipBackend:
             self.set_form(self.fista, 0.0)
         else:
             self.cur = 0
-        return float(min(each[1:nl.value])) if nl.value > 1 else float(each[0])
+        return float(np.mean(each[1:nl.value])) if nl.value > 1 else float(each[0])
 
     @classmethod
     def best_of(cls, candidates: int, layout, dtype, fista, device: int = 0, hbm_fraction: float = 0.8,
