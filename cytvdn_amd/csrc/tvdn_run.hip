@@ -17,118 +17,11 @@
 
 #include "tvdn_common.hpp"
 
+#include "tvdn_run_parts.hpp"
+
 namespace tvdn {
 
-struct DevBuf {
-    void *p = nullptr;
-    int device = 0;
-    bool owned = true;  // false: the caller's workspace
-    size_t bytes = 0;   // size of the allocation (state blocks only)
-    bool keep = false;  // a state block that goes to the cache instead of back to the driver
-    ~DevBuf()
-    {
-        if (p && owned) {
-            (void)hipSetDevice(device);
-            if (keep && bytes)
-                state_release(p, bytes, device);
-            else
-                (void)dev_free(p);
-        }
-    }
-};
-
-template <typename T>
-static T delta_in_dtype(const double s[3])
-{
-    // the reference divides its two dtype-width sums in the array dtype (utils.pyx:125)
-    return (T)s[1] / (T)s[2];
-}
-
-// One slab: rows [g0, g1) of the cube plus a halo row on every interior side, resident on one device.
-struct Slab {
-    int device = 0;
-    int64_t g0 = 0, g1 = 0, halo_lo = 0, halo_hi = 0;  // global own rows; halo rows held
-    tvdn_ctx *ctx = nullptr;
-    hipStream_t main = nullptr, copy = nullptr;
-    hipEvent_t edge_done = nullptr, halo_done = nullptr;
-    // a run with a stopping rule (run_impl, "speculation by one"): the sums of the last two iterations as the device left them in
-    // host memory (two slots of four doubles), and the event behind each slot's last fold
-    double *peek = nullptr;
-    hipEvent_t summed[2] = {nullptr, nullptr};
-    DevBuf state;  // ONE allocation: per axis 2-3 rotating arrays, recon x2, orig
-    DevBuf ref, sums, mse;
-    tvdn_many_args roles;  // arrays and who plays which role (tvdn_common.hpp roles_bind / roles_advance); .base = the sweep's fixed arguments
-    char *orig = nullptr;
-    char *recon(int i) const { return (char *)roles.recon[i]; }
-    // carve one allocation into the arrays of the state: per axis 2-3 rotating arrays, recon[1], orig, recon[0]
-    void assign(char *base, size_t stride, int nd, int per_axis)
-    {
-        int k = 0;
-        for (int q = 0; q < nd; ++q)
-            for (int j = 0; j < per_axis; ++j) roles.S[q][j] = base + stride * (size_t)(k++);
-        roles.recon[1] = base + stride * (size_t)(k++);
-        orig = base + stride * (size_t)(k++);
-        roles.recon[0] = base + stride * (size_t)(k++);
-        roles.base.orig = orig;
-    }
-    int64_t rows() const { return halo_lo + (g1 - g0) + halo_hi; }
-    int64_t row_lo() const { return halo_lo; }
-    int64_t row_hi() const { return halo_lo + (g1 - g0); }
-    int main_level = 0, copy_level = 0;
-    ~Slab()
-    {
-        (void)hipSetDevice(device);
-        if (edge_done) (void)hipEventDestroy(edge_done);
-        if (halo_done) (void)hipEventDestroy(halo_done);
-        for (hipEvent_t e : summed)
-            if (e) (void)hipEventDestroy(e);
-        if (peek) {
-            if (main) (void)hipStreamSynchronize(main);  // (an error path: a fold that still writes there)
-            (void)hipHostFree(peek);
-        }
-        // context, streams and the sums' buffer go to the next run of this device (tvdn_run_state.hip kit_release), or are destroyed
-        RunKit k;
-        k.ctx = ctx;
-        k.main = main;
-        k.copy = copy;
-        k.main_level = main_level;
-        k.copy_level = copy_level;
-        k.sums = sums.p;
-        k.sums_bytes = sums.bytes;
-        sums.p = nullptr;
-        if (k.ctx) {
-            kit_release(device, k);
-        } else {
-            if (main) (void)hipStreamDestroy(main);
-            if (copy) (void)hipStreamDestroy(copy);
-            if (k.sums) (void)hipFree(k.sums);
-        }
-    }
-};
-
-static int64_t edge_block(int64_t own)
-{
-    const int64_t e = 8;  // a whole march per side: no extra look-ahead rows (engine.edge_block)
-    const int64_t cap = (own - 1) / 2;
-    return cap < 1 ? 1 : (e < cap ? e : cap);
-}
-
-// TVDN_RUN_TIMING=1: where a resident run's wall time goes (stderr; the device is drained at every mark, so the phases
-// are honest and the total a little longer than an untimed run's).
-struct RunClock {
-    bool on = getenv("TVDN_RUN_TIMING") != nullptr;
-    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-    void mark(const char *what)
-    {
-        if (!on) return;
-        (void)hipDeviceSynchronize();
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "tvdn_run: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
-        t = now;
-    }
-};
-
-static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats)
+int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats)
 {
     const auto t_entry = std::chrono::steady_clock::now();
     auto since_entry = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count(); };
@@ -1022,108 +915,3 @@ static int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats
 }
 
 }  // namespace tvdn
-
-
-extern "C" int tvdn_run(const tvdn_run_args *a)
-{
-    tvdn::DeviceRestore restore;  // declared first: destroyed after every slab, stream and buffer of the run
-    TVDN_REQUIRE(a != nullptr, "args is NULL");
-    TVDN_REQUIRE(a->dtype == TVDN_F32 || a->dtype == TVDN_F64, "bad dtype %d", a->dtype);
-    TVDN_REQUIRE(a->ndim == 3 || a->ndim == 4, "ndim must be 3 or 4, got %d", a->ndim);
-    for (int i = 0; i < a->ndim; ++i) TVDN_REQUIRE(a->shape[i] >= 1, "shape[%d] must be >= 1", i);
-    TVDN_REQUIRE(a->n_fista >= 0 && a->n_plain >= 0, "negative iteration count");
-    TVDN_REQUIRE(a->data && a->recon_out, "data / recon_out is NULL");
-    TVDN_REQUIRE(a->sums_out || a->n_fista + a->n_plain == 0, "sums_out is NULL");
-    TVDN_REQUIRE(a->n_devices >= 0 && a->n_devices <= TVDN_MAX_DEVICES, "n_devices must be 0..%d", TVDN_MAX_DEVICES);
-    const bool stream_auto = a->stream_rows == -1 && a->stream_k == -1;
-    TVDN_REQUIRE(stream_auto || (a->stream_rows >= 0 && a->stream_k >= 0 && (a->stream_rows > 0) == (a->stream_k > 0)),
-                 "stream_rows and stream_k must both be 0 (never stream), both be -1 (stream when needed) or both be positive");
-    {
-        int n = 0;
-        if (hipGetDeviceCount(&n) != hipSuccess || n < 1) {
-            tvdn::set_error("no HIP device visible: the product path needs an MI355X (gfx950); there is no CPU fallback");
-            return TVDN_ERR_NO_DEVICE;
-        }
-        if (a->n_devices == 0) TVDN_REQUIRE(a->device >= 0 && a->device < n, "device %d out of range (0..%d)", a->device, n - 1);
-        for (int i = 0; i < a->n_devices; ++i)
-            TVDN_REQUIRE(a->devices[i] >= 0 && a->devices[i] < n, "devices[%d] = %d out of range (0..%d)", i, a->devices[i], n - 1);
-    }
-    if (a->bc_mode == TVDN_BC_MIRROR) {
-        tvdn::set_error("bc_mode 1 (mirror) reconstruction update reads out of bounds upstream (utils.pyx:117-120): unsupported");
-        return TVDN_ERR_UNSUPPORTED;
-    }
-    TVDN_REQUIRE(a->bc_mode == 0 || a->bc_mode == 2, "bc_mode must be 0 or 2, got %d", a->bc_mode);
-    if (a->slab) {  // one slab of a multi-process streamed run: the caller's hooks carry what crosses process boundaries
-        TVDN_REQUIRE(a->stream_rows > 0 && a->stream_k > 0, "a slab of a multi-process run (tvdn_run_args.slab) is streamed: stream_rows and stream_k must be positive");
-        TVDN_REQUIRE(a->n_devices <= 1, "a slab of a multi-process run uses one device");
-        return tvdn::run_streamed_rank(a, a->stream_rows, a->stream_k);
-    }
-    if (a->stream_rows > 0) {
-        const auto ts = std::chrono::steady_clock::now();
-        // several devices: every slab streamed through its own GPU from host arrays all of them share (tvdn_stream.hip)
-        const int rcs = a->n_devices > 1 ? tvdn::run_streamed_slabs(a, a->stream_rows, a->stream_k)
-                                         : tvdn::run_streamed(a, a->stream_rows, a->stream_k, a->stream_resident);
-        if (getenv("TVDN_STREAM_TIMING"))
-            fprintf(stderr, "tvdn_run streamed: whole call %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count());
-        return rcs;
-    }
-    {   // say clearly when the slabs cannot fit, instead of failing somewhere inside hipMalloc
-        const int world = a->n_devices > 0 ? a->n_devices : 1;
-        TVDN_REQUIRE(a->shape[0] >= world, "axis 0 (%lld rows) cannot be cut into %d slabs", (long long)a->shape[0], world);
-        tvdn_plan_out pl;
-        const int rc = tvdn_plan(a->dtype, a->ndim, a->shape, a->n_fista > 0, world, a->n_devices > 0 ? a->devices[0] : a->device, &pl);
-        if (rc) return rc;
-        int same = 0;  // slabs sharing the first device share its HBM
-        for (int i = 0; i < world; ++i) same += (a->n_devices == 0 || a->devices[i] == a->devices[0]) ? 1 : 0;
-        // ONE threshold (tvdn_plan's `fits`): a state beyond 90 % of the free HBM streams when asked to decide, else is refused
-        // a caller that brings the state's memory (workspace, one slab) has nothing left to fit but the sums
-        const bool brought = a->workspace != nullptr && world == 1;
-        const bool over = !brought && pl.bytes_per_slab * same > (int64_t)(0.9 * (double)pl.free_bytes);
-        if (stream_auto && over && world == 1) {
-            // asked to decide: one device, state beyond its HBM -> stream it (tvdn_stream.hip; it refuses, before it
-            // touches the caller's arrays, what the host cannot hold either)
-            size_t row_bytes = a->dtype == TVDN_F32 ? 4 : 8;
-            for (int i = 1; i < a->ndim; ++i) row_bytes *= (size_t)a->shape[i];
-            int64_t rows = 0, k = 0, res = 0;
-            const bool keep = a->bc_mode == TVDN_BC_JIA_ZHAO && !(a->mse_out && a->reference) && a->stream_resident != 0;
-            const int rc2 = tvdn::choose_stream_shape(a->ndim, a->shape[0], row_bytes, (size_t)pl.free_bytes, a->mse_out && a->reference, true,
-                                                      a->n_fista > 0 ? 2 : 1, keep, a->use_stop ? 1 : a->n_fista + a->n_plain, &rows, &k, &res,
-                                                      a->use_stop ? 0 : a->n_fista + a->n_plain);
-            if (rc2) return rc2;
-            return tvdn::run_streamed(a, rows, k, a->stream_resident > 0 ? a->stream_resident : (keep ? res : 0));
-        }
-        if (stream_auto && over && world > 1) {
-            // asked to decide, several devices, slabs beyond their HBM: BASELINE configs[4] in structure -- every slab streamed
-            // through its own device (the depth that one slab's rings allow; no rows kept resident: the halo rows of a pass are
-            // read from the shared host arrays)
-            size_t row_bytes = a->dtype == TVDN_F32 ? 4 : 8;
-            for (int i = 1; i < a->ndim; ++i) row_bytes *= (size_t)a->shape[i];
-            int64_t rows = 0, k = 0, res = 0;
-            const int rc2 = tvdn::choose_stream_shape(a->ndim, (a->shape[0] + world - 1) / world, row_bytes, (size_t)(pl.free_bytes / same),
-                                                      a->mse_out && a->reference, false, a->n_fista > 0 ? 2 : 1, false,
-                                                      a->use_stop ? 1 : a->n_fista + a->n_plain, &rows, &k, &res,
-                                                      a->use_stop ? 0 : a->n_fista + a->n_plain);
-            if (rc2) return rc2;
-            return tvdn::run_streamed_slabs(a, rows, k);
-        }
-        if (over) {
-            tvdn::set_error("state of %lld bytes per slab x %d slab(s) on device %d exceeds 90 %% of its %lld free bytes of HBM: use more "
-                            "devices (fewest slabs that fit one each: %d) or the streamed engines (stream_rows / stream_k; cytvdn_amd.plan_run)",
-                            (long long)pl.bytes_per_slab, same, a->n_devices > 0 ? a->devices[0] : a->device,
-                            (long long)pl.free_bytes, pl.min_slabs);
-            return TVDN_ERR_UNSUPPORTED;
-        }
-    }
-    if ((a->n_devices > 1) || a->workspace) (void)tvdn_release_cache();  // several slabs / the caller's own memory: no use for a kept block
-    tvdn::RunClock clk;
-    const auto t0 = std::chrono::steady_clock::now();
-    tvdn_run_stats stats;
-    std::memset(&stats, 0, sizeof stats);
-    const int rc = tvdn::run_impl(a, clk, stats);
-    clk.mark("release");
-    if (!rc && a->stats) {
-        stats.total_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        *a->stats = stats;
-    }
-    return rc;
-}

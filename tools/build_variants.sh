@@ -3,7 +3,7 @@
 # TVDN_LIB=<path> (cytvdn_amd/_lib.py).  Output: tools/ubench/libtvdn_hip_<tag>.so (git-ignored).
 set -e
 cd "$(dirname "$0")/.."
-SRC="cytvdn_amd/csrc/tvdn_capi.hip cytvdn_amd/csrc/tvdn_passes.hip cytvdn_amd/csrc/tvdn_fused.hip cytvdn_amd/csrc/tvdn_run.hip cytvdn_amd/csrc/tvdn_stream.hip cytvdn_amd/csrc/tvdn_hostio.hip"
+SRC="$(ls cytvdn_amd/csrc/*.hip | tr "\n" " ")"   # every source of the library (cytvdn_amd/csrc/Makefile)
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fPIC -shared -Wl,-rpath,/opt/rocm/lib -lpthread"
 build() { # tag, extra flags
   /opt/rocm/bin/hipcc $FLAGS $2 $SRC -o tools/ubench/libtvdn_hip_$1.so
