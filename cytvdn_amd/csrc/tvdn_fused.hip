@@ -138,11 +138,29 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const void *row_base)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(row_base), 0, -1, 0x00020000);
 }
 
+// cache-policy bits of the raw buffer accesses (gfx940+: bit 0 = sc0, bit 1 = nt, bit 4 = sc1).  Measurement builds may override
+// them (tools/build_variants.sh aux): streaming loads / other loads / stores.  Round 6, variants alternating on one allocation
+// (profiles/r06_ab_inproc_aux.jsonl): on the loads nothing beats nt alone on the streams and no bit on the rest; stores with
+// nt + sc1 are 0.9-1.3 % FASTER in the float64 forms (config 3: 17.24 -> 17.08 ms, FISTA f64: 23.32 -> 23.09) and 0.2 % slower in
+// float32 FISTA (config 2: 11.206 -> 11.231), the same in the other float32 forms -- so the bit goes with the element size.
+#ifndef TVDN_LDNT_AUX
+#define TVDN_LDNT_AUX 2
+#endif
+#ifndef TVDN_LD_AUX
+#define TVDN_LD_AUX 0
+#endif
+#ifndef TVDN_ST_AUX
+#define TVDN_ST_AUX (kNtStores ? 2 : 0)
+#endif
+#ifndef TVDN_ST_AUX64
+#define TVDN_ST_AUX64 (kNtStores ? 18 : 0)
+#endif
+
 template <typename T, int VEC, bool NT>
 __device__ __forceinline__ Pack<T, VEC> ldb(const T *row_base, unsigned e)
 {
     constexpr int BYTES = (int)sizeof(T) * VEC;
-    constexpr int AUX = NT ? 2 : 0;  // bit 1 = nt
+    constexpr int AUX = NT ? TVDN_LDNT_AUX : TVDN_LD_AUX;
     const __amdgpu_buffer_rsrc_t rs = row_rsrc(row_base);
     const unsigned off = e * (unsigned)sizeof(T);
     Pack<T, VEC> x;
@@ -169,7 +187,7 @@ template <typename T, int VEC>
 __device__ __forceinline__ void stb(T *row_base, unsigned e, const Pack<T, VEC> &x)
 {
     constexpr int BYTES = (int)sizeof(T) * VEC;
-    constexpr int AUX = kNtStores ? 2 : 0;
+    constexpr int AUX = sizeof(T) == 8 ? TVDN_ST_AUX64 : TVDN_ST_AUX;
     const __amdgpu_buffer_rsrc_t rs = row_rsrc(row_base);
     const unsigned off = e * (unsigned)sizeof(T);
     if (BYTES == 16) {

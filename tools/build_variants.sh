@@ -17,6 +17,13 @@ if [ "$1" = "waves" ]; then   # round 4: occupancy targets of the fused sweep (a
   for w in 3 4 5 6 7 8; do build wav$w "-DTVDN_WAVES_PER_EU=$w" & done
   wait; ls -la tools/ubench/*wav*.so; exit 0
 fi
+if [ "$1" = "aux" ]; then   # round 6: cache-policy bits of the sweep's buffer accesses (sc0 = 1, nt = 2, sc1 = 16)
+  for v in 18 19 16 3; do build st$v "-DTVDN_ST_AUX=$v -DTVDN_ST_AUX64=$v" & done
+  wait
+  for v in 18 19 3; do build ldnt$v "-DTVDN_LDNT_AUX=$v" & done
+  build ld1 "-DTVDN_LD_AUX=1" &
+  wait; ls -la tools/ubench/*st1*.so tools/ubench/*ld*.so; exit 0
+fi
 if [ "$1" = "ntmask" ]; then   # round 3: which accumulator-state loads stream past the L2 (csrc/tvdn_fused.hip, kNtMask)
   for m in 1 2 3 7 11 27 31 4 16; do build ntm$m "-DTVDN_NTMASK=$m" & done
   wait; ls -la tools/ubench/*ntm*.so; exit 0
