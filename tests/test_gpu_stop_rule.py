@@ -116,3 +116,42 @@ def test_a_rule_that_never_fires_changes_nothing(oracle):
         assert bits_equal(u, v)
     ref = oracle.denoise(x, mu, [9, 6], True)
     assert bits_equal(ruled[0], ref["recon"])
+
+
+def test_calls_from_several_threads_share_what_runs_keep(oracle):
+    """ctypes releases the GIL inside tvdn_run, so denoise3D/4D may run on several threads at once.  What a resident run keeps for the
+    next one of its device -- reduction context, streams, sums buffer (csrc/tvdn_run_state.hip kit_acquire / kit_release) -- goes to
+    ONE run at a time: four threads, calls with and without a stopping rule interleaved, every result the oracle's."""
+    import threading
+    import cytvdn_amd as tv
+    from cytvdn_amd import synth, _lib
+    dt = np.dtype(np.float32)
+    cases = []
+    for i, (shape, its, stop) in enumerate([((9, 10, 32), 12, None), ((7, 6, 8, 12), [5, 4], 0.05), ((12, 8, 16), 15, 0.02),
+                                            ((6, 5, 8, 8), 9, None)]):
+        nd = len(shape)
+        x = synth.cube(shape, seed=71 + i, dtype=dt) + dt.type(0.25)
+        mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
+        ref = oracle.denoise(x, mu, its, True, stopping_relative_change=stop)
+        cases.append((tv.denoise4D if nd == 4 else tv.denoise3D, x, mu, its, stop, ref))
+    errors = []
+
+    def work(k):
+        try:
+            for rep in range(6):
+                fn, x, mu, its, stop, ref = cases[(k + rep) % len(cases)]
+                got = fn(x, mu, its, FISTA=True, stopping_relative_change=stop, quiet=True)
+                if not bits_equal(got[0], ref["recon"]) or not np.array_equal(got[2] != 0, ref["delta_recon"] != 0):
+                    errors.append((k, rep, "differs from the oracle"))
+        except Exception as e:      # noqa: BLE001 -- reported below
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    _lib.check(_lib.lib().tvdn_release_cache())      # the kept kit goes back with the kept state
+    got = cases[0][0](cases[0][1], cases[0][2], cases[0][3], FISTA=True, quiet=True)   # ... and the next run makes its own
+    assert bits_equal(got[0], cases[0][5]["recon"])
