@@ -616,6 +616,10 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
         chunk = e_chunk ? atoll(e_chunk) : 8;
         if (chunk < 1) chunk = 1;
         while (chunk > 4 && p.tiles * ((rows + chunk - 1) / chunk) < 256 * 8) chunk /= 2;
+        // the smallest cubes are bound by the serial row steps of a march, not by bytes: under 1024 workgroups the marches get
+        // shorter still (32 x 32 x 128: 11.5 -> 8.3 us per sweep at one row per march, 64 x 64 x 256: 15.9 -> 15.0 at two,
+        // 16 x 16 x 64 x 64: 19.1 -> 17.9; from 96 x 96 x 384 on four rows and more are the faster: profiles/r06_small_chunk.txt)
+        while (!e_chunk && chunk > 1 && p.tiles * ((rows + chunk - 1) / chunk) < 1024) chunk /= 2;
         // the reduction scratch grows with the grid (ensure_partials), so big planes keep their short marches;
         // only beyond kMaxPartialBlocks workgroups do the marches get longer
         while (p.tiles * ((rows + chunk - 1) / chunk) > kMaxPartialBlocks && chunk < rows) chunk *= 2;
