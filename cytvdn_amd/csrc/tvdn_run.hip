@@ -21,7 +21,7 @@
 
 namespace tvdn {
 
-int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats)
+int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats, bool pipeline_with_rule)
 {
     const auto t_entry = std::chrono::steady_clock::now();
     auto since_entry = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count(); };
@@ -362,16 +362,22 @@ int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats)
     //   end    the last k1 iterations run the same way, and every chunk's finished rows go home (a second helper thread)
     //          while the chunks after it are still being swept.
     // The sweeps at the cube's top face take the Jia-Zhao zero (TVDN_EDGE_ZERO) because row 0 of the buffers belongs to a
-    // later level by then: Jia-Zhao runs with a finite first row only; no stopping rule, no MSE trace (both need whole
-    // iterations).  TVDN_PIPELINE=0 keeps the plain order, "R,k0,k1" forces a shape (tests).
+    // later level by then: Jia-Zhao runs with a finite first row only; no MSE trace (it needs whole iterations); with a stopping
+    // rule the start only (below).  TVDN_PIPELINE=0 keeps the plain order, "R,k0,k1" forces a shape (tests).
     int64_t pipe_R = 0;
     int pipe_k0 = 0, pipe_k1 = 0;
-    if (world == 1 && a->bc_mode == TVDN_BC_JIA_ZHAO && !a->use_stop && !want_mse && !row0_bad) {
+    // A stopping rule (round 6): the START is pipelined all the same -- the first k0 iterations follow the upload, their sums are
+    // looked at when the last chunk has been swept, and the rest of the run looks at every iteration one behind (below).  Should
+    // the rule have been met INSIDE those first iterations (the levels after it have run on, nothing to take back), the whole run
+    // is done again in plain order (kRetryPlain: tvdn_run_entry.hip) -- a rule that fires within eight iterations of the start is
+    // rare and the run it ends is short.  The END cannot be: which iteration is the last is not known until it has run.
+    const bool lag_on = !(getenv("TVDN_STOP_LAG") && atoi(getenv("TVDN_STOP_LAG")) == 0);
+    if (world == 1 && a->bc_mode == TVDN_BC_JIA_ZHAO && !want_mse && !row0_bad && (!a->use_stop || (pipeline_with_rule && lag_on))) {
         int32_t pl[3];
         pipeline_plan(N0, n_total, (int64_t)N0 * (int64_t)row_bytes, pl);
         pipe_R = pl[0];
         pipe_k0 = pl[1];
-        pipe_k1 = pl[2];
+        pipe_k1 = a->use_stop ? 0 : pl[2];
     }
     const bool pipelined = pipe_R > 0;
     stats.pipelined = pipelined ? 1 : 0;
@@ -612,6 +618,93 @@ int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats)
         return TVDN_OK;
     };
 
+    auto run_ruled = [&](int first) -> int {
+        // ---- a stopping rule, looked at one iteration behind ---------------------------------------------------------------
+        // Upstream reads delta_recon[i] after iteration i and breaks (cyTVDN.py:189-195, :231-237).  Done in stream order that is a
+        // round trip per iteration -- launch, sweep, fold, copy of three doubles, wake-up: 27-29 us on top of a sweep of 12 us for a
+        // 64 x 64 x 256 cube and 70 us for BASELINE configs[0]'s shape (profiles/r06_stop_rule.jsonl: 2.7 x and 1.34 x the time of
+        // the same run without a rule).  So iteration i+1 is queued BEFORE the sums of iteration i are looked at: the fold of an
+        // iteration leaves them in host memory as well (tvdn_ctx::mirror), an event behind it says when, and the device never waits
+        // for the host.  If iteration i did satisfy the rule, iteration i+1 has run in vain and is taken back: it read the state
+        // iteration i left and wrote into the buffers that rotate out (recon[cur ^ 1], the oldest array of every axis), so putting
+        // the roles back IS the state after iteration i, bit for bit; its sums and MSE slots are zeroed on the way home, as the
+        // tails upstream leaves.  TVDN_STOP_LAG=0: the blocking form (tests compare the two).
+        for (int r = 0; r < world; ++r) {
+            Slab &s = sl[r];
+            TVDN_HIP(hipSetDevice(s.device));
+            TVDN_HIP(hipHostMalloc((void **)&s.peek, 8 * sizeof(double), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(s.peek, 0, 8 * sizeof(double));
+            for (hipEvent_t &e : s.summed) TVDN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        auto post = [&](int slot) -> int {  // the folds of `slot` are queued on every slab: mark their end
+            for (int r = 0; r < world; ++r) {
+                TVDN_HIP(hipSetDevice(sl[r].device));
+                TVDN_HIP(hipEventRecord(sl[r].summed[slot & 1], sl[r].main));
+            }
+            return TVDN_OK;
+        };
+        auto rule_met = [&](int slot, bool &stop) -> int {
+            double tot[3] = {0.0, 0.0, 0.0};
+            for (int r = 0; r < world; ++r) {  // the global criterion: sums over every slab, in slab order
+                hipEvent_t ev = sl[r].summed[slot & 1];
+                const auto t0 = std::chrono::steady_clock::now();
+                for (;;) {  // short iterations: ask; long ones: sleep on it
+                    const hipError_t e = hipEventQuery(ev);
+                    if (e == hipSuccess) break;
+                    if (e != hipErrorNotReady) TVDN_HIP(e);
+                    (void)hipGetLastError();
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
+                        TVDN_HIP(hipEventSynchronize(ev));
+                        break;
+                    }
+                }
+                const volatile double *pk = sl[r].peek + 4 * (slot & 1);
+                for (int j = 0; j < 3; ++j) tot[j] += pk[j];
+            }
+            const double delta = a->dtype == TVDN_F32 ? (double)delta_in_dtype<float>(tot) : delta_in_dtype<double>(tot);
+            stop = delta < a->stop;
+            return TVDN_OK;
+        };
+        std::vector<tvdn_many_args> before((size_t)world);
+        if (first >= n_total) return TVDN_OK;
+        int slot = first;
+        int rc = one(first, is_fista(first), ratios[first]);
+        if (!rc) rc = post(first);
+        if (rc) return rc;
+        while (slot >= 0) {
+            const int ahead = slot + 1 < n_total ? slot + 1 : -1;
+            if (ahead >= 0) {
+                for (int r = 0; r < world; ++r) before[(size_t)r] = sl[r].roles;
+                rc = one(ahead, is_fista(ahead), ratios[ahead]);
+                if (!rc) rc = post(ahead);
+                if (rc) return rc;
+            }
+            ++ran_phase[is_fista(slot) ? 0 : 1];
+            tick(slot + 1);
+            bool st;
+            rc = rule_met(slot, st);
+            if (rc) return rc;
+            if (!st) {
+                slot = ahead;
+                continue;
+            }
+            // a FISTA-phase stop falls through to the unaccelerated phase (cyTVDN.py:189-201); a stop there ends the run
+            const int resume = (is_fista(slot) && a->n_plain > 0) ? a->n_fista : -1;
+            if (ahead >= 0 && ahead != resume) {  // iteration `ahead` ran in vain
+                for (int r = 0; r < world; ++r) sl[r].roles = before[(size_t)r];
+                --ran;
+                void_slots.push_back(ahead);
+                if (resume >= 0) {
+                    rc = one(resume, false, 0.0);
+                    if (!rc) rc = post(resume);
+                    if (rc) return rc;
+                }
+            }
+            slot = resume;
+        }
+        return TVDN_OK;
+    };
+
     // no stopping rule, one slab: nobody reads the sums before the end, small launches fold them in batches (tvdn_common.hpp)
     const bool defer_sums = world == 1 && !a->use_stop;
     if (defer_sums) sums_defer_begin(sl[0].ctx);
@@ -643,10 +736,23 @@ int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats)
                 (void)hipSetDevice(s.device);
                 result_pinned = host_pin_result(a->recon_out, (size_t)N0 * row_bytes) == TVDN_OK ? 1 : 0;
             });
-        for (int i = pipe_k0; i < n_total - pipe_k1; ++i) {
-            const int rc = one(i, is_fista(i), ratios[i]);
+        if (a->use_stop) {
+            // the first k0 iterations have run behind the upload: was the rule met inside them?
+            for (int i = 0; i < pipe_k0; ++i) {
+                bool st;
+                const int rc = stopped(i, st);
+                if (rc) return rc;
+                if (st) return kRetryPlain;
+                ++ran_phase[is_fista(i) ? 0 : 1];
+            }
+            const int rc = run_ruled(pipe_k0);
             if (rc) return rc;
-            tick(i + 1);
+        } else {
+            for (int i = pipe_k0; i < n_total - pipe_k1; ++i) {
+                const int rc = one(i, is_fista(i), ratios[i]);
+                if (rc) return rc;
+                tick(i + 1);
+            }
         }
         clk.mark("middle iterations");
         if (pipe_k1 > 0) {
@@ -755,92 +861,14 @@ int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats)
             tick(n_total);
             clk.mark("last iterations + download");
         }
-        ran = n_total;
-        ran_phase[0] = a->n_fista;
-        ran_phase[1] = a->n_plain;
-    } else if (a->use_stop && n_total > 0 && !(getenv("TVDN_STOP_LAG") && atoi(getenv("TVDN_STOP_LAG")) == 0)) {
-        // ---- a stopping rule, looked at one iteration behind ---------------------------------------------------------------
-        // Upstream reads delta_recon[i] after iteration i and breaks (cyTVDN.py:189-195, :231-237).  Done in stream order that is a
-        // round trip per iteration -- launch, sweep, fold, copy of three doubles, wake-up: 27-29 us on top of a sweep of 12 us for a
-        // 64 x 64 x 256 cube and 70 us for BASELINE configs[0]'s shape (profiles/r06_stop_rule.jsonl: 2.7 x and 1.34 x the time of
-        // the same run without a rule).  So iteration i+1 is queued BEFORE the sums of iteration i are looked at: the fold of an
-        // iteration leaves them in host memory as well (tvdn_ctx::mirror), an event behind it says when, and the device never waits
-        // for the host.  If iteration i did satisfy the rule, iteration i+1 has run in vain and is taken back: it read the state
-        // iteration i left and wrote into the buffers that rotate out (recon[cur ^ 1], the oldest array of every axis), so putting
-        // the roles back IS the state after iteration i, bit for bit; its sums and MSE slots are zeroed on the way home, as the
-        // tails upstream leaves.  TVDN_STOP_LAG=0: the blocking form (tests compare the two).
-        for (int r = 0; r < world; ++r) {
-            Slab &s = sl[r];
-            TVDN_HIP(hipSetDevice(s.device));
-            TVDN_HIP(hipHostMalloc((void **)&s.peek, 8 * sizeof(double), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
-            std::memset(s.peek, 0, 8 * sizeof(double));
-            for (hipEvent_t &e : s.summed) TVDN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (!a->use_stop) {
+            ran = n_total;
+            ran_phase[0] = a->n_fista;
+            ran_phase[1] = a->n_plain;
         }
-        auto post = [&](int slot) -> int {  // the folds of `slot` are queued on every slab: mark their end
-            for (int r = 0; r < world; ++r) {
-                TVDN_HIP(hipSetDevice(sl[r].device));
-                TVDN_HIP(hipEventRecord(sl[r].summed[slot & 1], sl[r].main));
-            }
-            return TVDN_OK;
-        };
-        auto rule_met = [&](int slot, bool &stop) -> int {
-            double tot[3] = {0.0, 0.0, 0.0};
-            for (int r = 0; r < world; ++r) {  // the global criterion: sums over every slab, in slab order
-                hipEvent_t ev = sl[r].summed[slot & 1];
-                const auto t0 = std::chrono::steady_clock::now();
-                for (;;) {  // short iterations: ask; long ones: sleep on it
-                    const hipError_t e = hipEventQuery(ev);
-                    if (e == hipSuccess) break;
-                    if (e != hipErrorNotReady) TVDN_HIP(e);
-                    (void)hipGetLastError();
-                    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
-                        TVDN_HIP(hipEventSynchronize(ev));
-                        break;
-                    }
-                }
-                const volatile double *pk = sl[r].peek + 4 * (slot & 1);
-                for (int j = 0; j < 3; ++j) tot[j] += pk[j];
-            }
-            const double delta = a->dtype == TVDN_F32 ? (double)delta_in_dtype<float>(tot) : delta_in_dtype<double>(tot);
-            stop = delta < a->stop;
-            return TVDN_OK;
-        };
-        std::vector<tvdn_many_args> before((size_t)world);
-        int slot = 0;
-        int rc = one(0, is_fista(0), ratios[0]);
-        if (!rc) rc = post(0);
+    } else if (a->use_stop && n_total > 0 && lag_on) {
+        const int rc = run_ruled(0);
         if (rc) return rc;
-        while (slot >= 0) {
-            const int ahead = slot + 1 < n_total ? slot + 1 : -1;
-            if (ahead >= 0) {
-                for (int r = 0; r < world; ++r) before[(size_t)r] = sl[r].roles;
-                rc = one(ahead, is_fista(ahead), ratios[ahead]);
-                if (!rc) rc = post(ahead);
-                if (rc) return rc;
-            }
-            ++ran_phase[is_fista(slot) ? 0 : 1];
-            tick(slot + 1);
-            bool st;
-            rc = rule_met(slot, st);
-            if (rc) return rc;
-            if (!st) {
-                slot = ahead;
-                continue;
-            }
-            // a FISTA-phase stop falls through to the unaccelerated phase (cyTVDN.py:189-201); a stop there ends the run
-            const int resume = (is_fista(slot) && a->n_plain > 0) ? a->n_fista : -1;
-            if (ahead >= 0 && ahead != resume) {  // iteration `ahead` ran in vain
-                for (int r = 0; r < world; ++r) sl[r].roles = before[(size_t)r];
-                --ran;
-                void_slots.push_back(ahead);
-                if (resume >= 0) {
-                    rc = one(resume, false, 0.0);
-                    if (!rc) rc = post(resume);
-                    if (rc) return rc;
-                }
-            }
-            slot = resume;
-        }
     } else {
         for (int i = 0; i < a->n_fista; ++i) {
             int rc = one(i, true, ratios[i]);

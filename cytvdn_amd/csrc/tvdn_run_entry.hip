@@ -102,7 +102,11 @@ extern "C" int tvdn_run(const tvdn_run_args *a)
     const auto t0 = std::chrono::steady_clock::now();
     tvdn_run_stats stats;
     std::memset(&stats, 0, sizeof stats);
-    const int rc = tvdn::run_impl(a, clk, stats);
+    int rc = tvdn::run_impl(a, clk, stats);
+    if (rc == tvdn::kRetryPlain) {  // a stopping rule met inside the iterations that followed the upload (tvdn_run.hip): plain order
+        std::memset(&stats, 0, sizeof stats);
+        rc = tvdn::run_impl(a, clk, stats, false);
+    }
     clk.mark("release");
     if (!rc && a->stats) {
         stats.total_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -119,6 +119,9 @@ struct RunClock {
 };
 
 // tvdn_run.hip: the resident run itself (one device or a device list)
-int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats);
+// `pipeline_with_rule`: a run with a stopping rule may start pipelined (first iterations behind the upload); kRetryPlain comes back
+// when the rule turned out to have been met inside those iterations: the caller runs it again without
+constexpr int kRetryPlain = 1 << 20;
+int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats, bool pipeline_with_rule = true);
 
 }  // namespace tvdn

@@ -528,8 +528,9 @@ int tvdn_run_workspace_bytes(const tvdn_run_args *args, int64_t *bytes);
  * datacube in, cyTVDN.py:145; recon out, :244-247): out[0] = rows per chunk, out[1] = iterations that follow the upload
  * chunk by chunk, out[2] = iterations that run over the download; all 0 = plain order (upload, iterate, download).  Pure
  * host arithmetic, the very function tvdn_run asks: cubes from 256 MiB and 32 rows on, runs from 4 iterations on, eight
- * chunks, at most 8 iterations at either end.  tvdn_run applies it to Jia-Zhao runs without stopping rule or MSE trace
- * whose first row is finite; recon is bit-identical to the plain order either way, the sums agree with it to rounding (1e-6
+ * chunks, at most 8 iterations at either end.  tvdn_run applies it to Jia-Zhao runs without MSE trace whose first row is
+ * finite -- with a stopping rule the start only (out[2] taken as 0; a rule met inside the iterations that followed the upload
+ * has the run done again in plain order) --; recon is bit-identical to the plain order either way, the sums agree with it to rounding (1e-6
  * relative: the rows' partial sums are added in another order).  Environment: TVDN_PIPELINE=0
  * (never), "rows,k_start,k_end" (forced). */
 int tvdn_pipeline_plan(int64_t n0, int32_t n_iters, int64_t cube_bytes, int32_t *out);

@@ -155,3 +155,61 @@ def test_calls_from_several_threads_share_what_runs_keep(oracle):
     _lib.check(_lib.lib().tvdn_release_cache())      # the kept kit goes back with the kept state
     got = cases[0][0](cases[0][1], cases[0][2], cases[0][3], FISTA=True, quiet=True)   # ... and the next run makes its own
     assert bits_equal(got[0], cases[0][5]["recon"])
+
+
+@pytest.mark.parametrize("shape,dtype,n_f,n_p", [((26, 4, 8, 12), np.float32, 14, 0), ((24, 5, 16), np.float64, 7, 8), ((28, 3, 8, 8), np.float32, 0, 14)])
+def test_a_rule_with_a_pipelined_start(oracle, monkeypatch, shape, dtype, n_f, n_p):
+    """With a stopping rule the START of a resident run is still pipelined (csrc/tvdn_run.hip): three iterations follow the upload
+    chunk by chunk, their sums are looked at when the last chunk has been swept, the rest of the run looks at every iteration one
+    behind.  A rule met INSIDE those first iterations sends the whole run round again in plain order (stats.pipelined says which
+    happened); whichever slot it fires at, the bits are the oracle's."""
+    import ctypes as C
+    from cytvdn_amd import _lib, synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=67, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
+    lam = mu / dt.type(32.0 if nd == 4 else 16.0)
+    its = [n_f, n_p] if (n_f and n_p) else (n_f or n_p)
+    fista = n_f > 0
+    n = n_f + n_p
+    free = oracle.denoise(x, mu, its, fista)
+    d64 = free["delta64"] / free["rnorm64"]
+    k0 = 3
+    thr = _thresholds(d64, sorted({0, 1, k0 - 1, k0, k0 + 1, (n_f or n_p) - 1, n - 1}))
+    thr[None] = 1e-30          # never met
+    assert len(thr) >= 5
+    monkeypatch.setenv("TVDN_PIPELINE", f"4,{k0},2")
+    seen_pipelined, seen_retry = 0, 0
+    for k, t in thr.items():
+        ref = oracle.denoise(x, mu, its, fista, stopping_relative_change=t)
+        a = _lib.RunArgs(dtype=_lib.dtype_code(dt), ndim=nd, bc_mode=2, device=0, n_fista=n_f, n_plain=n_p, use_stop=1, stop=float(t))
+        for i, s in enumerate(shape):
+            a.shape[i] = s
+        for q in range(nd):
+            a.clip[q] = float((1.0 / lam)[q])
+            a.lambda_mu[q] = float((lam / mu).astype(dt)[q])
+        recon = np.empty_like(x)
+        sums = np.zeros((n, 3))
+        phases = (C.c_int32 * 2)(0, 0)
+        st = _lib.RunStats()
+        a.data, a.recon_out, a.sums_out = x.ctypes.data, recon.ctypes.data, sums.ctypes.data
+        a.phase_iters = C.addressof(phases)
+        a.stats = C.addressof(st)
+        _lib.check(_lib.lib().tvdn_run(C.byref(a)))
+        assert bits_equal(recon, ref["recon"]), k
+        ran = ref["delta_recon"] != 0
+        assert np.array_equal(sums[:, 2] != 0, ran), (k, sums[:, 2], ref["delta_recon"])
+        assert phases[0] == int(ran[:n_f].sum()) and phases[1] == int(ran[n_f:].sum())
+        tol = 3e-7 if dt == np.float32 else 1e-11
+        np.testing.assert_allclose(sums[ran, 0], ref["b_norm64"][ran], rtol=tol)
+        np.testing.assert_allclose(sums[ran, 1] / sums[ran, 2], ref["delta64"][ran] / ref["rnorm64"][ran], rtol=tol)
+        first_stop = int(np.nonzero(ran)[0][-1]) if k is not None else n
+        if k is not None and k < k0:
+            assert st.pipelined == 0      # met inside the iterations that followed the upload: done again in plain order
+            seen_retry += 1
+        else:
+            assert st.pipelined == 1
+            seen_pipelined += 1
+        del first_stop
+    assert seen_pipelined >= 2 and seen_retry >= 1

@@ -26,7 +26,10 @@ kinds = {"resident, pipelined": ({}, {}), "resident, plain order": ({"TVDN_PIPEL
          # round 4: rows resident in HBM beside the streamed ones; a device list whose slabs are streamed; a stopping rule
          "streamed 4 rows x 3, rows resident": ({"TVDN_WAVEFRONT": "4,3"}, {}),
          "streamed device list [0, 0, 0]": ({"TVDN_WAVEFRONT": "4,3"}, {"device": [0, 0, 0]}),
-         "streamed with a stopping rule": ({"TVDN_STAGED": "8,1"}, {"stopping_relative_change": 1e-9})}
+         "streamed with a stopping rule": ({"TVDN_STAGED": "8,1"}, {"stopping_relative_change": 1e-9}),
+         # round 6: the resident run with a rule (host-visible sums mirror and two events per run), also over slabs
+         "resident with a stopping rule": ({}, {"stopping_relative_change": 1e-9}),
+         "device list [0, 0] with a stopping rule": ({}, {"device": [0, 0], "stopping_relative_change": 1e-9})}
 for name, (env, kw) in kinds.items():
     os.environ.update(env)
     for _ in range(3):
