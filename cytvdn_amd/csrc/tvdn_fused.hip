@@ -441,6 +441,9 @@ __global__ void __launch_bounds__(BLOCK) TVDN_OCCUPANCY fused_iter_kernel(FusedP
             const long long rown = row_slot<RING>(mn, p.ring) * SM;
             const long long rown_1 = RING ? row_slot<RING>(mn, p.ring_in1) * SM : rown, rown_2 = RING ? row_slot<RING>(mn, p.ring_in2) * SM : rown;
             const long long rown_o = RING ? row_slot<RING>(mn, p.ring_out) * SM : rown;
+#ifdef TVDN_ORIG_FIRST  // (measurement build: the data term's load issued first instead of last; no difference, profiles/r06_ab_inproc_order.jsonl)
+            const P og = ldb<T, VEC, kNtLoads>(p.orig + (RING ? row_slot<RING>(m, p.ring_orig) * SM : row), e0);
+#endif
             if (look) {
                 r_next = ldb<T, VEC, false>(wrapz ? p.wrap : p.r_in + rown, e0);
                 mv1 = ldb<T, VEC, kNtLoads>(sM.in1 + rown_1, e0);
@@ -457,7 +460,9 @@ __global__ void __launch_bounds__(BLOCK) TVDN_OCCUPANCY fused_iter_kernel(FusedP
                 load_pack<T, VEC, MODE, (kNtMask & 4) != 0, (kNtMask & 16) != 0>(lA, r_row, p.ax[iA], row_1, row_2, e0, eA_prev, eA_next);
             load_pack<T, VEC, MODE, (kNtMask & 1) != 0, (kNtMask & 8) != 0>(lB, r_row, p.ax[iB], row_1, row_2, e0, eB_prev, eB_next);
             load_contig<T, VEC, MODE, (kNtMask & 2) != 0>(lC, r_row, p.ax[iC], row_1, row_2, e0, eC_prev, eC_next);
+#ifndef TVDN_ORIG_FIRST
             const P og = ldb<T, VEC, kNtLoads>(p.orig + (RING ? row_slot<RING>(m, p.ring_orig) * SM : row), e0);
+#endif
 
             // (1) M-axis accumulator of the next row (look-ahead by one row)
             if (look) {

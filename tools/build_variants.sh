@@ -24,6 +24,9 @@ if [ "$1" = "aux" ]; then   # round 6: cache-policy bits of the sweep's buffer a
   build ld1 "-DTVDN_LD_AUX=1" &
   wait; ls -la tools/ubench/*st1*.so tools/ubench/*ld*.so; exit 0
 fi
+if [ "$1" = "order" ]; then   # round 6: the data term's load first instead of last
+  build origfirst "-DTVDN_ORIG_FIRST=1"; ls -la tools/ubench/*origfirst*.so; exit 0
+fi
 if [ "$1" = "ntmask" ]; then   # round 3: which accumulator-state loads stream past the L2 (csrc/tvdn_fused.hip, kNtMask)
   for m in 1 2 3 7 11 27 31 4 16; do build ntm$m "-DTVDN_NTMASK=$m" & done
   wait; ls -la tools/ubench/*ntm*.so; exit 0
