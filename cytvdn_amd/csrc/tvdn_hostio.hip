@@ -30,12 +30,12 @@ struct Lane {
 
 struct HostIo {
     int device = -1;
+    std::mutex mu;  // one transfer at a time per DEVICE: its bounce buffers are shared (devices have lanes, buffers and links of their own)
     std::atomic<bool> ready{false};
     Lane lane[kLanes];
     PinnedBuf pinned;  // the lanes' bounce buffers: ONE registration (never released: the process's staging for good)
 };
 
-static std::mutex g_io_mutex;       // one transfer at a time per process: the bounce buffers are shared
 static HostIo g_io[16];
 
 static std::atomic<int> g_lanes_cap{0};
@@ -92,7 +92,7 @@ static int lanes_wanted()
 // The bounce buffers of all lanes are ONE piece of anonymous memory with huge pages asked for, touched by many threads and
 // page-locked with one hipHostRegister (PinnedBuf): 256 MiB in a few ms where sixteen hipHostMalloc calls of 16 MiB took ~100 ms
 // of the first transfer of a process -- a third of what the first denoise4D of a process paid over the second (round 6,
-// profiles/r06_first_call.jsonl).  Same PCIe rate either way (profiles/r04_pin_probe.jsonl).  (g_io_mutex held.)
+// profiles/r06_first_call.jsonl).  Same PCIe rate either way (profiles/r04_pin_probe.jsonl).  (io.mu held.)
 static int io_init(HostIo &io, int device)
 {
     if (io.ready) return TVDN_OK;
@@ -128,7 +128,7 @@ void io_warm(int device)
 {
     if (device < 0 || device >= 16 || g_io[device].ready.load()) return;
     DeviceRestore restore;
-    std::lock_guard<std::mutex> lock(g_io_mutex);
+    std::lock_guard<std::mutex> lock(g_io[device].mu);
     if (io_init(g_io[device], device) != TVDN_OK) (void)hipGetLastError();
 }
 
@@ -180,7 +180,8 @@ static int transfer(bool up, void *dst, const void *src, size_t bytes, int devic
     TVDN_REQUIRE(bytes == 0 || (dst && src), "NULL buffer");
     if (bytes == 0) return TVDN_OK;
     DeviceRestore restore;
-    std::lock_guard<std::mutex> lock(g_io_mutex);
+    // (per device since round 6: the slabs of a device list on several GPUs go up and come home side by side, each over its own link)
+    std::lock_guard<std::mutex> lock(g_io[device].mu);
     // Only copies of a few hundred bytes go through the runtime's own path for pageable memory.  For anything larger the runtime
     // PINS THE CALLER'S PAGES IN PLACE for the transfer and keeps the pinned object in a small cache keyed by address and size
     // (DmaBlitManager::hsaCopyStagedOrPinned); when the memory behind that address has meanwhile been given back and mapped anew

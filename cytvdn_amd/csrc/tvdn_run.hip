@@ -488,19 +488,55 @@ int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats, bool 
         up.join();
         clk.mark("upload + first iterations");
     }
-    for (int r = 0; r < world && !pipelined; ++r) {
-        Slab &s = sl[r];
-        int rc = rows_to_device(s, s.orig, a->data);
-        if (rc) return rc;
-        TVDN_HIP(hipMemcpyAsync(s.recon(0), s.orig, (size_t)s.rows() * row_bytes, hipMemcpyDeviceToDevice, s.main));
-        if (want_mse) {
-            s.ref.device = s.mse.device = s.device;
-            TVDN_HIP(hipMalloc(&s.ref.p, (size_t)s.rows() * row_bytes));
-            rc = rows_to_device(s, (char *)s.ref.p, a->reference);
-            if (rc) return rc;
-            TVDN_HIP(hipMalloc(&s.mse.p, sizeof(double) * (size_t)(n_total + 1)));
-            TVDN_HIP(hipMemsetAsync(s.mse.p, 0, sizeof(double) * (size_t)(n_total + 1), s.main));
+    // Slabs on SEVERAL devices go up -- and come home, below -- side by side, a host thread per slab: every GPU has a link and
+    // staging lanes of its own (tvdn_hostio.hip), and one after the other the eight slabs of BASELINE config 4 (8 GiB each) would
+    // spend 1.3 s on the way up and as long on the way home where 0.2 s do, around 4.6 s of sweeps for 200 iterations.  One device
+    // (or TVDN_SLAB_IO_THREADS=0): in turn, as before; =1 forces the threads (tests on one GPU: same bytes, the lanes take turns).
+    bool io_threads = false;
+    for (int r = 1; r < world; ++r) io_threads = io_threads || sl[r].device != sl[0].device;
+    if (const char *e = getenv("TVDN_SLAB_IO_THREADS")) io_threads = world > 1 && atoi(e) != 0;
+    auto each_slab = [&](const std::function<int(int)> &fn) -> int {  // fn(r) for every slab; the first failure's status and text
+        if (!io_threads) {
+            for (int r = 0; r < world; ++r) {
+                const int rc = fn(r);
+                if (rc) return rc;
+            }
+            return TVDN_OK;
         }
+        std::vector<int> rcs((size_t)world, TVDN_OK);
+        std::vector<std::string> msgs((size_t)world);
+        std::vector<std::thread> th;
+        for (int r = 0; r < world; ++r)
+            th.emplace_back([&, r] {
+                rcs[(size_t)r] = fn(r);
+                if (rcs[(size_t)r]) msgs[(size_t)r] = tvdn_last_error();  // (the last-error text is per thread)
+            });
+        for (auto &t : th) t.join();
+        for (int r = 0; r < world; ++r)
+            if (rcs[(size_t)r]) {
+                set_error("%s", msgs[(size_t)r].c_str());
+                return rcs[(size_t)r];
+            }
+        return TVDN_OK;
+    };
+    if (!pipelined) {
+        const int rc_up = each_slab([&](int r) -> int {
+            Slab &s = sl[r];
+            int rc = rows_to_device(s, s.orig, a->data);
+            if (rc) return rc;
+            TVDN_HIP(hipMemcpyAsync(s.recon(0), s.orig, (size_t)s.rows() * row_bytes, hipMemcpyDeviceToDevice, s.main));
+            if (want_mse) {
+                s.ref.device = s.mse.device = s.device;
+                TVDN_HIP(hipMalloc(&s.ref.p, (size_t)s.rows() * row_bytes));
+                rc = rows_to_device(s, (char *)s.ref.p, a->reference);
+                if (rc) return rc;
+                TVDN_HIP(hipMalloc(&s.mse.p, sizeof(double) * (size_t)(n_total + 1)));
+                TVDN_HIP(hipMemsetAsync(s.mse.p, 0, sizeof(double) * (size_t)(n_total + 1), s.main));
+            }
+            return TVDN_OK;
+        });
+        if (rc_up) return rc_up;
+        TVDN_HIP(hipSetDevice(sl[0].device));
     }
     if (!pipelined) clk.mark("upload");
     // sum of squared errors over the own rows of every slab, into mse[slot]
@@ -903,15 +939,23 @@ int run_impl(const tvdn_run_args *a, RunClock &clk, tvdn_run_stats &stats, bool 
     if (n_total > 0) std::memset(a->sums_out, 0, sizeof(double) * 3 * (size_t)n_total);
     if (want_mse) std::memset(a->mse_out, 0, sizeof(double) * (size_t)(n_total + 1));
     std::unique_ptr<double[]> tmp(new double[3 * (size_t)(n_total > 0 ? n_total : 1) + (size_t)n_total + 1]);
+    {
+        const int cur_home = cur_of();
+        const int rc_home = each_slab([&](int r) -> int {  // every slab's rows, side by side where the slabs sit on several devices
+            Slab &s = sl[r];
+            TVDN_HIP(hipSetDevice(s.device));
+            TVDN_HIP(hipStreamSynchronize(s.main));
+            TVDN_HIP(hipStreamSynchronize(s.copy));
+            return recon_home ? TVDN_OK
+                              : tvdn_copy_to_host((char *)a->recon_out + (size_t)s.g0 * row_bytes, s.recon(cur_home) + (size_t)s.row_lo() * row_bytes,
+                                                  (size_t)(s.g1 - s.g0) * row_bytes, s.device);
+        });
+        if (rc_home) return rc_home;
+    }
     for (int r = 0; r < world; ++r) {
         Slab &s = sl[r];
         TVDN_HIP(hipSetDevice(s.device));
-        TVDN_HIP(hipStreamSynchronize(s.main));
-        TVDN_HIP(hipStreamSynchronize(s.copy));
-        int rc = recon_home ? TVDN_OK
-                            : tvdn_copy_to_host((char *)a->recon_out + (size_t)s.g0 * row_bytes, s.recon(cur_of()) + (size_t)s.row_lo() * row_bytes,
-                                                (size_t)(s.g1 - s.g0) * row_bytes, s.device);
-        if (rc) return rc;
+        int rc = TVDN_OK;
         if (n_total > 0) {
             rc = tvdn_copy_to_host(tmp.get(), s.sums.p, sizeof(double) * 3 * (size_t)n_total, s.device);  // (never the runtime's path for pageable memory: tvdn_hostio.hip)
             if (rc) return rc;

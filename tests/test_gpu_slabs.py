@@ -123,3 +123,28 @@ def test_entry_points_leave_the_current_device_alone(oracle):
     assert torch.cuda.current_device() == 0
     ref = oracle.denoise(x, mu, 4, True)["recon"]
     assert bits_equal(got[0], ref) and bits_equal(got2[0], ref)
+
+
+@pytest.mark.parametrize("shape,dtype,its,with_ref,bc", [((23, 4, 8, 16), np.float32, [4, 3], True, 2), ((18, 6, 16), np.float64, 6, False, 0)])
+def test_slabs_go_up_and_come_home_side_by_side(oracle, monkeypatch, shape, dtype, its, with_ref, bc):
+    """Slabs on several devices are uploaded and downloaded by a host thread each (csrc/tvdn_run.hip each_slab; the staging lanes
+    are per device).  On one GPU the threads are forced (TVDN_SLAB_IO_THREADS=1: the lanes of the one device take turns): same
+    bits as the run that moves the slabs in turn, and the oracle's."""
+    import cytvdn_amd as tv
+    from cytvdn_amd import synth
+    dt = np.dtype(dtype)
+    nd = len(shape)
+    x = synth.cube(shape, seed=23, dtype=dt) + dt.type(0.25)
+    refd = synth.cube(shape, seed=23, dtype=dt, kind="mean") if with_ref else None
+    mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
+    fn = tv.denoise4D if nd == 4 else tv.denoise3D
+    monkeypatch.setenv("TVDN_SLAB_IO_THREADS", "0")
+    in_turn = fn(x, mu, its, FISTA=True, reference_data=refd, BC_mode=bc, quiet=True, device=[0, 0, 0, 0])
+    monkeypatch.setenv("TVDN_SLAB_IO_THREADS", "1")
+    for _ in range(3):
+        got = fn(x, mu, its, FISTA=True, reference_data=refd, BC_mode=bc, quiet=True, device=[0, 0, 0, 0])
+        assert len(got) == len(in_turn)
+        for u, v in zip(got, in_turn):
+            assert bits_equal(u, v)
+    ref = oracle.denoise(x, mu, its, True, reference_data=refd, BC_mode=bc)
+    assert bits_equal(got[0], ref["recon"])
