@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Random runs with a stopping rule against the oracle: shapes, dtypes, schedules, boundary conditions, device lists, forced pipeline
-shapes, thresholds at random points of the free run's delta trace.  One line per failure, a summary at the end."""
+shapes, thresholds at random points of the free run's delta trace.  One line per failure, a summary at the end.  Test infrastructure
+(not collected by pytest: run by hand on a GPU box, `python3 tests/fuzz_stop_rule.py 1500 [seed]`; profiles/r06_rule_fuzz.txt)."""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import cytvdn_amd as tv
 from cytvdn_amd import synth
