@@ -73,6 +73,10 @@ struct FusedParams {
     int xcd;          // 1: remap workgroup ids so each XCD sweeps a contiguous run of tiles
     // patch order of the tiles of a cross-section (0 = plain order): patches of patch_a A-rows x patch_t tiles
     long long patch_a, patch_t, tiles_per_arow;
+    // column order (0 = off): every XCD sweeps a COLUMN of tiles through all marches, col_group tiles at a time -- march c + 1 of a tile is
+    // dispatched one round of the XCD's workgroups after march c, so the row that march c looks ahead at is read again (as march c + 1's
+    // first row) while it may still be in the XCD's L2
+    long long col_group, n_march;
     // row rings (RING instantiations only): row m of r_in lives at slot m % ring, of the in1 / in2 arrays at m % ring_in1 / m %
     // ring_in2, of r_out at m % ring_rout, of the out1 / out2 arrays at m % ring_out, of orig at m % ring_orig (one ring size for
     // all of them but orig in a plain streamed pass; a "ring" longer than the cube is an array: rows kept in HBM, swept in place)
@@ -325,8 +329,14 @@ __global__ void __launch_bounds__(BLOCK) TVDN_OCCUPANCY fused_iter_kernel(FusedP
     constexpr bool HAS_A = (NAX == 4);
 
     const long long L = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (long long)blockIdx.x;
-    const long long chunk_id = L / p.tiles;
+    long long chunk_id = L / p.tiles;
     long long tile = L % p.tiles;
+    if (p.col_group > 0) {
+        const long long per = (long long)gridDim.x / 8, x = L / per, l = L % per;  // (the XCD remap is on: this XCD's run of ids)
+        const long long blk = p.n_march * p.col_group, g = l / blk, r = l % blk;
+        chunk_id = r / p.col_group;
+        tile = x * (p.tiles / 8) + g * p.col_group + r % p.col_group;
+    }
     if (HAS_A && p.patch_a > 1) {
         // The workgroups resident on an XCD at one time cover ~128 consecutive tiles.  In plain order that is a run
         // of 512 KiB of B x C, which for long A-rows (config-4 planes: 256 KiB each) holds only two of them, so the
@@ -668,6 +678,13 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
             p.patch_a = ga; p.patch_t = gt; p.tiles_per_arow = tr;
         }
         p.xcd = e_xcd ? atoi(e_xcd) : (long_rows ? 0 : 1);
+        // measurement knob TVDN_COLGROUP=n (round 6; profiles/r06_ab_inproc_colgroup.jsonl): column order, n tiles at a time per XCD
+        p.col_group = 0;
+        p.n_march = n_march;
+        if (const char *e_col = getenv("TVDN_COLGROUP")) {
+            const long long cg = atoll(e_col);
+            if (cg > 0 && p.xcd && p.patch_a == 0 && grid % 8 == 0 && p.tiles % (8 * cg) == 0 && rows % chunk == 0) p.col_group = cg;
+        }
     }
     TVDN_REQUIRE(grid >= 1 && grid <= kMaxPartialBlocks, "fused grid %lld out of range (max %d)", grid, kMaxPartialBlocks);
     {
