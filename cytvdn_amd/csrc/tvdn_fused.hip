@@ -612,6 +612,9 @@ static int iterate_fused_impl(tvdn_ctx *ctx, const tvdn_iter_args *a, double *su
         p.ring = p.ring_in1 = p.ring_in2 = p.ring_rout = p.ring_out = p.ring_orig = (unsigned)a->shape[0];  // resident arrays (same rows, same bits)
     p.partials = ctx->partials;
 
+    // packs of 16 bytes where the last axis is a multiple of them, else one element per thread (5-7 % slower: 128 x 128 x 513 106
+    // against 114 Gvoxel-iters/s).  Packs of 8 bytes for float32 cubes with an even last axis (126, 510 channels) were built and
+    // measured in round 6: no faster than the scalar form (128 x 128 x 510: 102.7 against 106.6; 256 x 256 x 126 x 126: 89.8 / 90.3).
     const int vec = (al && (p.C % VMAX == 0)) ? VMAX : 1;
     TVDN_REQUIRE((unsigned long long)(p.A * p.B * p.C) * sizeof(T) < (1ull << 32),
                  "a row-plane (shape[1:]) of %lld elements is 4 GiB or more: positions inside a plane are 32-bit byte offsets",

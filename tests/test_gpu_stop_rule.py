@@ -213,3 +213,29 @@ def test_a_rule_with_a_pipelined_start(oracle, monkeypatch, shape, dtype, n_f, n
             seen_pipelined += 1
         del first_stop
     assert seen_pipelined >= 2 and seen_retry >= 1
+
+
+@pytest.mark.parametrize("shape,its,fista,bc", [((9, 6, 8, 10), [5, 4], True, 2), ((11, 7, 14), 9, True, 0), ((8, 5, 6, 126), 6, False, 2),
+                                               ((10, 12, 510), 7, True, 2), ((7, 3, 4, 2), 5, True, 0)])
+def test_an_even_last_axis_that_is_no_multiple_of_four(oracle, monkeypatch, shape, its, fista, bc):
+    """float32 cubes whose last axis is even but no multiple of four elements (126, 510 channels: detectors and spectrometers do
+    come like that) run on one element per thread (csrc/tvdn_fused.hip; packs of 8 bytes were measured no faster): the oracle's
+    bits -- resident, over slabs, and streamed."""
+    import cytvdn_amd as tv
+    from cytvdn_amd import synth
+    dt = np.dtype(np.float32)
+    nd = len(shape)
+    x = synth.cube(shape, seed=83, dtype=dt) + dt.type(0.25)
+    mu = np.array([1.0, 1.0, 0.5, 0.5][:nd] if nd == 4 else [1.0, 1.0, 0.5], dt)
+    fn = tv.denoise4D if nd == 4 else tv.denoise3D
+    ref = oracle.denoise(x, mu, its, fista, BC_mode=bc)
+    got = fn(x, mu, its, FISTA=fista, BC_mode=bc, quiet=True)
+    assert bits_equal(got[0], ref["recon"])
+    np.testing.assert_allclose(got[1], ref["b_norm64"], rtol=3e-7)
+    if shape[0] >= 8:
+        slabs = fn(x, mu, its, FISTA=fista, BC_mode=bc, quiet=True, device=[0, 0, 0])
+        assert bits_equal(slabs[0], ref["recon"])
+        if bc == 2:
+            monkeypatch.setenv("TVDN_WAVEFRONT", "4,3")
+            streamed = fn(x, mu, its, FISTA=fista, BC_mode=bc, quiet=True)
+            assert bits_equal(streamed[0], ref["recon"])
