@@ -24,7 +24,7 @@
 //   * Equal granules.  Every granule of a block has the same size and the block is rounded up to a whole number of them: on ROCm
 //     7.2 a reservation mapped from handles of different sizes confuses the runtime's own address lookups -- hipMemcpy /
 //     hipMemset into the part behind the odd handle land elsewhere while kernels see the right bytes (tools/ubench/
-//     vmm_memset.hip).  1 GiB from 8 GiB on, else the power of two nearest below an eighth of the block, at least 64 MiB.
+//     vmm_memset.hip).  1 GiB from 8 GiB on, 64 MiB below (granule_for).
 //   * Stale translations.  On ROCm 7.2 hipMemUnmap / hipMemMap do not make the GPU forget the old translation of an address:
 //     kernels and copies go on using the physical memory that WAS mapped there (tools/ubench/vmm_remap_check.hip), also after
 //     hipMemAddressFree + a new reservation that overlaps the old one.  A hipFree of any plain block flushes the TLBs
@@ -175,10 +175,14 @@ hipError_t tlb_flush()
     return fault(e, "TLB flush: hipMalloc + hipFree", nullptr, bytes);
 }
 
+// 1 GiB from 8 GiB on, 64 MiB below.  (Until round 6 "the power of two nearest below an eighth of the block": a 4.5 GiB state then
+// sat on ten granules of 512 MiB, one per array, and its sweep time was one draw -- eight seeded draws side by side in one process,
+// tools/granule_size_ab.py, profiles/r06_granule_size_seeds.jsonl: 3-D plain 512^3 0.811 ... 0.865 ms on 512 MiB granules (mean
+// 0.832), 0.815 ... 0.829 on 64 MiB ones (mean 0.820); 128 x 64 x 128 x 128 (7.7 GiB): 1.408 ... 1.430 / mean 1.417 against
+// 1.404 ... 1.414 / 1.408.  From 15 GiB on the 1 GiB granules are as good or better: 128^4 2.826 ... 2.839 against 2.806 ... 2.897.)
 size_t granule_for(size_t bytes)
 {
-    size_t G = 1024 * kMiB;
-    while (G > 64 * kMiB && G > bytes / 8) G /= 2;
+    const size_t G = bytes >= (size_t)8192 * kMiB ? 1024 * kMiB : 64 * kMiB;
     return env_mib("TVDN_GRANULE_MIB", G / kMiB) * kMiB;
 }
 
@@ -389,7 +393,7 @@ hipError_t draw_granules(size_t need, size_t G, int device, double budget_s, std
         return e != hipSuccess ? e : hipErrorOutOfMemory;
     }
     {
-        static std::mt19937_64 rng(0x9e3779b97f4a7c15ULL);  // a fixed sequence per process: runs repeat
+        static std::mt19937_64 rng(0x9e3779b97f4a7c15ULL ^ (unsigned long long)env_mib("TVDN_SPREAD_SEED", 0));  // a fixed sequence per process: runs repeat (the env: measurement, other draws)
         std::lock_guard<std::mutex> lk(g_mu);
         std::shuffle(pool.begin(), pool.end(), rng);
     }
@@ -409,7 +413,7 @@ hipError_t draw_granules(size_t need, size_t G, int device, double budget_s, std
 hipError_t map_block(VmmBlock &b)
 {
     {
-        static std::mt19937_64 rng(0x7476646eULL);
+        static std::mt19937_64 rng(0x7476646eULL ^ (unsigned long long)env_mib("TVDN_SPREAD_SEED", 0));
         std::lock_guard<std::mutex> lk(g_mu);
         std::shuffle(b.handles.begin(), b.handles.end(), rng);
     }
